@@ -1,0 +1,176 @@
+/*
+ * libmocogan_hip.so -- C ABI of the MI355X (gfx950) MoCoGAN training hot path.
+ *
+ * The reference (raahii/mocogan-chainer) has no FFI: its hot path sits behind the Python
+ * classes of model/net.py and model/updater.py and delegates all arithmetic to Chainer
+ * 3.1.0 links/functions.  Each entry point below replaces one family of those Chainer calls
+ * (the reference call site is cited on every declaration); the build's own model/net.py and
+ * model/updater.py call them through ctypes with raw device pointers.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative mcg_status; nothing throws;
+ *   - all pointers are caller-owned DEVICE pointers (fp32 unless noted); no hidden allocation:
+ *     scratch is passed in explicitly and sized with the *_workspace_bytes queries;
+ *   - `stream` is a hipStream_t passed as void*; calls are asynchronous on it;
+ *   - activations are channels-last fp32, [N][T][H][W][C] with C padded to a multiple of 4
+ *     (2-D tensors have T = 1); padded channels hold zeros;
+ *   - conv / deconv weights use ONE layout for every layer: w[Co][kt][kh][kw][Ci] with
+ *     kh = kw = 4 and kt in {1,4}, "Co" being the channel count on the small-extent side and
+ *     "Ci" (padded to a multiple of 4) the one on the large-extent side.  A Chainer
+ *     Convolution weight (Cout,Cin,k..) and a Chainer Deconvolution weight (Cin,Cout,k,k) both
+ *     map to it with Co = first axis.
+ */
+#ifndef MOCOGAN_HIP_H
+#define MOCOGAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum mcg_status {
+    MCG_OK = 0,
+    MCG_ERR_BAD_ARG = -1,      /* null pointer, non power-of-two extent, unpadded channel count ... */
+    MCG_ERR_UNSUPPORTED = -2,  /* geometry outside the k4/s2/p1 family this library implements */
+    MCG_ERR_LAUNCH = -3,       /* hipGetLastError() != hipSuccess after the launch */
+    MCG_ERR_WORKSPACE = -4     /* workspace too small */
+} mcg_status;
+
+enum { MCG_ACT_NONE = 0, MCG_ACT_RELU = 1, MCG_ACT_LRELU = 2, MCG_ACT_TANH = 3 };
+
+/* Geometry of one 4x4(x4) stride-(1,2,2) pad-(0,1,1) convolution, i.e. every strided layer of
+ * the reference: L.ConvolutionND / L.Convolution2D dc1..dc4 (model/net.py:133-136,174-177) and,
+ * read backwards, L.DeconvolutionND dc2..dc5 (model/net.py:45-48).
+ * "x" is the large side [N][Ti][Hi][Wi][Ci]; "y" the small side [N][To][Ho][Wo][Co] with
+ * To = Ti - kt + 1, Ho = Hi/2, Wo = Wi/2 (Ho, Wo powers of two).  y is always dense.  The
+ * start of batch item n of x is x + (n % x_perm_n) * x_stride0 + (n / x_perm_n) * x_stride1
+ * elements (x_perm_n = 0 means plain n * x_stride0): this expresses both the frame-t view
+ * x[:, :, t] of a clip tensor (model/updater.py:97,107) and the (T,N)->(N,T) transpose of
+ * model/updater.py:102 without a copy. */
+typedef struct mcg_conv_geom {
+    int32_t N, Ti, Hi, Wi, Ci;
+    int32_t To, Ho, Wo, Co;
+    int32_t kt;
+    int32_t x_perm_n;
+    int64_t x_stride0, x_stride1;
+} mcg_conv_geom;
+
+int mcg_version(void);
+/* test / tuning hook: force the GEMM block tile of the conv kernels (0 = auto, 1 = 128x128,
+ * 2 = 128x64, 3 = 64x64).  Process-global; not part of the reference-facing surface. */
+void mcg_set_tile_override(int tile);
+
+/* ---- implicit-GEMM convolution on the fp32 MFMA (v_mfma_f32_32x32x2_f32) ------------------- */
+
+/* y = conv(x, w) + bias.  Replaces the forward of L.ConvolutionND/L.Convolution2D
+ * (model/net.py:149-155,190-196) and the input-gradient of L.DeconvolutionND (autograd of
+ * model/net.py:111-114).  bias may be NULL. */
+int mcg_conv_fprop(const mcg_conv_geom* g, const float* x, const float* w, const float* bias,
+                   float* y, void* stream);
+
+/* x (+)= conv_transpose(y, w) + bias; optional tanh.  Replaces the forward of
+ * L.DeconvolutionND dc2..dc5 (model/net.py:111-114, tanh at :114) and the input-gradient of
+ * the convolutions (loss.backward() in model/updater.py:111-113).  accumulate != 0 adds into x
+ * (used to add D_I's frame-t gradient onto D_V's clip gradient).  bias may be NULL. */
+int mcg_conv_dgrad(const mcg_conv_geom* g, const float* y, const float* w, const float* bias,
+                   float* x, int act, int accumulate, void* stream);
+
+/* dw += sum over pixels y (x) x.  Weight gradient of both layer kinds (model/updater.py:111-113).
+ * dw must have been zeroed (or hold the other pass' gradient): the kernel adds with fp32
+ * atomics (split-K over pixels). */
+int mcg_conv_wgrad(const mcg_conv_geom* g, const float* x, const float* y, float* dw, void* stream);
+
+/* ---- full-window layers: D's dc5 (model/net.py:137,178) and G's dc1 (model/net.py:44) ------ */
+/* x is [M][K] (one dense window per row), y is [M][Co], w is [Co][K]. */
+int mcg_fc_fprop(int M, int K, int Co, const float* x, const float* w, const float* bias,
+                 float* y, void* stream);
+/* x = y w (+ bias[k % bias_period]) */
+int mcg_fc_dgrad(int M, int K, int Co, const float* y, const float* w, const float* bias,
+                 int bias_period, float* x, void* stream);
+/* dw += y^T x */
+int mcg_fc_wgrad(int M, int K, int Co, const float* x, const float* y, float* dw, void* stream);
+
+/* ---- BatchNormalization (train mode) + activation + add_noise ------------------------------ */
+/* L.BatchNormalization (model/net.py:50-53,139-141,180-182; Chainer decay 0.9, eps 2e-5).
+ * y is [M][C].  stats is a caller buffer of 4*C floats: mean, inv_std, scale = gamma*inv_std,
+ * shift = beta - mean*scale (kept for the backward pass).  avg_mean/avg_var (may be NULL) get
+ * Chainer's running update.  workspace: mcg_bn_workspace_bytes(M, C). */
+int64_t mcg_bn_workspace_bytes(int64_t M, int C);
+int mcg_bn_stats(int64_t M, int C, const float* y, const float* gamma, const float* beta,
+                 float* stats, float* avg_mean, float* avg_var, float eps, float decay,
+                 void* workspace, void* stream);
+
+/* out = act(y * scale + shift) + noise.  scale_shift = stats + 2*C or NULL (identity).
+ * noise: `addend` when non-NULL (parity mode: the caller's pre-scaled sigma*randn tensor),
+ * else sigma * N(0,1) from Philox4x32-10 keyed by (seed, stream_id) when sigma > 0, else none;
+ * generated noise is added to channels < c_valid only (padded channels stay exactly zero).
+ * Replaces F.relu/F.leaky_relu(bn(.)) followed by add_noise (model/net.py:10-15,110-113,
+ * 148-155,189-196). */
+int mcg_bn_act_fwd(int64_t M, int C, int c_valid, const float* y, const float* scale_shift, int act,
+                   const float* addend, float sigma, uint64_t seed, uint64_t stream_id,
+                   float* out, void* stream);
+
+/* Backward of the line above + BN.  g_out: gradient w.r.t. `out`.  Computes
+ * g_bn = g_out * act'(y*scale+shift) (the mask is recomputed from the SAVED scale/shift, i.e.
+ * the forward's output sign, as Chainer's retained-output backward does), then
+ * gx = gamma*inv_std * (g_bn - (x_hat * ggamma + gbeta) / M) with the CURRENT gamma (quirk Q5).
+ * dgamma/dbeta (may be NULL: gradient through D for G's loss) are accumulated (+=).
+ * stats == NULL means "no BN": gx = g_out * act'(y).  act == MCG_ACT_TANH uses y as the saved
+ * tanh OUTPUT.  in-place (gx == g_out) is allowed.  workspace: mcg_bn_workspace_bytes(M, C). */
+int mcg_bn_act_bwd(int64_t M, int C, const float* g_out, const float* y, const float* stats,
+                   const float* gamma, int act, float* gx, float* dgamma, float* dbeta,
+                   void* workspace, void* stream);
+
+/* db += column sums of g [M][C] (bias gradient of every conv/deconv). */
+int mcg_colsum_acc(int64_t M, int C, const float* g, float* db, void* workspace, void* stream);
+
+/* ---- layout ------------------------------------------------------------------------------- */
+/* out[N][T][H][W][Cp] = x[N][C][T][H][W] (+ noise as above); padded channels = 0.  Turns the
+ * reference-layout real clip batch (model/updater.py:89-90) into D's first conv input. */
+int mcg_pack_clip(int N, int C, int Cp, int T, int HW, const float* x, const float* addend,
+                  float sigma, uint64_t seed, uint64_t stream_id, float* out, void* stream);
+/* x[N][C][T][HW] = in[N][T][HW][Cp] (first C channels) */
+int mcg_unpack_clip(int N, int C, int Cp, int T, int HW, const float* in, float* x, void* stream);
+/* g_frames[(t*N+n)][HW][Cp] = g_clip[n][t][HW][Cp] * (1 - x_clip^2): tanh backward fused with the
+ * (N,T)->(T,N) transpose back to generator frame order (autograd of model/net.py:114-115,
+ * model/updater.py:102). */
+int mcg_tanh_bwd_to_frames(int N, int T, int64_t frame_elems, const float* g_clip,
+                           const float* x_clip, float* g_frames, void* stream);
+
+/* ---- GRU motion-code recurrence (L.StatelessGRU, model/net.py:39-41,61-81) ------------------ */
+/* params: the six Linear links packed as [W_r|U_r|W_z|U_z|W|U], each (weights row-major
+ * [dim_zm][in], then bias[dim_zm]); in = dim_zl + dim_zm for W_*, dim_zm for U_*.
+ * h0 [N][dim_zm]; e [T][N][dim_zm]; labels [N] int32 (ignored when dim_zl == 0); zc [N][dim_zc].
+ * z [T*N][dim_zc + dim_zm] = concat(tile(zc), zm)  (model/net.py:102-107).
+ * saved: [T][N][4*dim_zm] (r, z, h_bar, h_prev) for the backward pass. */
+int mcg_gru_seq_fwd(int N, int T, int dim_zm, int dim_zl, int dim_zc, const float* params,
+                    const float* h0, const float* e, const int32_t* labels, const float* zc,
+                    float* z, float* saved, void* stream);
+/* gz [T*N][dim_zc+dim_zm]: gradient w.r.t. z.  dparams += gradient of all GRU parameters. */
+int mcg_gru_seq_bwd(int N, int T, int dim_zm, int dim_zl, int dim_zc, const float* params,
+                    const float* e, const int32_t* labels, const float* saved, const float* gz,
+                    float* dparams, void* stream);
+
+/* ---- losses (model/updater.py:21-63) -------------------------------------------------------- */
+/* logits are [N][C] (C = 1, or 1+K for infogan).  loss_out[0] = loss.  with_ce: add the
+ * categorical terms (infogan and VideoDiscriminator only, model/updater.py:28-37). */
+int mcg_loss_dis(int N, int C, const float* y_real, const float* y_fake, const int32_t* t_real,
+                 const int32_t* t_fake, int with_ce, float* loss_out, float* g_real, float* g_fake,
+                 void* stream);
+int mcg_loss_gen(int N, int C, const float* y_fake_i, const float* y_fake_v, const int32_t* t_fake,
+                 int with_ce, float* loss_out, float* g_i, float* g_v, void* stream);
+
+/* ---- optimiser (train.py:93-101: Chainer Adam + WeightDecay hook) --------------------------- */
+/* g += wd*p; m += (1-b1)(g-m); v += (1-b2)(g*g-v); p -= lr_t * m / (sqrt(v) + eps), with
+ * lr_t = alpha*sqrt(1-b2^t)/(1-b1^t) computed by the caller in double. */
+int mcg_adam_wd(int64_t n, float* p, const float* g, float* m, float* v, float lr_t, float beta1,
+                float beta2, float eps, float wd, void* stream);
+
+/* out[i] = sigma * N(0,1), the same Philox stream mcg_bn_act_fwd / mcg_pack_clip draw from. */
+int mcg_randn(int64_t n, float sigma, uint64_t seed, uint64_t stream_id, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOCOGAN_HIP_H */

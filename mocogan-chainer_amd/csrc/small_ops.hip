@@ -1,0 +1,735 @@
+// HBM-bound and tiny kernels of the MoCoGAN step for gfx950: BatchNorm statistics / apply /
+// backward fused with the activations and add_noise, Philox noise, layout packing, the
+// full-window (1x1-output) layers, the fused GRU recurrence, the GAN losses and Chainer-Adam.
+// All tensors are channels-last fp32 with C % 4 == 0, so every kernel moves 16 bytes per lane.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mocogan_hip.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int NT = 256;
+constexpr int MAX_PART = 512;        // max partial-reduction blocks (workspace sizing)
+constexpr float LRELU_SLOPE = 0.2f;  // model/net.py:149-155,190-196
+
+int launch_status() { return hipGetLastError() == hipSuccess ? MCG_OK : MCG_ERR_LAUNCH; }
+
+// ------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., Random123) + Box-Muller.  counter = (idx_lo, idx_hi, stream_lo,
+// stream_hi), key = (seed_lo, seed_hi); one call yields the 4 normals of one float4.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ f32x4 randn4(uint64_t idx4, uint64_t seed, uint64_t stream_id) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)idx4, (uint32_t)(idx4 >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32),
+                  (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    const float S = 2.3283064365386963e-10f;   // 2^-32
+    float u1 = ((float)r[0] + 1.0f) * S, u2 = (float)r[1] * S;
+    float u3 = ((float)r[2] + 1.0f) * S, u4 = (float)r[3] * S;
+    u1 = fminf(u1, 1.0f); u3 = fminf(u3, 1.0f);
+    float ra = sqrtf(-2.0f * logf(u1)), rb = sqrtf(-2.0f * logf(u3));
+    float s1, c1, s2, c2;
+    sincospif(2.0f * u2, &s1, &c1);
+    sincospif(2.0f * u4, &s2, &c2);
+    f32x4 o = {ra * c1, ra * s1, rb * c2, rb * s2};
+    return o;
+}
+
+__device__ __forceinline__ float act_fwd(float v, int act) {
+    if (act == MCG_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == MCG_ACT_LRELU) return v >= 0.f ? v : v * LRELU_SLOPE;
+    if (act == MCG_ACT_TANH) return tanhf(v);
+    return v;
+}
+// derivative factor given the pre-activation value v (Chainer masks on the retained output,
+// whose sign equals the pre-activation's sign for relu / leaky_relu)
+__device__ __forceinline__ float act_mask(float v, int act) {
+    if (act == MCG_ACT_RELU) return v > 0.f ? 1.f : 0.f;
+    if (act == MCG_ACT_LRELU) return v < 0.f ? LRELU_SLOPE : 1.f;
+    return 1.f;
+}
+
+// ------------------------------------------------------------------------------------------
+// per-channel partial sums over rows of a [M][C] tensor.
+// MODE 0: (sum y, sum y^2)           -> BN statistics
+// MODE 1: (sum g_bn, sum g_bn*x_hat) -> BN backward
+// MODE 2: (sum g, unused)            -> bias gradient
+// Thread layout: C4 = C/4 float4 columns, NT/C4 row lanes per pass; the block's row lanes are
+// combined through LDS; part[block][2][C].
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(NT) void col_partial_kernel(long long M, int C, long long rows_per_block,
+                                                         const float* __restrict__ a, const float* __restrict__ y,
+                                                         const float* __restrict__ stats, int act,
+                                                         float* __restrict__ part) {
+    __shared__ f32x4 red[2][NT];
+    const int C4 = C >> 2;
+    const int c4 = threadIdx.x % C4, rl = threadIdx.x / C4, RL = NT / C4;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    long long r1 = r0 + rows_per_block; if (r1 > M) r1 = M;
+    f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
+    f32x4 mean = {0, 0, 0, 0}, istd = {1, 1, 1, 1}, sc = {1, 1, 1, 1}, sh = {0, 0, 0, 0};
+    if (MODE == 1 && stats && rl < RL) {
+        mean = *reinterpret_cast<const f32x4*>(stats + c4 * 4);
+        istd = *reinterpret_cast<const f32x4*>(stats + C + c4 * 4);
+        sc = *reinterpret_cast<const f32x4*>(stats + 2 * C + c4 * 4);
+        sh = *reinterpret_cast<const f32x4*>(stats + 3 * C + c4 * 4);
+    }
+    if (rl < RL) {
+        for (long long r = r0 + rl; r < r1; r += RL) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(a + r * C + c4 * 4);
+            if (MODE == 0) { s0 += v; s1 += v * v; }
+            else if (MODE == 2) { s0 += v; }
+            else {
+                f32x4 yy = *reinterpret_cast<const f32x4*>(y + r * C + c4 * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float gb = v[i] * act_mask(fmaf(yy[i], sc[i], sh[i]), act);
+                    s0[i] += gb; s1[i] += gb * (yy[i] - mean[i]) * istd[i];
+                }
+            }
+        }
+    }
+    red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
+    __syncthreads();
+    if (threadIdx.x < C4) {
+        for (int k = 1; k < RL; ++k) { s0 += red[0][k * C4 + c4]; s1 += red[1][k * C4 + c4]; }
+        float* p = part + (long long)blockIdx.x * 2 * C;
+        *reinterpret_cast<f32x4*>(p + c4 * 4) = s0;
+        *reinterpret_cast<f32x4*>(p + C + c4 * 4) = s1;
+    }
+}
+
+// C may exceed NT*4/…: handled by requiring C4 <= NT (C <= 1024)
+struct PartPlan { int blocks; long long rows_per_block; };
+PartPlan plan_partial(long long M, int C) {
+    int RL = NT / (C >> 2);
+    long long min_rows = (long long)RL * 8;                   // >= 8 rows per thread
+    long long b = (M + min_rows - 1) / min_rows;
+    if (b > MAX_PART) b = MAX_PART;
+    if (b < 1) b = 1;
+    PartPlan p;
+    p.rows_per_block = (M + b - 1) / b;
+    p.blocks = (int)((M + p.rows_per_block - 1) / p.rows_per_block);
+    return p;
+}
+
+__global__ void bn_stats_finalize_kernel(int nblocks, int C, double inv_m, double adjust, const float* __restrict__ part,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                         float* __restrict__ stats, float* avg_mean, float* avg_var, float eps, float decay) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0, ss = 0;
+    for (int b = 0; b < nblocks; ++b) { s += part[(long long)b * 2 * C + c]; ss += part[(long long)b * 2 * C + C + c]; }
+    double mean = s * inv_m;
+    double var = ss * inv_m - mean * mean;
+    if (var < 0) var = 0;
+    var += eps;                                            // Chainer 3.1: var += eps before everything else
+    float istd = (float)(1.0 / sqrt(var));
+    float scale = gamma[c] * istd;
+    stats[c] = (float)mean;
+    stats[C + c] = istd;
+    stats[2 * C + c] = scale;
+    stats[3 * C + c] = fmaf(-(float)mean, scale, beta[c]);
+    if (avg_mean) {
+        avg_mean[c] = avg_mean[c] * decay + (1.f - decay) * (float)mean;
+        avg_var[c] = avg_var[c] * decay + (1.f - decay) * (float)(adjust * var);
+    }
+}
+
+// coef[0..C) = gamma*inv_std, [C..2C) = ggamma/M, [2C..3C) = gbeta/M ; dgamma/dbeta accumulated
+__global__ void bn_bwd_finalize_kernel(int nblocks, int C, double inv_m, const float* __restrict__ part,
+                                       const float* __restrict__ stats, const float* __restrict__ gamma,
+                                       float* __restrict__ coef, float* dgamma, float* dbeta) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double gb = 0, gg = 0;
+    for (int b = 0; b < nblocks; ++b) { gb += part[(long long)b * 2 * C + c]; gg += part[(long long)b * 2 * C + C + c]; }
+    coef[c] = gamma[c] * stats[C + c];
+    coef[C + c] = (float)(gg * inv_m);
+    coef[2 * C + c] = (float)(gb * inv_m);
+    if (dgamma) dgamma[c] += (float)gg;
+    if (dbeta) dbeta[c] += (float)gb;
+}
+
+__global__ void colsum_finalize_kernel(int nblocks, int C, const float* __restrict__ part, float* db) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0;
+    for (int b = 0; b < nblocks; ++b) s += part[(long long)b * 2 * C + c];
+    db[c] += (float)s;
+}
+
+// out = act(y*scale+shift) + noise
+__global__ __launch_bounds__(NT) void bn_act_fwd_kernel(long long n4, int C, int c_valid, const float* __restrict__ y,
+                                                        const float* __restrict__ ss, int act,
+                                                        const float* __restrict__ addend, float sigma,
+                                                        uint64_t seed, uint64_t stream_id, float* __restrict__ out) {
+    const int C4 = C >> 2;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long long)gridDim.x * NT) {
+        int c4 = (int)(i % C4);
+        f32x4 v = *reinterpret_cast<const f32x4*>(y + i * 4);
+        if (ss) {
+            f32x4 sc = *reinterpret_cast<const f32x4*>(ss + c4 * 4);
+            f32x4 sh = *reinterpret_cast<const f32x4*>(ss + C + c4 * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fmaf(v[k], sc[k], sh[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = act_fwd(v[k], act);
+        if (addend) {
+            v += *reinterpret_cast<const f32x4*>(addend + i * 4);
+        } else if (sigma > 0.f) {
+            f32x4 z = randn4((uint64_t)i, seed, stream_id);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (c4 * 4 + k < c_valid) v[k] = fmaf(sigma, z[k], v[k]);
+        }
+        *reinterpret_cast<f32x4*>(out + i * 4) = v;
+    }
+}
+
+// gx = coef0 * (g*mask - x_hat*coef1 - coef2)    (BN)   or   gx = g*mask(y) / g*(1-y^2)  (no BN)
+__global__ __launch_bounds__(NT) void bn_act_bwd_apply_kernel(long long n4, int C, const float* __restrict__ g,
+                                                              const float* __restrict__ y, const float* __restrict__ stats,
+                                                              const float* __restrict__ coef, int act, float* __restrict__ gx) {
+    const int C4 = C >> 2;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long long)gridDim.x * NT) {
+        int c4 = (int)(i % C4);
+        f32x4 gv = *reinterpret_cast<const f32x4*>(g + i * 4);
+        f32x4 yv = *reinterpret_cast<const f32x4*>(y + i * 4);
+        f32x4 o;
+        if (stats) {
+            f32x4 mean = *reinterpret_cast<const f32x4*>(stats + c4 * 4);
+            f32x4 istd = *reinterpret_cast<const f32x4*>(stats + C + c4 * 4);
+            f32x4 sc = *reinterpret_cast<const f32x4*>(stats + 2 * C + c4 * 4);
+            f32x4 sh = *reinterpret_cast<const f32x4*>(stats + 3 * C + c4 * 4);
+            f32x4 k0 = *reinterpret_cast<const f32x4*>(coef + c4 * 4);
+            f32x4 k1 = *reinterpret_cast<const f32x4*>(coef + C + c4 * 4);
+            f32x4 k2 = *reinterpret_cast<const f32x4*>(coef + 2 * C + c4 * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float gb = gv[k] * act_mask(fmaf(yv[k], sc[k], sh[k]), act);
+                float xh = (yv[k] - mean[k]) * istd[k];
+                o[k] = k0[k] * (gb - xh * k1[k] - k2[k]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                o[k] = act == MCG_ACT_TANH ? gv[k] * (1.f - yv[k] * yv[k]) : gv[k] * act_mask(yv[k], act);
+        }
+        *reinterpret_cast<f32x4*>(gx + i * 4) = o;
+    }
+}
+
+int ew_grid(long long n4) {
+    long long b = (n4 + NT - 1) / NT;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// ------------------------------------------------------------------------------------------
+// layout kernels
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void pack_clip_kernel(int N, int C, int Cp, int T, int HW, const float* __restrict__ x,
+                                                       const float* __restrict__ addend, float sigma, uint64_t seed,
+                                                       uint64_t stream_id, float* __restrict__ out) {
+    const long long npix = (long long)N * T * HW;
+    const int Cp4 = Cp >> 2;
+    for (long long p = (long long)blockIdx.x * NT + threadIdx.x; p < npix; p += (long long)gridDim.x * NT) {
+        int hw = (int)(p % HW);
+        long long q = p / HW;
+        int t = (int)(q % T), n = (int)(q / T);
+        const float* src = x + ((long long)n * C * T + t) * HW + hw;
+        for (int c4 = 0; c4 < Cp4; ++c4) {
+            f32x4 v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int c = c4 * 4 + k;
+                v[k] = c < C ? src[(long long)c * T * HW] : 0.f;
+            }
+            long long i4 = p * Cp4 + c4;
+            if (addend) v += *reinterpret_cast<const f32x4*>(addend + i4 * 4);
+            else if (sigma > 0.f) {
+                f32x4 z = randn4((uint64_t)i4, seed, stream_id);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (c4 * 4 + k < C) v[k] = fmaf(sigma, z[k], v[k]);
+            }
+            *reinterpret_cast<f32x4*>(out + i4 * 4) = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(NT) void unpack_clip_kernel(int N, int C, int Cp, int T, int HW, const float* __restrict__ in,
+                                                         float* __restrict__ x) {
+    const long long npix = (long long)N * T * HW;
+    for (long long p = (long long)blockIdx.x * NT + threadIdx.x; p < npix; p += (long long)gridDim.x * NT) {
+        int hw = (int)(p % HW);
+        long long q = p / HW;
+        int t = (int)(q % T), n = (int)(q / T);
+        for (int c = 0; c < C; ++c) x[(((long long)n * C + c) * T + t) * HW + hw] = in[p * Cp + c];
+    }
+}
+
+__global__ __launch_bounds__(NT) void tanh_bwd_to_frames_kernel(int N, int T, long long fe4, const float* __restrict__ g_clip,
+                                                                const float* __restrict__ x_clip, float* __restrict__ g_frames) {
+    const long long n4 = (long long)N * T * fe4;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long long)gridDim.x * NT) {
+        long long e = i % fe4, f = i / fe4;      // f = clip-order frame index n*T + t
+        int t = (int)(f % T), n = (int)(f / T);
+        f32x4 g = *reinterpret_cast<const f32x4*>(g_clip + i * 4);
+        f32x4 xv = *reinterpret_cast<const f32x4*>(x_clip + i * 4);
+        f32x4 o = g * (1.f - xv * xv);
+        *reinterpret_cast<f32x4*>(g_frames + (((long long)t * N + n) * fe4 + e) * 4) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// full-window layers
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void fc_fprop_kernel(int K, int Co, const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ y) {
+    __shared__ float red[NT / 64];
+    const int m = blockIdx.x, co = blockIdx.y;
+    const float* xr = x + (long long)m * K;
+    const float* wr = w + (long long)co * K;
+    float s = 0.f;
+    for (int k = threadIdx.x * 4; k < K; k += NT * 4) {
+        f32x4 a = *reinterpret_cast<const f32x4*>(xr + k), b = *reinterpret_cast<const f32x4*>(wr + k);
+        s += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < NT / 64; ++i) t += red[i];
+        y[(long long)m * Co + co] = t + (bias ? bias[co] : 0.f);
+    }
+}
+
+__global__ __launch_bounds__(NT) void fc_dgrad_kernel(int K, int Co, const float* __restrict__ y, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, int bias_period, float* __restrict__ x) {
+    const int m = blockIdx.y;
+    const int k = (blockIdx.x * NT + threadIdx.x) * 4;
+    if (k >= K) return;
+    f32x4 s = {0, 0, 0, 0};
+    for (int co = 0; co < Co; ++co) {
+        float yv = y[(long long)m * Co + co];
+        s += yv * *reinterpret_cast<const f32x4*>(w + (long long)co * K + k);
+    }
+    if (bias) s += *reinterpret_cast<const f32x4*>(bias + (k % bias_period));
+    *reinterpret_cast<f32x4*>(x + (long long)m * K + k) = s;
+}
+
+__global__ __launch_bounds__(NT) void fc_wgrad_kernel(int M, int K, int Co, const float* __restrict__ x, const float* __restrict__ y,
+                                                      float* __restrict__ dw) {
+    const int co = blockIdx.y;
+    const int k = (blockIdx.x * NT + threadIdx.x) * 4;
+    if (k >= K) return;
+    f32x4 s = {0, 0, 0, 0};
+    for (int m = 0; m < M; ++m) s += y[(long long)m * Co + co] * *reinterpret_cast<const f32x4*>(x + (long long)m * K + k);
+    f32x4* d = reinterpret_cast<f32x4*>(dw + (long long)co * K + k);
+    *d = *d + s;
+}
+
+// ------------------------------------------------------------------------------------------
+// GRU (Chainer StatelessGRU): thread = (sample, hidden unit); 16 samples x 16 units per block
+// ------------------------------------------------------------------------------------------
+constexpr int GRU_S = 16, GRU_U = 16, GRU_MAXIN = 32, GRU_MAXP = 6 * (GRU_U * GRU_MAXIN + GRU_U);
+
+struct GruOff { int w[6]; int b[6]; int in[6]; int total; };
+__host__ __device__ inline GruOff gru_offsets(int dim_zm, int dim_zl) {
+    GruOff o; int p = 0;
+    for (int i = 0; i < 6; ++i) {           // W_r U_r W_z U_z W U
+        o.in[i] = (i & 1) ? dim_zm : dim_zm + dim_zl;
+        o.w[i] = p; p += dim_zm * o.in[i];
+        o.b[i] = p; p += dim_zm;
+    }
+    o.total = p;
+    return o;
+}
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 0.5f * tanhf(0.5f * v) + 0.5f; }
+
+__global__ __launch_bounds__(GRU_S * GRU_U) void gru_fwd_kernel(int N, int T, int dz, int dl, int dc, const float* __restrict__ params,
+                                                                const float* __restrict__ h0, const float* __restrict__ e,
+                                                                const int32_t* __restrict__ labels, const float* __restrict__ zc,
+                                                                float* __restrict__ z, float* __restrict__ saved) {
+    __shared__ float P[GRU_MAXP];
+    __shared__ float xs[GRU_S][GRU_MAXIN], hs[GRU_S][GRU_U], rhs[GRU_S][GRU_U];
+    const GruOff o = gru_offsets(dz, dl);
+    for (int i = threadIdx.x; i < o.total; i += blockDim.x) P[i] = params[i];
+    const int s = threadIdx.x / GRU_U, j = threadIdx.x % GRU_U;
+    const int n = blockIdx.x * GRU_S + s;
+    const bool live = n < N && j < dz;
+    const int in = dz + dl, zw = dc + dz;
+    if (live) hs[s][j] = h0[n * dz + j];
+    if (n < N) {
+        for (int c = j; c < dl; c += GRU_U) xs[s][c] = (c == labels[n]) ? 1.f : 0.f;
+        for (int t = 0; t < T; ++t) for (int c = j; c < dc; c += GRU_U) z[((long long)t * N + n) * zw + c] = zc[n * dc + c];
+    }
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        if (live) xs[s][dl + j] = e[((long long)t * N + n) * dz + j];
+        __syncthreads();
+        float r = 0, zz = 0, hb = 0, h = 0;
+        if (live) {
+            float ar = P[o.b[0] + j] + P[o.b[1] + j], az = P[o.b[2] + j] + P[o.b[3] + j];
+            hb = P[o.b[4] + j] + P[o.b[5] + j];
+            for (int c = 0; c < in; ++c) {
+                float xv = xs[s][c];
+                ar = fmaf(P[o.w[0] + j * in + c], xv, ar);
+                az = fmaf(P[o.w[2] + j * in + c], xv, az);
+                hb = fmaf(P[o.w[4] + j * in + c], xv, hb);
+            }
+            for (int c = 0; c < dz; ++c) {
+                float hv = hs[s][c];
+                ar = fmaf(P[o.w[1] + j * dz + c], hv, ar);
+                az = fmaf(P[o.w[3] + j * dz + c], hv, az);
+            }
+            r = sigmoidf_(ar); zz = sigmoidf_(az); h = hs[s][j];
+            rhs[s][j] = r * h;
+        }
+        __syncthreads();
+        if (live) {
+            for (int c = 0; c < dz; ++c) hb = fmaf(P[o.w[5] + j * dz + c], rhs[s][c], hb);
+            hb = tanhf(hb);
+            float hn = (1.f - zz) * h + zz * hb;
+            float* sv = saved + ((long long)t * N + n) * 4 * dz;
+            sv[j] = r; sv[dz + j] = zz; sv[2 * dz + j] = hb; sv[3 * dz + j] = h;
+            z[((long long)t * N + n) * zw + dc + j] = hn;
+            hs[s][j] = hn;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(GRU_S * GRU_U) void gru_bwd_kernel(int N, int T, int dz, int dl, int dc, const float* __restrict__ params,
+                                                                const float* __restrict__ e, const int32_t* __restrict__ labels,
+                                                                const float* __restrict__ saved, const float* __restrict__ gz,
+                                                                float* __restrict__ dparams) {
+    __shared__ float P[GRU_MAXP], DP[GRU_MAXP];
+    __shared__ float xs[GRU_S][GRU_MAXIN], ga_s[GRU_S][GRU_U], gaz_s[GRU_S][GRU_U], gar_s[GRU_S][GRU_U];
+    __shared__ float h_s[GRU_S][GRU_U], rh_s[GRU_S][GRU_U];
+    const GruOff o = gru_offsets(dz, dl);
+    for (int i = threadIdx.x; i < o.total; i += blockDim.x) { P[i] = params[i]; DP[i] = 0.f; }
+    const int s = threadIdx.x / GRU_U, j = threadIdx.x % GRU_U;
+    const int n = blockIdx.x * GRU_S + s;
+    const bool live = n < N && j < dz;
+    const int in = dz + dl, zw = dc + dz;
+    if (n < N) for (int c = j; c < dl; c += GRU_U) xs[s][c] = (c == labels[n]) ? 1.f : 0.f;
+    float gh = 0.f;
+    __syncthreads();
+    for (int t = T - 1; t >= 0; --t) {
+        float r = 0, zz = 0, hb = 0, h = 0, ga = 0, gaz = 0, ghn = 0;
+        if (live) {
+            const float* sv = saved + ((long long)t * N + n) * 4 * dz;
+            r = sv[j]; zz = sv[dz + j]; hb = sv[2 * dz + j]; h = sv[3 * dz + j];
+            xs[s][dl + j] = e[((long long)t * N + n) * dz + j];
+            ghn = gh + gz[((long long)t * N + n) * zw + dc + j];
+            float gzz = ghn * (hb - h), ghb = ghn * zz;
+            ga = ghb * (1.f - hb * hb);
+            gaz = gzz * zz * (1.f - zz);
+            ga_s[s][j] = ga; gaz_s[s][j] = gaz; h_s[s][j] = h; rh_s[s][j] = r * h;
+        }
+        __syncthreads();
+        float gar = 0.f;
+        if (live) {
+            float grh = 0.f;
+            for (int i = 0; i < dz; ++i) grh = fmaf(ga_s[s][i], P[o.w[5] + i * dz + j], grh);
+            gh = ghn * (1.f - zz) + grh * r;
+            float gr = grh * h;
+            gar = gr * r * (1.f - r);
+            gar_s[s][j] = gar;
+        }
+        __syncthreads();
+        if (live) {
+            for (int i = 0; i < dz; ++i) {
+                gh = fmaf(gaz_s[s][i], P[o.w[3] + i * dz + j], gh);
+                gh = fmaf(gar_s[s][i], P[o.w[1] + i * dz + j], gh);
+            }
+            // parameter gradients of row j of each link
+            for (int c = 0; c < in; ++c) {
+                float xv = xs[s][c];
+                atomicAdd(&DP[o.w[4] + j * in + c], ga * xv);
+                atomicAdd(&DP[o.w[2] + j * in + c], gaz * xv);
+                atomicAdd(&DP[o.w[0] + j * in + c], gar * xv);
+            }
+            for (int c = 0; c < dz; ++c) {
+                atomicAdd(&DP[o.w[5] + j * dz + c], ga * rh_s[s][c]);
+                atomicAdd(&DP[o.w[3] + j * dz + c], gaz * h_s[s][c]);
+                atomicAdd(&DP[o.w[1] + j * dz + c], gar * h_s[s][c]);
+            }
+            atomicAdd(&DP[o.b[4] + j], ga); atomicAdd(&DP[o.b[5] + j], ga);
+            atomicAdd(&DP[o.b[2] + j], gaz); atomicAdd(&DP[o.b[3] + j], gaz);
+            atomicAdd(&DP[o.b[0] + j], gar); atomicAdd(&DP[o.b[1] + j], gar);
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < o.total; i += blockDim.x) atomicAdd(dparams + i, DP[i]);
+}
+
+// ------------------------------------------------------------------------------------------
+// losses: one block
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float softplusf_(float v) { return fmaxf(v, 0.f) + log1pf(expf(-fabsf(v))); }
+
+__device__ float block_sum(float v, float* red) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < NT / 64; ++i) t += red[i];
+    return t;
+}
+
+// softmax cross entropy over classes 1..C-1 of row n; returns loss term, writes grad/N (added)
+__device__ float ce_row(const float* yrow, int C, int label, float invn, float* grow) {
+    float mx = -INFINITY;
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, yrow[c]);
+    float se = 0.f;
+    for (int c = 1; c < C; ++c) se += expf(yrow[c] - mx);
+    float lse = mx + logf(se);
+    for (int c = 1; c < C; ++c) grow[c] += (expf(yrow[c] - lse) - (c - 1 == label ? 1.f : 0.f)) * invn;
+    return (lse - yrow[1 + label]) * invn;
+}
+
+__global__ __launch_bounds__(NT) void loss_dis_kernel(int N, int C, const float* __restrict__ yr, const float* __restrict__ yf,
+                                                      const int32_t* tr, const int32_t* tf, int with_ce, float* loss,
+                                                      float* __restrict__ gr, float* __restrict__ gf) {
+    __shared__ float red[NT / 64];
+    const float invn = 1.f / (float)N;
+    float l = 0.f;
+    for (int i = threadIdx.x; i < N * C; i += NT) {
+        bool first = i < C;                       // sample 0 only (model/updater.py:25-26)
+        gr[i] = first ? -sigmoidf_(-yr[i]) * invn : 0.f;
+        gf[i] = first ? sigmoidf_(yf[i]) * invn : 0.f;
+        if (first) l += (softplusf_(-yr[i]) + softplusf_(yf[i])) * invn;
+    }
+    __syncthreads();
+    if (with_ce) {
+        for (int n = threadIdx.x; n < N; n += NT) {
+            l += ce_row(yr + n * C, C, tr[n], invn, gr + n * C);
+            l += ce_row(yf + n * C, C, tf[n], invn, gf + n * C);
+        }
+    }
+    float t = block_sum(l, red);
+    if (threadIdx.x == 0) loss[0] = t;
+}
+
+__global__ __launch_bounds__(NT) void loss_gen_kernel(int N, int C, const float* __restrict__ yi, const float* __restrict__ yv,
+                                                      const int32_t* tf, int with_ce, float* loss,
+                                                      float* __restrict__ gi, float* __restrict__ gv) {
+    __shared__ float red[NT / 64];
+    const float invn = 1.f / (float)N;
+    float l = 0.f;
+    for (int i = threadIdx.x; i < N * C; i += NT) {
+        bool ch0 = (i % C) == 0;                  // channel 0, full batch (model/updater.py:50-51)
+        gi[i] = ch0 ? -sigmoidf_(-yi[i]) * invn : 0.f;
+        gv[i] = ch0 ? -sigmoidf_(-yv[i]) * invn : 0.f;
+        if (ch0) l += (softplusf_(-yi[i]) + softplusf_(-yv[i])) * invn;
+    }
+    __syncthreads();
+    if (with_ce) {
+        for (int n = threadIdx.x; n < N; n += NT) {
+            l += ce_row(yi + n * C, C, tf[n], invn, gi + n * C);
+            l += ce_row(yv + n * C, C, tf[n], invn, gv + n * C);
+        }
+    }
+    float t = block_sum(l, red);
+    if (threadIdx.x == 0) loss[0] = t;
+}
+
+// ------------------------------------------------------------------------------------------
+// Adam + weight decay, randn
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void adam_wd_kernel(long long n, float* __restrict__ p, const float* __restrict__ g,
+                                                     float* __restrict__ m, float* __restrict__ v, float lr, float b1c,
+                                                     float b2c, float eps, float wd) {
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n; i += (long long)gridDim.x * NT) {
+        float pv = p[i];
+        float gg = g[i] + wd * pv;
+        float mv = m[i], vv = v[i];
+        mv += b1c * (gg - mv);
+        vv += b2c * (gg * gg - vv);
+        m[i] = mv; v[i] = vv;
+        p[i] = pv - lr * mv / (sqrtf(vv) + eps);
+    }
+}
+
+__global__ __launch_bounds__(NT) void randn_kernel(long long n, float sigma, uint64_t seed, uint64_t stream_id, float* __restrict__ out) {
+    const long long n4 = (n + 3) / 4;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long long)gridDim.x * NT) {
+        f32x4 z = randn4((uint64_t)i, seed, stream_id);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (i * 4 + k < n) out[i * 4 + k] = sigma * z[k];
+    }
+}
+
+bool bad_c(int C) { return C <= 0 || (C & 3) || (C >> 2) > NT || (NT % (C >> 2)) != 0; }
+
+}  // namespace
+
+extern "C" int mcg_version(void) { return 1; }
+
+extern "C" int64_t mcg_bn_workspace_bytes(int64_t /*M*/, int C) {
+    return (int64_t)(MAX_PART * 2 * C + 3 * C) * (int64_t)sizeof(float);
+}
+
+extern "C" int mcg_bn_stats(int64_t M, int C, const float* y, const float* gamma, const float* beta, float* stats,
+                            float* avg_mean, float* avg_var, float eps, float decay, void* workspace, void* stream) {
+    if (!y || !gamma || !beta || !stats || !workspace || M <= 0 || bad_c(C)) return MCG_ERR_BAD_ARG;
+    if ((avg_mean == nullptr) != (avg_var == nullptr)) return MCG_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    PartPlan pl = plan_partial(M, C);
+    float* part = (float*)workspace;
+    hipLaunchKernelGGL(col_partial_kernel<0>, dim3(pl.blocks), dim3(NT), 0, s, (long long)M, C, pl.rows_per_block, y, nullptr, nullptr, 0, part);
+    double adjust = (double)M / (M - 1.0 > 1.0 ? M - 1.0 : 1.0);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, pl.blocks, C, 1.0 / (double)M, adjust,
+                       part, gamma, beta, stats, avg_mean, avg_var, eps, decay);
+    return launch_status();
+}
+
+extern "C" int mcg_bn_act_fwd(int64_t M, int C, int c_valid, const float* y, const float* scale_shift, int act, const float* addend,
+                              float sigma, uint64_t seed, uint64_t stream_id, float* out, void* stream) {
+    if (!y || !out || M <= 0 || C <= 0 || (C & 3)) return MCG_ERR_BAD_ARG;
+    long long n4 = (long long)M * (C >> 2);
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(n4)), dim3(NT), 0, (hipStream_t)stream, n4, C, c_valid, y, scale_shift, act,
+                       addend, sigma, seed, stream_id, out);
+    return launch_status();
+}
+
+extern "C" int mcg_bn_act_bwd(int64_t M, int C, const float* g_out, const float* y, const float* stats, const float* gamma, int act,
+                              float* gx, float* dgamma, float* dbeta, void* workspace, void* stream) {
+    if (!g_out || !y || !gx || M <= 0 || C <= 0 || (C & 3)) return MCG_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    long long n4 = (long long)M * (C >> 2);
+    float* coef = nullptr;
+    if (stats) {
+        if (!gamma || !workspace || bad_c(C)) return MCG_ERR_BAD_ARG;
+        PartPlan pl = plan_partial(M, C);
+        float* part = (float*)workspace;
+        coef = part + (long long)MAX_PART * 2 * C;
+        hipLaunchKernelGGL(col_partial_kernel<1>, dim3(pl.blocks), dim3(NT), 0, s, (long long)M, C, pl.rows_per_block, g_out, y, stats, act, part);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, pl.blocks, C, 1.0 / (double)M, part, stats, gamma,
+                           coef, dgamma, dbeta);
+    }
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(NT), 0, s, n4, C, g_out, y, stats, coef, act, gx);
+    return launch_status();
+}
+
+extern "C" int mcg_colsum_acc(int64_t M, int C, const float* g, float* db, void* workspace, void* stream) {
+    if (!g || !db || !workspace || M <= 0 || bad_c(C)) return MCG_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    PartPlan pl = plan_partial(M, C);
+    float* part = (float*)workspace;
+    hipLaunchKernelGGL(col_partial_kernel<2>, dim3(pl.blocks), dim3(NT), 0, s, (long long)M, C, pl.rows_per_block, g, nullptr, nullptr, 0, part);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, pl.blocks, C, part, db);
+    return launch_status();
+}
+
+extern "C" int mcg_pack_clip(int N, int C, int Cp, int T, int HW, const float* x, const float* addend, float sigma, uint64_t seed,
+                             uint64_t stream_id, float* out, void* stream) {
+    if (!x || !out || N <= 0 || C <= 0 || Cp < C || (Cp & 3) || T <= 0 || HW <= 0) return MCG_ERR_BAD_ARG;
+    long long npix = (long long)N * T * HW;
+    hipLaunchKernelGGL(pack_clip_kernel, dim3(ew_grid(npix)), dim3(NT), 0, (hipStream_t)stream, N, C, Cp, T, HW, x, addend, sigma, seed, stream_id, out);
+    return launch_status();
+}
+
+extern "C" int mcg_unpack_clip(int N, int C, int Cp, int T, int HW, const float* in, float* x, void* stream) {
+    if (!x || !in || N <= 0 || C <= 0 || Cp < C || T <= 0 || HW <= 0) return MCG_ERR_BAD_ARG;
+    long long npix = (long long)N * T * HW;
+    hipLaunchKernelGGL(unpack_clip_kernel, dim3(ew_grid(npix)), dim3(NT), 0, (hipStream_t)stream, N, C, Cp, T, HW, in, x);
+    return launch_status();
+}
+
+extern "C" int mcg_tanh_bwd_to_frames(int N, int T, int64_t frame_elems, const float* g_clip, const float* x_clip, float* g_frames, void* stream) {
+    if (!g_clip || !x_clip || !g_frames || N <= 0 || T <= 0 || frame_elems <= 0 || (frame_elems & 3)) return MCG_ERR_BAD_ARG;
+    long long n4 = (long long)N * T * (frame_elems >> 2);
+    hipLaunchKernelGGL(tanh_bwd_to_frames_kernel, dim3(ew_grid(n4)), dim3(NT), 0, (hipStream_t)stream, N, T, (long long)(frame_elems >> 2), g_clip, x_clip, g_frames);
+    return launch_status();
+}
+
+extern "C" int mcg_fc_fprop(int M, int K, int Co, const float* x, const float* w, const float* bias, float* y, void* stream) {
+    if (!x || !w || !y || M <= 0 || K <= 0 || (K & 3) || Co <= 0) return MCG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(fc_fprop_kernel, dim3(M, Co), dim3(NT), 0, (hipStream_t)stream, K, Co, x, w, bias, y);
+    return launch_status();
+}
+
+extern "C" int mcg_fc_dgrad(int M, int K, int Co, const float* y, const float* w, const float* bias, int bias_period, float* x, void* stream) {
+    if (!x || !w || !y || M <= 0 || K <= 0 || (K & 3) || Co <= 0) return MCG_ERR_BAD_ARG;
+    if (bias && (bias_period <= 0 || (bias_period & 3) || K % bias_period)) return MCG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(fc_dgrad_kernel, dim3((K / 4 + NT - 1) / NT, M), dim3(NT), 0, (hipStream_t)stream, K, Co, y, w, bias, bias_period, x);
+    return launch_status();
+}
+
+extern "C" int mcg_fc_wgrad(int M, int K, int Co, const float* x, const float* y, float* dw, void* stream) {
+    if (!x || !dw || !y || M <= 0 || K <= 0 || (K & 3) || Co <= 0) return MCG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(fc_wgrad_kernel, dim3((K / 4 + NT - 1) / NT, Co), dim3(NT), 0, (hipStream_t)stream, M, K, Co, x, y, dw);
+    return launch_status();
+}
+
+extern "C" int mcg_gru_seq_fwd(int N, int T, int dim_zm, int dim_zl, int dim_zc, const float* params, const float* h0, const float* e,
+                               const int32_t* labels, const float* zc, float* z, float* saved, void* stream) {
+    if (!params || !h0 || !e || !zc || !z || !saved || N <= 0 || T <= 0) return MCG_ERR_BAD_ARG;
+    if (dim_zm <= 0 || dim_zm > GRU_U || dim_zl < 0 || dim_zm + dim_zl > GRU_MAXIN || dim_zc < 0) return MCG_ERR_UNSUPPORTED;
+    if (dim_zl && !labels) return MCG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(gru_fwd_kernel, dim3((N + GRU_S - 1) / GRU_S), dim3(GRU_S * GRU_U), 0, (hipStream_t)stream, N, T, dim_zm, dim_zl, dim_zc,
+                       params, h0, e, labels, zc, z, saved);
+    return launch_status();
+}
+
+extern "C" int mcg_gru_seq_bwd(int N, int T, int dim_zm, int dim_zl, int dim_zc, const float* params, const float* e, const int32_t* labels,
+                               const float* saved, const float* gz, float* dparams, void* stream) {
+    if (!params || !e || !saved || !gz || !dparams || N <= 0 || T <= 0) return MCG_ERR_BAD_ARG;
+    if (dim_zm <= 0 || dim_zm > GRU_U || dim_zl < 0 || dim_zm + dim_zl > GRU_MAXIN || dim_zc < 0) return MCG_ERR_UNSUPPORTED;
+    if (dim_zl && !labels) return MCG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(gru_bwd_kernel, dim3((N + GRU_S - 1) / GRU_S), dim3(GRU_S * GRU_U), 0, (hipStream_t)stream, N, T, dim_zm, dim_zl, dim_zc,
+                       params, e, labels, saved, gz, dparams);
+    return launch_status();
+}
+
+extern "C" int mcg_loss_dis(int N, int C, const float* y_real, const float* y_fake, const int32_t* t_real, const int32_t* t_fake, int with_ce,
+                            float* loss_out, float* g_real, float* g_fake, void* stream) {
+    if (!y_real || !y_fake || !loss_out || !g_real || !g_fake || N <= 0 || C <= 0) return MCG_ERR_BAD_ARG;
+    if (with_ce && (!t_real || !t_fake || C < 2)) return MCG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(loss_dis_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, N, C, y_real, y_fake, t_real, t_fake, with_ce, loss_out, g_real, g_fake);
+    return launch_status();
+}
+
+extern "C" int mcg_loss_gen(int N, int C, const float* y_fake_i, const float* y_fake_v, const int32_t* t_fake, int with_ce, float* loss_out,
+                            float* g_i, float* g_v, void* stream) {
+    if (!y_fake_i || !y_fake_v || !loss_out || !g_i || !g_v || N <= 0 || C <= 0) return MCG_ERR_BAD_ARG;
+    if (with_ce && (!t_fake || C < 2)) return MCG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(loss_gen_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, N, C, y_fake_i, y_fake_v, t_fake, with_ce, loss_out, g_i, g_v);
+    return launch_status();
+}
+
+extern "C" int mcg_adam_wd(int64_t n, float* p, const float* g, float* m, float* v, float lr_t, float beta1, float beta2, float eps, float wd,
+                           void* stream) {
+    if (!p || !g || !m || !v || n <= 0) return MCG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(adam_wd_kernel, dim3(ew_grid((n + 0) / 1)), dim3(NT), 0, (hipStream_t)stream, (long long)n, p, g, m, v, lr_t, 1.f - beta1,
+                       1.f - beta2, eps, wd);
+    return launch_status();
+}
+
+extern "C" int mcg_randn(int64_t n, float sigma, uint64_t seed, uint64_t stream_id, float* out, void* stream) {
+    if (!out || n <= 0) return MCG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(randn_kernel, dim3(ew_grid((n + 3) / 4)), dim3(NT), 0, (hipStream_t)stream, (long long)n, sigma, seed, stream_id, out);
+    return launch_status();
+}

@@ -1,0 +1,214 @@
+"""ctypes binding of libmocogan_hip.so (declared in include/mocogan_hip.h).
+
+PyTorch-ROCm supplies device memory and the HIP stream only; every call below hands raw
+device pointers to a hand-written gfx950 kernel.  There is no fallback: if the library is
+missing or a status is non-zero this module raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+from .build import lib_path
+
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+
+_STATUS = {0: "MCG_OK", -1: "MCG_ERR_BAD_ARG", -2: "MCG_ERR_UNSUPPORTED", -3: "MCG_ERR_LAUNCH",
+           -4: "MCG_ERR_WORKSPACE"}
+
+
+class McgError(RuntimeError):
+    pass
+
+
+class ConvGeom(C.Structure):
+    """mcg_conv_geom"""
+    _fields_ = [("N", C.c_int32), ("Ti", C.c_int32), ("Hi", C.c_int32), ("Wi", C.c_int32), ("Ci", C.c_int32),
+                ("To", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32), ("Co", C.c_int32),
+                ("kt", C.c_int32), ("x_perm_n", C.c_int32),
+                ("x_stride0", C.c_int64), ("x_stride1", C.c_int64)]
+
+
+_P, _I, _I64, _U64, _F = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float
+_GP = C.POINTER(ConvGeom)
+
+# name -> (restype, argtypes); mirrors include/mocogan_hip.h one to one
+SIGNATURES = {
+    "mcg_version": (_I, []),
+    "mcg_set_tile_override": (None, [_I]),
+    "mcg_conv_fprop": (_I, [_GP, _P, _P, _P, _P, _P]),
+    "mcg_conv_dgrad": (_I, [_GP, _P, _P, _P, _P, _I, _I, _P]),
+    "mcg_conv_wgrad": (_I, [_GP, _P, _P, _P, _P]),
+    "mcg_fc_fprop": (_I, [_I, _I, _I, _P, _P, _P, _P, _P]),
+    "mcg_fc_dgrad": (_I, [_I, _I, _I, _P, _P, _P, _I, _P, _P]),
+    "mcg_fc_wgrad": (_I, [_I, _I, _I, _P, _P, _P, _P]),
+    "mcg_bn_workspace_bytes": (_I64, [_I64, _I]),
+    "mcg_bn_stats": (_I, [_I64, _I, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P]),
+    "mcg_bn_act_fwd": (_I, [_I64, _I, _I, _P, _P, _I, _P, _F, _U64, _U64, _P, _P]),
+    "mcg_bn_act_bwd": (_I, [_I64, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
+    "mcg_colsum_acc": (_I, [_I64, _I, _P, _P, _P, _P]),
+    "mcg_pack_clip": (_I, [_I, _I, _I, _I, _I, _P, _P, _F, _U64, _U64, _P, _P]),
+    "mcg_unpack_clip": (_I, [_I, _I, _I, _I, _I, _P, _P, _P]),
+    "mcg_tanh_bwd_to_frames": (_I, [_I, _I, _I64, _P, _P, _P, _P]),
+    "mcg_gru_seq_fwd": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mcg_gru_seq_bwd": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "mcg_loss_dis": (_I, [_I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
+    "mcg_loss_gen": (_I, [_I, _I, _P, _P, _P, _I, _P, _P, _P, _P]),
+    "mcg_adam_wd": (_I, [_I64, _P, _P, _P, _P, _F, _F, _F, _F, _F, _P]),
+    "mcg_randn": (_I, [_I64, _F, _U64, _U64, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree library (never a site-packages copy) and type every entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise McgError("libmocogan_hip.so not built (%s): run __graft_entry__.build(); "
+                       "there is no CPU fallback for the product path" % path)
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def set_tile_override(t):
+    load().mcg_set_tile_override(int(t))
+
+
+def _check(status, name):
+    if status != 0:
+        raise McgError("%s failed: %s" % (name, _STATUS.get(status, status)))
+
+
+def _p(t, dtype=torch.float32):
+    """device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise McgError("the HIP path needs device tensors (got a %s tensor)" % t.device)
+    if t.dtype != dtype:
+        raise McgError("expected %s, got %s" % (dtype, t.dtype))
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dense(t):
+    if t is not None and not t.is_contiguous():
+        raise McgError("tensor must be dense")
+    return t
+
+
+def make_geom(N, Ti, Hi, Wi, Ci, Co, kt, x_stride0=None, x_perm_n=0, x_stride1=0):
+    """Geometry of one k4 s(1,2,2) p(0,1,1) layer; x side [N][Ti][Hi][Wi][Ci], y side dense."""
+    g = ConvGeom()
+    g.N, g.Ti, g.Hi, g.Wi, g.Ci = N, Ti, Hi, Wi, Ci
+    g.To, g.Ho, g.Wo, g.Co, g.kt = Ti - kt + 1, Hi // 2, Wi // 2, Co, kt
+    g.x_perm_n = x_perm_n
+    g.x_stride0 = Ti * Hi * Wi * Ci if x_stride0 is None else x_stride0
+    g.x_stride1 = x_stride1
+    return g
+
+
+# ------------------------------------------------------------------------------------------
+# thin typed wrappers (tensors in, nothing allocated here)
+# ------------------------------------------------------------------------------------------
+def conv_fprop(g, x, w, bias, y):
+    _check(load().mcg_conv_fprop(C.byref(g), _p(x), _p(_dense(w)), _p(bias), _p(_dense(y)), _stream()), "mcg_conv_fprop")
+
+
+def conv_dgrad(g, y, w, bias, x, act=ACT_NONE, accumulate=False):
+    _check(load().mcg_conv_dgrad(C.byref(g), _p(_dense(y)), _p(_dense(w)), _p(bias), _p(x), act, int(accumulate), _stream()),
+           "mcg_conv_dgrad")
+
+
+def conv_wgrad(g, x, y, dw):
+    _check(load().mcg_conv_wgrad(C.byref(g), _p(x), _p(_dense(y)), _p(_dense(dw)), _stream()), "mcg_conv_wgrad")
+
+
+def fc_fprop(M, K, Co, x, w, bias, y):
+    _check(load().mcg_fc_fprop(M, K, Co, _p(_dense(x)), _p(_dense(w)), _p(bias), _p(_dense(y)), _stream()), "mcg_fc_fprop")
+
+
+def fc_dgrad(M, K, Co, y, w, bias, bias_period, x):
+    _check(load().mcg_fc_dgrad(M, K, Co, _p(_dense(y)), _p(_dense(w)), _p(bias), bias_period, _p(_dense(x)), _stream()), "mcg_fc_dgrad")
+
+
+def fc_wgrad(M, K, Co, x, y, dw):
+    _check(load().mcg_fc_wgrad(M, K, Co, _p(_dense(x)), _p(_dense(y)), _p(_dense(dw)), _stream()), "mcg_fc_wgrad")
+
+
+def bn_workspace_floats(C_max):
+    return int(load().mcg_bn_workspace_bytes(0, C_max)) // 4
+
+
+def bn_stats(M, Cn, y, gamma, beta, stats, avg_mean, avg_var, ws, eps=2e-5, decay=0.9):
+    _check(load().mcg_bn_stats(M, Cn, _p(_dense(y)), _p(gamma), _p(beta), _p(stats), _p(avg_mean), _p(avg_var),
+                               eps, decay, _p(ws), _stream()), "mcg_bn_stats")
+
+
+def bn_act_fwd(M, Cn, y, scale_shift, act, out, addend=None, sigma=0.0, seed=0, stream_id=0, c_valid=None):
+    _check(load().mcg_bn_act_fwd(M, Cn, Cn if c_valid is None else c_valid, _p(_dense(y)), _p(scale_shift), act,
+                                 _p(_dense(addend)), sigma, seed, stream_id, _p(_dense(out)), _stream()), "mcg_bn_act_fwd")
+
+
+def bn_act_bwd(M, Cn, g_out, y, stats, gamma, act, gx, dgamma, dbeta, ws):
+    _check(load().mcg_bn_act_bwd(M, Cn, _p(_dense(g_out)), _p(_dense(y)), _p(stats), _p(gamma), act, _p(_dense(gx)),
+                                 _p(dgamma), _p(dbeta), _p(ws), _stream()), "mcg_bn_act_bwd")
+
+
+def colsum_acc(M, Cn, g, db, ws):
+    _check(load().mcg_colsum_acc(M, Cn, _p(_dense(g)), _p(db), _p(ws), _stream()), "mcg_colsum_acc")
+
+
+def pack_clip(N, Cn, Cp, T, HW, x, out, addend=None, sigma=0.0, seed=0, stream_id=0):
+    _check(load().mcg_pack_clip(N, Cn, Cp, T, HW, _p(_dense(x)), _p(_dense(addend)), sigma, seed, stream_id,
+                                _p(_dense(out)), _stream()), "mcg_pack_clip")
+
+
+def unpack_clip(N, Cn, Cp, T, HW, inp, x):
+    _check(load().mcg_unpack_clip(N, Cn, Cp, T, HW, _p(_dense(inp)), _p(_dense(x)), _stream()), "mcg_unpack_clip")
+
+
+def tanh_bwd_to_frames(N, T, frame_elems, g_clip, x_clip, g_frames):
+    _check(load().mcg_tanh_bwd_to_frames(N, T, frame_elems, _p(_dense(g_clip)), _p(_dense(x_clip)), _p(_dense(g_frames)),
+                                         _stream()), "mcg_tanh_bwd_to_frames")
+
+
+def gru_seq_fwd(N, T, dz, dl, dc, params, h0, e, labels, zc, z, saved):
+    _check(load().mcg_gru_seq_fwd(N, T, dz, dl, dc, _p(params), _p(_dense(h0)), _p(_dense(e)), _p(labels, torch.int32),
+                                  _p(_dense(zc)), _p(_dense(z)), _p(_dense(saved)), _stream()), "mcg_gru_seq_fwd")
+
+
+def gru_seq_bwd(N, T, dz, dl, dc, params, e, labels, saved, gz, dparams):
+    _check(load().mcg_gru_seq_bwd(N, T, dz, dl, dc, _p(params), _p(_dense(e)), _p(labels, torch.int32), _p(_dense(saved)),
+                                  _p(_dense(gz)), _p(dparams), _stream()), "mcg_gru_seq_bwd")
+
+
+def loss_dis(N, Cn, y_real, y_fake, t_real, t_fake, with_ce, loss_out, g_real, g_fake):
+    _check(load().mcg_loss_dis(N, Cn, _p(_dense(y_real)), _p(_dense(y_fake)), _p(t_real, torch.int32), _p(t_fake, torch.int32),
+                               int(with_ce), _p(loss_out), _p(_dense(g_real)), _p(_dense(g_fake)), _stream()), "mcg_loss_dis")
+
+
+def loss_gen(N, Cn, y_i, y_v, t_fake, with_ce, loss_out, g_i, g_v):
+    _check(load().mcg_loss_gen(N, Cn, _p(_dense(y_i)), _p(_dense(y_v)), _p(t_fake, torch.int32), int(with_ce), _p(loss_out),
+                               _p(_dense(g_i)), _p(_dense(g_v)), _stream()), "mcg_loss_gen")
+
+
+def adam_wd(p, g, m, v, lr_t, beta1, beta2, eps, wd):
+    _check(load().mcg_adam_wd(p.numel(), _p(_dense(p)), _p(_dense(g)), _p(_dense(m)), _p(_dense(v)), lr_t, beta1, beta2, eps, wd,
+                              _stream()), "mcg_adam_wd")
+
+
+def randn(out, sigma, seed, stream_id):
+    _check(load().mcg_randn(out.numel(), sigma, seed, stream_id, _p(_dense(out)), _stream()), "mcg_randn")

@@ -1,0 +1,48 @@
+"""NumPy restatement of the device noise generator (TEST INFRASTRUCTURE, see oracle/__init__.py).
+
+The reference draws add_noise's normals from NumPy's MT19937 on the host
+(model/net.py:13); a GPU cannot reproduce that stream, so in "perf mode" the build draws
+sigma*N(0,1) in-kernel from Philox4x32-10 (Salmon et al. 2011, Random123) + Box-Muller.  This
+file states the same generator so the in-kernel draw is checkable:
+counter = (idx_lo, idx_hi, stream_lo, stream_hi), key = (seed_lo, seed_hi), one counter per
+group of 4 consecutive elements.
+"""
+import numpy as np
+
+M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+W0, W1 = np.uint32(0x9E3779B9), np.uint32(0xBB67AE85)
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    c0, c1, c2, c3 = (np.asarray(c, np.uint32) for c in (c0, c1, c2, c3))
+    k0, k1 = np.uint32(k0), np.uint32(k1)
+    with np.errstate(over='ignore'):
+        for _ in range(10):
+            p0 = M0 * c0.astype(np.uint64)
+            p1 = M1 * c2.astype(np.uint64)
+            hi0, lo0 = (p0 >> np.uint64(32)).astype(np.uint32), p0.astype(np.uint32)
+            hi1, lo1 = (p1 >> np.uint64(32)).astype(np.uint32), p1.astype(np.uint32)
+            c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+            k0 = np.uint32(k0 + W0)
+            k1 = np.uint32(k1 + W1)
+    return c0, c1, c2, c3
+
+
+def randn(n, sigma, seed, stream_id):
+    """The first n elements of the stream (float64 math; the device uses float32 intrinsics)."""
+    n4 = (n + 3) // 4
+    idx = np.arange(n4, dtype=np.uint64)
+    z = np.zeros(n4, np.uint32)
+    r = philox4x32_10((idx & np.uint64(0xFFFFFFFF)).astype(np.uint32), (idx >> np.uint64(32)).astype(np.uint32),
+                      z + np.uint32(stream_id & 0xFFFFFFFF), z + np.uint32(stream_id >> 32),
+                      seed & 0xFFFFFFFF, seed >> 32)
+    S = 2.0 ** -32
+    f = [np.float32(x).astype(np.float64) for x in r]            # the device converts uint32 -> float32 first
+    u1 = np.minimum(np.float32((f[0] + 1.0)).astype(np.float64) * S, 1.0)
+    u2 = f[1] * S
+    u3 = np.minimum(np.float32((f[2] + 1.0)).astype(np.float64) * S, 1.0)
+    u4 = f[3] * S
+    ra, rb = np.sqrt(-2 * np.log(u1)), np.sqrt(-2 * np.log(u3))
+    out = np.stack([ra * np.cos(2 * np.pi * u2), ra * np.sin(2 * np.pi * u2),
+                    rb * np.cos(2 * np.pi * u4), rb * np.sin(2 * np.pi * u4)], axis=1).reshape(-1)
+    return sigma * out[:n]

@@ -1,0 +1,296 @@
+"""Op-level parity: every C-ABI entry point of libmocogan_hip.so against the float64 oracle on
+seeded inputs.  Tolerances: forward rel-L2 <= 1e-5, gradients <= 1e-4 (fp32 MFMA vs
+float64)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import functions as F
+from oracle import net as onet
+from oracle import updater as oupd
+from oracle import philox
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL, BWD_TOL = 1e-5, 1e-4
+
+
+@pytest.fixture(scope="module")
+def hl():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import mocogan_chainer_amd.hiplib as hiplib
+    hiplib.load()
+    return hiplib
+
+
+def L():
+    import mocogan_chainer_amd.layout as layout
+    return layout
+
+
+def dev(a, dtype=torch.float32):
+    return torch.tensor(np.asarray(a), dtype=dtype, device="cuda")
+
+
+def rel_l2(a, b):
+    a = a.detach().cpu().double().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+CONV_CASES = [
+    # N, Ti, H, Ci, Co, kt
+    (2, 7, 16, 8, 64, 4),
+    (2, 5, 16, 3, 64, 4),      # first layer: 3 channels padded to 4
+    (3, 1, 16, 16, 32, 1),     # 2-D, Co < tile
+    (2, 4, 8, 64, 160, 4),     # Co not a multiple of the tile
+    (5, 1, 4, 32, 256, 1),     # tiny spatial extent, M not a multiple of the tile
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+def test_conv_three_passes(hl, case, tile):
+    N, Ti, H, Ci, Co, kt = case
+    rng = np.random.RandomState(hash(case) % 2**31)
+    x = rng.uniform(-1, 1, (N, Ci, Ti, H, H))
+    W = rng.randn(Co, Ci, kt, 4, 4) * 0.1
+    b = rng.randn(Co)
+    stride, pad = (1, 2, 2), (0, 1, 1)
+    y_ref = F.conv3d_fwd(x, W, b, stride, pad)
+    gy = rng.randn(*y_ref.shape)
+    gx_ref, gW_ref, _ = F.conv3d_bwd(x, W, gy, stride, pad)
+
+    lay = L()
+    xd, wd, bd = lay.act_to_dev(dev(x)), lay.conv_w_to_dev(dev(W)), dev(b)
+    Cip = xd.shape[-1]
+    g = hl.make_geom(N, Ti, H, H, Cip, Co, kt)
+    hl.set_tile_override(tile)
+    try:
+        yd = torch.empty((N, g.To, g.Ho, g.Wo, Co), device="cuda")
+        hl.conv_fprop(g, xd, wd, bd, yd)
+        assert rel_l2(lay.act_from_dev(yd, Co), y_ref) < FWD_TOL
+
+        gyd = lay.act_to_dev(dev(gy))
+        gxd = torch.full_like(xd, 7.0)
+        hl.conv_dgrad(g, gyd, wd, None, gxd)
+        assert rel_l2(lay.act_from_dev(gxd, Ci), gx_ref) < BWD_TOL
+        if Cip != Ci:
+            assert float(gxd[..., Ci:].abs().max()) == 0.0      # padded channels: zero weights -> zero gradient
+
+        hl.conv_dgrad(g, gyd, wd, None, gxd, accumulate=True)
+        assert rel_l2(lay.act_from_dev(gxd, Ci), 2 * gx_ref) < BWD_TOL
+
+        dwd = torch.zeros_like(wd)
+        hl.conv_wgrad(g, xd, gyd, dwd)
+        hl.conv_wgrad(g, xd, gyd, dwd)                           # accumulates
+        assert rel_l2(lay.conv_w_from_dev(dwd, Ci, 3), 2 * gW_ref) < BWD_TOL
+    finally:
+        hl.set_tile_override(0)
+
+
+def test_conv_frame_view_and_frame_permutation(hl):
+    """x[:, :, t] as the x side (model/updater.py:97) and the (T,N)->(N,T) output permutation of the
+    generator's last layer (model/updater.py:102)."""
+    lay = L()
+    rng = np.random.RandomState(11)
+    N, T, H, C, Co, t = 3, 5, 16, 3, 64, 2
+    clip = rng.uniform(-1, 1, (N, C, T, H, H))
+    W = rng.randn(Co, C, 4, 4) * 0.1
+    y_ref = F.conv2d_fwd(clip[:, :, t], W, None, 2, 1)
+    clipd = lay.act_to_dev(dev(clip))                       # [N][T][H][W][4]
+    g = hl.make_geom(N, 1, H, H, 4, Co, 1, x_stride0=T * H * H * 4)
+    yd = torch.empty((N, 1, H // 2, H // 2, Co), device="cuda")
+    hl.conv_fprop(g, clipd[:, t], lay.conv_w_to_dev(dev(W)), None, yd)
+    assert rel_l2(lay.act_from_dev(yd, Co, 2), y_ref) < FWD_TOL
+
+    # deconv forward of T*N frames written straight into clip order, with bias + tanh
+    Ci_d = 16
+    xin = rng.randn(T * N, Ci_d, H // 2, H // 2)
+    Wd = rng.randn(Ci_d, C, 4, 4) * 0.1
+    bd = rng.randn(C) * 0.1
+    out_ref = np.tanh(F.deconv2d_fwd(xin, Wd, bd, 2, 1)).reshape(T, N, C, H, H).transpose(1, 2, 0, 3, 4)
+    g2 = hl.make_geom(T * N, 1, H, H, 4, Ci_d, 1, x_stride0=T * H * H * 4, x_perm_n=N, x_stride1=H * H * 4)
+    outd = torch.zeros((N, T, H, H, 4), device="cuda")
+    hl.conv_dgrad(g2, lay.act_to_dev(dev(xin)), lay.deconv_w_to_dev(dev(Wd)), lay.vec_to_dev(dev(bd)), outd, act=hl.ACT_TANH)
+    assert rel_l2(lay.act_from_dev(outd, C), out_ref) < FWD_TOL
+
+
+def test_conv_rejects_bad_geometry(hl):
+    g = hl.make_geom(1, 4, 12, 12, 4, 64, 4)                # Ho = 6 is not a power of two
+    x = torch.zeros(1, device="cuda")
+    with pytest.raises(hl.McgError):
+        hl.conv_fprop(g, x, x, None, x)
+    g = hl.make_geom(1, 4, 16, 16, 3, 64, 4)                # unpadded channel count
+    with pytest.raises(hl.McgError):
+        hl.conv_fprop(g, x, x, None, x)
+    with pytest.raises(hl.McgError):
+        hl.conv_fprop(hl.make_geom(1, 4, 16, 16, 4, 64, 4), torch.zeros(1), x, None, x)   # host tensor
+
+
+@pytest.mark.parametrize("M,K,Co", [(4, 512, 1), (3, 2048, 7), (32, 1024, 60)])
+def test_fc_ops(hl, M, K, Co):
+    rng = np.random.RandomState(M * 7 + Co)
+    x, w, b, gy = rng.randn(M, K), rng.randn(Co, K) * 0.05, rng.randn(Co), rng.randn(M, Co)
+    xd, wd, bd, gyd = dev(x), dev(w), dev(b), dev(gy)
+    yd = torch.empty((M, Co), device="cuda")
+    hl.fc_fprop(M, K, Co, xd, wd, bd, yd)
+    assert rel_l2(yd, x @ w.T + b) < FWD_TOL
+    bias_k = rng.randn(64)
+    gxd = torch.empty((M, K), device="cuda")
+    hl.fc_dgrad(M, K, Co, gyd, wd, dev(bias_k), 64, gxd)
+    assert rel_l2(gxd, gy @ w + np.tile(bias_k, K // 64)) < FWD_TOL
+    dwd = torch.ones((Co, K), device="cuda")
+    hl.fc_wgrad(M, K, Co, xd, gyd, dwd)
+    assert rel_l2(dwd, gy.T @ x + 1) < BWD_TOL
+
+
+@pytest.mark.parametrize("C,M,act", [(64, 5000, 2), (128, 777, 1), (512, 64, 2), (256, 4096, 1)])
+def test_batchnorm_activation_fwd_bwd(hl, C, M, act):
+    rng = np.random.RandomState(C + M)
+    y = rng.randn(M, C) * 1.7 + 0.3
+    gamma, beta = 1 + 0.1 * rng.randn(C), 0.1 * rng.randn(C)
+    noise = 0.2 * rng.randn(M, C)
+    am, av = np.zeros(C), np.ones(C)
+    y4 = y.T.reshape(1, C, M, 1)                                  # oracle layout (N,C,H,W)
+    bn, cache = F.bn_train_fwd(y4, gamma, beta, am, av)
+    out_ref = (F.leaky_relu_fwd(bn) if act == 2 else F.relu_fwd(bn))
+    ws = torch.empty(hl.bn_workspace_floats(C), device="cuda")
+    yd, gd, bd = dev(y), dev(gamma), dev(beta)
+    stats = torch.empty(4 * C, device="cuda")
+    amd, avd = dev(am * 0), dev(av * 0 + 1)
+    hl.bn_stats(M, C, yd, gd, bd, stats, amd, avd, ws)
+    assert rel_l2(stats[:C], cache['mean']) < 1e-5 and rel_l2(stats[C:2 * C], cache['inv_std']) < 1e-5
+    assert rel_l2(amd, am) < 1e-5 and rel_l2(avd, av) < 1e-5
+    outd = torch.empty_like(yd)
+    hl.bn_act_fwd(M, C, yd, stats[2 * C:], act, outd, addend=dev(noise))
+    assert rel_l2(outd, out_ref[0, :, :, 0].T + noise) < FWD_TOL
+
+    g_out = rng.randn(M, C)
+    g4 = g_out.T.reshape(1, C, M, 1)
+    g_bn = F.leaky_relu_bwd(out_ref, g4) if act == 2 else F.relu_bwd(out_ref, g4)
+    gamma_new = gamma * 1.01                                      # Q5: backward sees the updated gamma
+    gx_ref, gg_ref, gb_ref = F.bn_train_bwd(cache, gamma_new, g_bn)
+    dg, db = torch.ones(C, device="cuda"), torch.ones(C, device="cuda")
+    gxd = torch.empty_like(yd)
+    hl.bn_act_bwd(M, C, dev(g_out), yd, stats, dev(gamma_new), act, gxd, dg, db, ws)
+    assert rel_l2(gxd, gx_ref[0, :, :, 0].T) < BWD_TOL
+    assert rel_l2(dg, gg_ref + 1) < BWD_TOL and rel_l2(db, gb_ref + 1) < BWD_TOL
+    # no-BN form (D's first layer): lrelu only
+    hl.bn_act_bwd(M, C, dev(g_out), yd, None, None, hl.ACT_LRELU, gxd, None, None, ws)
+    assert rel_l2(gxd, F.leaky_relu_bwd(F.leaky_relu_fwd(y), g_out)) < 1e-6
+    cs = torch.ones(C, device="cuda")
+    hl.colsum_acc(M, C, dev(g_out), cs, ws)
+    assert rel_l2(cs, g_out.sum(0) + 1) < 1e-5
+
+
+def test_philox_noise_matches_oracle_stream(hl):
+    n = 100003
+    out = torch.empty(n, device="cuda")
+    hl.randn(out, 0.2, 0x1234567887654321, 42)
+    ref = philox.randn(n, 0.2, 0x1234567887654321, 42)
+    assert np.abs(out.cpu().numpy() - ref).max() < 2e-6
+    # the fused paths draw the SAME stream: lrelu(y) + sigma*randn, padded channel masked
+    M, C = 1000, 4
+    y = torch.randn(M, C, device="cuda")
+    o = torch.empty_like(y)
+    hl.bn_act_fwd(M, C, y, None, hl.ACT_LRELU, o, sigma=0.2, seed=7, stream_id=3, c_valid=3)
+    z = philox.randn(M * C, 0.2, 7, 3).reshape(M, C)
+    z[:, 3] = 0
+    yl = torch.where(y >= 0, y, 0.2 * y).cpu().numpy()
+    assert np.abs(o.cpu().numpy() - (yl + z)).max() < 3e-6
+
+
+def test_pack_unpack_and_tanh_bwd_to_frames(hl):
+    rng = np.random.RandomState(3)
+    N, C, T, H = 3, 3, 5, 8
+    x = rng.randn(N, C, T, H, H)
+    noise = rng.randn(N, C, T, H, H)
+    lay = L()
+    out = torch.empty((N, T, H, H, 4), device="cuda")
+    hl.pack_clip(N, C, 4, T, H * H, dev(x), out, addend=lay.act_to_dev(dev(noise)))
+    assert rel_l2(lay.act_from_dev(out, C), x + noise) < 1e-6
+    assert float(out[..., 3].abs().max()) == 0.0
+    back = torch.empty((N, C, T, H, H), device="cuda")
+    hl.unpack_clip(N, C, 4, T, H * H, out, back)
+    assert rel_l2(back, x + noise) < 1e-6
+    g = rng.randn(N, T, H, H, 4)
+    xc = np.tanh(rng.randn(N, T, H, H, 4))
+    gf = torch.empty((T * N, H, H, 4), device="cuda")
+    hl.tanh_bwd_to_frames(N, T, H * H * 4, dev(g), dev(xc), gf)
+    ref = (g * (1 - xc * xc)).transpose(1, 0, 2, 3, 4).reshape(T * N, H, H, 4)
+    assert rel_l2(gf, ref) < 1e-6
+
+
+@pytest.mark.parametrize("N,dim_zl", [(5, 0), (37, 6)])
+def test_gru_sequence(hl, N, dim_zl):
+    rng = np.random.RandomState(N)
+    T, dz, dc = 16, 10, 50
+    p = onet.init_generator(rng, dim_zl=dim_zl, n_filters=2, dtype=np.float64)
+    gp = {k: (v + 0.1 * rng.randn(*v.shape)) for k, v in p.items() if k.startswith('g0/')}
+    draw = onet.gen_draw(rng, N, dim_zl=dim_zl, dtype=np.float64)
+    # oracle: run the recurrence alone
+    gpo = {k[3:]: v for k, v in gp.items()}
+    zl = np.eye(dim_zl)[draw['labels']] if dim_zl else None
+    h, hs, caches = draw['h0'], [], []
+    for t in range(T):
+        et = draw['e'][t] if zl is None else np.concatenate((zl, draw['e'][t]), 1)
+        h, c = F.gru_step_fwd(gpo, h, et)
+        hs.append(h), caches.append(c)
+    z_ref = np.concatenate((np.tile(draw['zc'], (T, 1, 1)), np.stack(hs)), 2).reshape(T * N, dc + dz)
+    lay = L()
+    flat = lay.gru_to_dev({k: dev(v) for k, v in gp.items()})
+    labels = dev(draw['labels'], torch.int32) if dim_zl else None
+    z = torch.empty((T * N, dc + dz), device="cuda")
+    saved = torch.empty((T, N, 4 * dz), device="cuda")
+    hl.gru_seq_fwd(N, T, dz, dim_zl, dc, flat, dev(draw['h0']), dev(draw['e']), labels, dev(draw['zc']), z, saved)
+    assert rel_l2(z, z_ref) < FWD_TOL
+    gz = rng.randn(T * N, dc + dz)
+    grads = {k: np.zeros_like(v) for k, v in gpo.items()}
+    gh = np.zeros((N, dz))
+    for t in reversed(range(T)):
+        gh = gh + gz.reshape(T, N, -1)[t][:, dc:]
+        gh, _ = F.gru_step_bwd(gpo, caches[t], gh, grads)
+    dflat = torch.zeros_like(flat)
+    hl.gru_seq_bwd(N, T, dz, dim_zl, dc, flat, dev(draw['e']), labels, saved, dev(gz), dflat)
+    got = lay.gru_from_dev(dflat, dz, dim_zl, prefix='')
+    for k in grads:
+        assert rel_l2(got[k], grads[k]) < BWD_TOL, k
+
+
+@pytest.mark.parametrize("C,with_ce", [(1, False), (7, False), (7, True)])
+def test_losses(hl, C, with_ce):
+    rng = np.random.RandomState(C)
+    N = 19
+    model = 'infogan' if C == 7 else 'normal'
+    yr, yf = rng.randn(N, C, 1, 1, 1) * 3, rng.randn(N, C, 1, 1, 1) * 3
+    tr, tf = rng.randint(0, 6, N), rng.randint(0, 6, N)
+    l_ref, gr_ref, gf_ref = oupd.loss_dis(model, with_ce, yr, yf, tr, tf)
+    loss = torch.empty(1, device="cuda")
+    gr, gf = torch.empty((N, C), device="cuda"), torch.empty((N, C), device="cuda")
+    hl.loss_dis(N, C, dev(yr.reshape(N, C)), dev(yf.reshape(N, C)), dev(tr, torch.int32), dev(tf, torch.int32), with_ce, loss, gr, gf)
+    assert abs(float(loss) - l_ref) < 1e-5
+    assert rel_l2(gr, gr_ref.reshape(N, C)) < 1e-5 and rel_l2(gf, gf_ref.reshape(N, C)) < 1e-5
+    if C == 7 and not with_ce:
+        return
+    yi = rng.randn(N, C, 1, 1) * 3
+    l_ref, gi_ref, gv_ref = oupd.loss_gen(model, yi, yf, tf)
+    gi, gv = torch.empty((N, C), device="cuda"), torch.empty((N, C), device="cuda")
+    hl.loss_gen(N, C, dev(yi.reshape(N, C)), dev(yf.reshape(N, C)), dev(tf, torch.int32), C == 7, loss, gi, gv)
+    assert abs(float(loss) - l_ref) < 1e-5
+    assert rel_l2(gi, gi_ref.reshape(N, C)) < 1e-5 and rel_l2(gv, gv_ref.reshape(N, C)) < 1e-5
+
+
+def test_adam_weight_decay(hl):
+    rng = np.random.RandomState(9)
+    n = 10007
+    p = {'x/W': rng.randn(n).astype(np.float32)}
+    st = oupd.new_adam_state(p)
+    pd, md, vd = dev(p['x/W']), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for t in (1, 2, 3):
+        g = (rng.randn(n) * 10.0 ** rng.uniform(-9, 0, n)).astype(np.float32)
+        oupd.adam_wd_update(p, {'x/W': g}, st)
+        lr_t = oupd.ADAM_ALPHA * np.sqrt(1 - oupd.ADAM_BETA2 ** t) / (1 - oupd.ADAM_BETA1 ** t)
+        hl.adam_wd(pd, dev(g), md, vd, lr_t, oupd.ADAM_BETA1, oupd.ADAM_BETA2, oupd.ADAM_EPS, oupd.WEIGHT_DECAY)
+        assert np.abs(pd.cpu().numpy() - p['x/W']).max() < 1e-6
