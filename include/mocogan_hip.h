@@ -88,8 +88,9 @@ int mcg_fc_fprop(int M, int K, int Co, const float* x, const float* w, const flo
 /* x = y w (+ bias[k % bias_period]) */
 int mcg_fc_dgrad(int M, int K, int Co, const float* y, const float* w, const float* bias,
                  int bias_period, float* x, void* stream);
-/* dw += y^T x */
-int mcg_fc_wgrad(int M, int K, int Co, const float* x, const float* y, float* dw, void* stream);
+/* dw += y^T x ; db[co] += sum_m y[m][co] when db != NULL */
+int mcg_fc_wgrad(int M, int K, int Co, const float* x, const float* y, float* dw, float* db,
+                 void* stream);
 
 /* ---- BatchNormalization (train mode) + activation + add_noise ------------------------------ */
 /* L.BatchNormalization (model/net.py:50-53,139-141,180-182; Chainer decay 0.9, eps 2e-5).
@@ -106,8 +107,11 @@ int mcg_bn_stats(int64_t M, int C, const float* y, const float* gamma, const flo
  * else sigma * N(0,1) from Philox4x32-10 keyed by (seed, stream_id) when sigma > 0, else none;
  * generated noise is added to channels < c_valid only (padded channels stay exactly zero).
  * Replaces F.relu/F.leaky_relu(bn(.)) followed by add_noise (model/net.py:10-15,110-113,
- * 148-155,189-196). */
-int mcg_bn_act_fwd(int64_t M, int C, int c_valid, const float* y, const float* scale_shift, int act,
+ * 148-155,189-196).
+ * y may be a batch-strided view: when y_rows_per_item > 0, row r of y starts at
+ * y + (r / y_rows_per_item) * y_item_stride + (r % y_rows_per_item) * C  (frame t of a clip). */
+int mcg_bn_act_fwd(int64_t M, int C, int c_valid, const float* y, int64_t y_rows_per_item,
+                   int64_t y_item_stride, const float* scale_shift, int act,
                    const float* addend, float sigma, uint64_t seed, uint64_t stream_id,
                    float* out, void* stream);
 
@@ -127,8 +131,11 @@ int mcg_colsum_acc(int64_t M, int C, const float* g, float* db, void* workspace,
 
 /* ---- layout ------------------------------------------------------------------------------- */
 /* out[N][T][H][W][Cp] = x[N][C][T][H][W] (+ noise as above); padded channels = 0.  Turns the
- * reference-layout real clip batch (model/updater.py:89-90) into D's first conv input. */
-int mcg_pack_clip(int N, int C, int Cp, int T, int HW, const float* x, const float* addend,
+ * reference-layout real clip batch (model/updater.py:89-90) into D's first conv input.
+ * Element (n,c,t,hw) of x is at x + n*x_stride_n + c*x_stride_c + t*HW + hw, so a single frame
+ * x[:, :, t] of a clip batch is expressed with T = 1 and the clip's strides. */
+int mcg_pack_clip(int N, int C, int Cp, int T, int HW, const float* x, int64_t x_stride_n,
+                  int64_t x_stride_c, const float* addend,
                   float sigma, uint64_t seed, uint64_t stream_id, float* out, void* stream);
 /* x[N][C][T][HW] = in[N][T][HW][Cp] (first C channels) */
 int mcg_unpack_clip(int N, int C, int Cp, int T, int HW, const float* in, float* x, void* stream);
@@ -164,8 +171,8 @@ int mcg_loss_gen(int N, int C, const float* y_fake_i, const float* y_fake_v, con
 /* ---- optimiser (train.py:93-101: Chainer Adam + WeightDecay hook) --------------------------- */
 /* g += wd*p; m += (1-b1)(g-m); v += (1-b2)(g*g-v); p -= lr_t * m / (sqrt(v) + eps), with
  * lr_t = alpha*sqrt(1-b2^t)/(1-b1^t) computed by the caller in double. */
-int mcg_adam_wd(int64_t n, float* p, const float* g, float* m, float* v, float lr_t, float beta1,
-                float beta2, float eps, float wd, void* stream);
+int mcg_adam_wd(int64_t n, float* p, const float* g, float* m, float* v, double lr_t, double beta1,
+                double beta2, double eps, double wd, void* stream);
 
 /* out[i] = sigma * N(0,1), the same Philox stream mcg_bn_act_fwd / mcg_pack_clip draw from. */
 int mcg_randn(int64_t n, float sigma, uint64_t seed, uint64_t stream_id, float* out, void* stream);

@@ -175,13 +175,16 @@ __global__ void colsum_finalize_kernel(int nblocks, int C, const float* __restri
 
 // out = act(y*scale+shift) + noise
 __global__ __launch_bounds__(NT) void bn_act_fwd_kernel(long long n4, int C, int c_valid, const float* __restrict__ y,
+                                                        long long item4, long long item_stride,
                                                         const float* __restrict__ ss, int act,
                                                         const float* __restrict__ addend, float sigma,
                                                         uint64_t seed, uint64_t stream_id, float* __restrict__ out) {
     const int C4 = C >> 2;
     for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long long)gridDim.x * NT) {
         int c4 = (int)(i % C4);
-        f32x4 v = *reinterpret_cast<const f32x4*>(y + i * 4);
+        // source may be a batch-strided view (frame t of a clip tensor): item = i / item4
+        long long src = item4 ? (i / item4) * item_stride + (i % item4) * 4 : i * 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(y + src);
         if (ss) {
             f32x4 sc = *reinterpret_cast<const f32x4*>(ss + c4 * 4);
             f32x4 sh = *reinterpret_cast<const f32x4*>(ss + C + c4 * 4);
@@ -245,6 +248,7 @@ int ew_grid(long long n4) {
 // layout kernels
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void pack_clip_kernel(int N, int C, int Cp, int T, int HW, const float* __restrict__ x,
+                                                       long long sn, long long sc,
                                                        const float* __restrict__ addend, float sigma, uint64_t seed,
                                                        uint64_t stream_id, float* __restrict__ out) {
     const long long npix = (long long)N * T * HW;
@@ -253,13 +257,13 @@ __global__ __launch_bounds__(NT) void pack_clip_kernel(int N, int C, int Cp, int
         int hw = (int)(p % HW);
         long long q = p / HW;
         int t = (int)(q % T), n = (int)(q / T);
-        const float* src = x + ((long long)n * C * T + t) * HW + hw;
+        const float* src = x + (long long)n * sn + (long long)t * HW + hw;
         for (int c4 = 0; c4 < Cp4; ++c4) {
             f32x4 v;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 int c = c4 * 4 + k;
-                v[k] = c < C ? src[(long long)c * T * HW] : 0.f;
+                v[k] = c < C ? src[(long long)c * sc] : 0.f;
             }
             long long i4 = p * Cp4 + c4;
             if (addend) v += *reinterpret_cast<const f32x4*>(addend + i4 * 4);
@@ -336,8 +340,13 @@ __global__ __launch_bounds__(NT) void fc_dgrad_kernel(int K, int Co, const float
 }
 
 __global__ __launch_bounds__(NT) void fc_wgrad_kernel(int M, int K, int Co, const float* __restrict__ x, const float* __restrict__ y,
-                                                      float* __restrict__ dw) {
+                                                      float* __restrict__ dw, float* db) {
     const int co = blockIdx.y;
+    if (db && blockIdx.x == 0 && threadIdx.x == 0) {
+        float t = 0.f;
+        for (int m = 0; m < M; ++m) t += y[(long long)m * Co + co];
+        db[co] += t;
+    }
     const int k = (blockIdx.x * NT + threadIdx.x) * 4;
     if (k >= K) return;
     f32x4 s = {0, 0, 0, 0};
@@ -605,11 +614,14 @@ extern "C" int mcg_bn_stats(int64_t M, int C, const float* y, const float* gamma
     return launch_status();
 }
 
-extern "C" int mcg_bn_act_fwd(int64_t M, int C, int c_valid, const float* y, const float* scale_shift, int act, const float* addend,
+extern "C" int mcg_bn_act_fwd(int64_t M, int C, int c_valid, const float* y, int64_t y_rows_per_item, int64_t y_item_stride,
+                              const float* scale_shift, int act, const float* addend,
                               float sigma, uint64_t seed, uint64_t stream_id, float* out, void* stream) {
     if (!y || !out || M <= 0 || C <= 0 || (C & 3)) return MCG_ERR_BAD_ARG;
+    if (y_rows_per_item < 0 || (y_rows_per_item > 0 && (M % y_rows_per_item || (y_item_stride & 3)))) return MCG_ERR_BAD_ARG;
     long long n4 = (long long)M * (C >> 2);
-    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(n4)), dim3(NT), 0, (hipStream_t)stream, n4, C, c_valid, y, scale_shift, act,
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(n4)), dim3(NT), 0, (hipStream_t)stream, n4, C, c_valid, y,
+                       (long long)y_rows_per_item * (C >> 2), (long long)y_item_stride, scale_shift, act,
                        addend, sigma, seed, stream_id, out);
     return launch_status();
 }
@@ -643,11 +655,12 @@ extern "C" int mcg_colsum_acc(int64_t M, int C, const float* g, float* db, void*
     return launch_status();
 }
 
-extern "C" int mcg_pack_clip(int N, int C, int Cp, int T, int HW, const float* x, const float* addend, float sigma, uint64_t seed,
-                             uint64_t stream_id, float* out, void* stream) {
+extern "C" int mcg_pack_clip(int N, int C, int Cp, int T, int HW, const float* x, int64_t x_stride_n, int64_t x_stride_c,
+                             const float* addend, float sigma, uint64_t seed, uint64_t stream_id, float* out, void* stream) {
     if (!x || !out || N <= 0 || C <= 0 || Cp < C || (Cp & 3) || T <= 0 || HW <= 0) return MCG_ERR_BAD_ARG;
     long long npix = (long long)N * T * HW;
-    hipLaunchKernelGGL(pack_clip_kernel, dim3(ew_grid(npix)), dim3(NT), 0, (hipStream_t)stream, N, C, Cp, T, HW, x, addend, sigma, seed, stream_id, out);
+    hipLaunchKernelGGL(pack_clip_kernel, dim3(ew_grid(npix)), dim3(NT), 0, (hipStream_t)stream, N, C, Cp, T, HW, x,
+                       (long long)x_stride_n, (long long)x_stride_c, addend, sigma, seed, stream_id, out);
     return launch_status();
 }
 
@@ -678,9 +691,9 @@ extern "C" int mcg_fc_dgrad(int M, int K, int Co, const float* y, const float* w
     return launch_status();
 }
 
-extern "C" int mcg_fc_wgrad(int M, int K, int Co, const float* x, const float* y, float* dw, void* stream) {
+extern "C" int mcg_fc_wgrad(int M, int K, int Co, const float* x, const float* y, float* dw, float* db, void* stream) {
     if (!x || !dw || !y || M <= 0 || K <= 0 || (K & 3) || Co <= 0) return MCG_ERR_BAD_ARG;
-    hipLaunchKernelGGL(fc_wgrad_kernel, dim3((K / 4 + NT - 1) / NT, Co), dim3(NT), 0, (hipStream_t)stream, M, K, Co, x, y, dw);
+    hipLaunchKernelGGL(fc_wgrad_kernel, dim3((K / 4 + NT - 1) / NT, Co), dim3(NT), 0, (hipStream_t)stream, M, K, Co, x, y, dw, db);
     return launch_status();
 }
 
@@ -720,11 +733,12 @@ extern "C" int mcg_loss_gen(int N, int C, const float* y_fake_i, const float* y_
     return launch_status();
 }
 
-extern "C" int mcg_adam_wd(int64_t n, float* p, const float* g, float* m, float* v, float lr_t, float beta1, float beta2, float eps, float wd,
-                           void* stream) {
+extern "C" int mcg_adam_wd(int64_t n, float* p, const float* g, float* m, float* v, double lr_t, double beta1, double beta2, double eps,
+                           double wd, void* stream) {
     if (!p || !g || !m || !v || n <= 0) return MCG_ERR_BAD_ARG;
-    hipLaunchKernelGGL(adam_wd_kernel, dim3(ew_grid((n + 0) / 1)), dim3(NT), 0, (hipStream_t)stream, (long long)n, p, g, m, v, lr_t, 1.f - beta1,
-                       1.f - beta2, eps, wd);
+    // hyper-parameters arrive as doubles so that (1 - beta) is rounded to fp32 once, like Chainer's python-float arithmetic
+    hipLaunchKernelGGL(adam_wd_kernel, dim3(ew_grid(n)), dim3(NT), 0, (hipStream_t)stream, (long long)n, p, g, m, v, (float)lr_t,
+                       (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)wd);
     return launch_status();
 }
 

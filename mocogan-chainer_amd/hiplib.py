@@ -29,7 +29,7 @@ class ConvGeom(C.Structure):
                 ("x_stride0", C.c_int64), ("x_stride1", C.c_int64)]
 
 
-_P, _I, _I64, _U64, _F = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float
+_P, _I, _I64, _U64, _F, _D = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double
 _GP = C.POINTER(ConvGeom)
 
 # name -> (restype, argtypes); mirrors include/mocogan_hip.h one to one
@@ -41,20 +41,20 @@ SIGNATURES = {
     "mcg_conv_wgrad": (_I, [_GP, _P, _P, _P, _P]),
     "mcg_fc_fprop": (_I, [_I, _I, _I, _P, _P, _P, _P, _P]),
     "mcg_fc_dgrad": (_I, [_I, _I, _I, _P, _P, _P, _I, _P, _P]),
-    "mcg_fc_wgrad": (_I, [_I, _I, _I, _P, _P, _P, _P]),
+    "mcg_fc_wgrad": (_I, [_I, _I, _I, _P, _P, _P, _P, _P]),
     "mcg_bn_workspace_bytes": (_I64, [_I64, _I]),
     "mcg_bn_stats": (_I, [_I64, _I, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P]),
-    "mcg_bn_act_fwd": (_I, [_I64, _I, _I, _P, _P, _I, _P, _F, _U64, _U64, _P, _P]),
+    "mcg_bn_act_fwd": (_I, [_I64, _I, _I, _P, _I64, _I64, _P, _I, _P, _F, _U64, _U64, _P, _P]),
     "mcg_bn_act_bwd": (_I, [_I64, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "mcg_colsum_acc": (_I, [_I64, _I, _P, _P, _P, _P]),
-    "mcg_pack_clip": (_I, [_I, _I, _I, _I, _I, _P, _P, _F, _U64, _U64, _P, _P]),
+    "mcg_pack_clip": (_I, [_I, _I, _I, _I, _I, _P, _I64, _I64, _P, _F, _U64, _U64, _P, _P]),
     "mcg_unpack_clip": (_I, [_I, _I, _I, _I, _I, _P, _P, _P]),
     "mcg_tanh_bwd_to_frames": (_I, [_I, _I, _I64, _P, _P, _P, _P]),
     "mcg_gru_seq_fwd": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mcg_gru_seq_bwd": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "mcg_loss_dis": (_I, [_I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
     "mcg_loss_gen": (_I, [_I, _I, _P, _P, _P, _I, _P, _P, _P, _P]),
-    "mcg_adam_wd": (_I, [_I64, _P, _P, _P, _P, _F, _F, _F, _F, _F, _P]),
+    "mcg_adam_wd": (_I, [_I64, _P, _P, _P, _P, _D, _D, _D, _D, _D, _P]),
     "mcg_randn": (_I, [_I64, _F, _U64, _U64, _P, _P]),
 }
 
@@ -83,9 +83,14 @@ def set_tile_override(t):
     load().mcg_set_tile_override(int(t))
 
 
+_SYNC_EVERY_CALL = os.environ.get("MCG_SYNC", "0") == "1"     # debugging aid: serialise host and device
+
+
 def _check(status, name):
     if status != 0:
         raise McgError("%s failed: %s" % (name, _STATUS.get(status, status)))
+    if _SYNC_EVERY_CALL:
+        torch.cuda.synchronize()
 
 
 def _p(t, dtype=torch.float32):
@@ -144,8 +149,8 @@ def fc_dgrad(M, K, Co, y, w, bias, bias_period, x):
     _check(load().mcg_fc_dgrad(M, K, Co, _p(_dense(y)), _p(_dense(w)), _p(bias), bias_period, _p(_dense(x)), _stream()), "mcg_fc_dgrad")
 
 
-def fc_wgrad(M, K, Co, x, y, dw):
-    _check(load().mcg_fc_wgrad(M, K, Co, _p(_dense(x)), _p(_dense(y)), _p(_dense(dw)), _stream()), "mcg_fc_wgrad")
+def fc_wgrad(M, K, Co, x, y, dw, db=None):
+    _check(load().mcg_fc_wgrad(M, K, Co, _p(_dense(x)), _p(_dense(y)), _p(_dense(dw)), _p(db), _stream()), "mcg_fc_wgrad")
 
 
 def bn_workspace_floats(C_max):
@@ -157,8 +162,12 @@ def bn_stats(M, Cn, y, gamma, beta, stats, avg_mean, avg_var, ws, eps=2e-5, deca
                                eps, decay, _p(ws), _stream()), "mcg_bn_stats")
 
 
-def bn_act_fwd(M, Cn, y, scale_shift, act, out, addend=None, sigma=0.0, seed=0, stream_id=0, c_valid=None):
-    _check(load().mcg_bn_act_fwd(M, Cn, Cn if c_valid is None else c_valid, _p(_dense(y)), _p(scale_shift), act,
+def bn_act_fwd(M, Cn, y, scale_shift, act, out, addend=None, sigma=0.0, seed=0, stream_id=0, c_valid=None,
+               rows_per_item=0, item_stride=0):
+    """y dense [M][Cn], or (rows_per_item > 0) a view whose items are item_stride elements apart."""
+    if rows_per_item == 0:
+        _dense(y)
+    _check(load().mcg_bn_act_fwd(M, Cn, Cn if c_valid is None else c_valid, _p(y), rows_per_item, item_stride, _p(scale_shift), act,
                                  _p(_dense(addend)), sigma, seed, stream_id, _p(_dense(out)), _stream()), "mcg_bn_act_fwd")
 
 
@@ -171,8 +180,11 @@ def colsum_acc(M, Cn, g, db, ws):
     _check(load().mcg_colsum_acc(M, Cn, _p(_dense(g)), _p(db), _p(ws), _stream()), "mcg_colsum_acc")
 
 
-def pack_clip(N, Cn, Cp, T, HW, x, out, addend=None, sigma=0.0, seed=0, stream_id=0):
-    _check(load().mcg_pack_clip(N, Cn, Cp, T, HW, _p(_dense(x)), _p(_dense(addend)), sigma, seed, stream_id,
+def pack_clip(N, Cn, Cp, T, HW, x, out, addend=None, sigma=0.0, seed=0, stream_id=0, stride_n=None, stride_c=None):
+    """x: reference-layout (N,C,T,H,W) tensor, or a frame view of one with explicit strides."""
+    stride_n = Cn * T * HW if stride_n is None else stride_n
+    stride_c = T * HW if stride_c is None else stride_c
+    _check(load().mcg_pack_clip(N, Cn, Cp, T, HW, _p(x), stride_n, stride_c, _p(_dense(addend)), sigma, seed, stream_id,
                                 _p(_dense(out)), _stream()), "mcg_pack_clip")
 
 

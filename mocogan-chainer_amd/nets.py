@@ -1,0 +1,490 @@
+"""The three MoCoGAN networks on the gfx950 kernel library.
+
+Mirrors the architecture of reference model/net.py (ImageGenerator :17-117,
+ImageDiscriminator :119-158, VideoDiscriminator :160-199) but owns its own execution plan:
+parameters live in one flat fp32 buffer per network (so Adam and the gradient all-reduce are
+single launches), activations are channels-last, and forward / backward are explicit kernel
+sequences -- there is no autograd graph.  Every saved tensor a backward pass needs is kept in
+the dict returned by forward, which is what lets the step reproduce Chainer's "backward through
+already-updated weights" ordering (quirk Q5) exactly.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import hiplib as hl
+from . import layout as lay
+
+NOISE_SIGMA_Z = 0.33          # make_hidden: np.random.normal(0, 0.33), model/net.py:55-56
+IMG = 64                      # output size hard-coded in the reference, model/net.py:115
+
+
+class Config:
+    """Stand-in for chainer.config: ``train`` selects batch-stat BN + add_noise (model/net.py:12)."""
+    train = True
+
+
+config = Config()
+
+
+class FlatParams:
+    """Named views into flat parameter / gradient / Adam-moment buffers (device layout)."""
+
+    def __init__(self, specs, device):
+        self.names, self.offsets, self.shapes = [], {}, {}
+        off = 0
+        for name, shape in specs:
+            self.names.append(name)
+            self.offsets[name] = off
+            self.shapes[name] = tuple(shape)
+            off += (int(np.prod(shape)) + 3) // 4 * 4          # keep every view 16-byte aligned
+        self.size = off
+        self.p = torch.zeros(off, dtype=torch.float32, device=device)
+        self.g = torch.zeros_like(self.p)
+        self.m = torch.zeros_like(self.p)
+        self.v = torch.zeros_like(self.p)
+
+    def _view(self, buf, name):
+        o, s = self.offsets[name], self.shapes[name]
+        return buf[o:o + int(np.prod(s))].view(s)
+
+    def param(self, name):
+        return self._view(self.p, name)
+
+    def grad(self, name):
+        return self._view(self.g, name)
+
+    def view(self, buf, name):
+        """buf in 'p' (parameters), 'g' (gradients), 'm' / 'v' (Adam moments)."""
+        return self._view(getattr(self, buf), name)
+
+
+def _np_to(t, device):
+    return torch.as_tensor(np.asarray(t), dtype=torch.float32).to(device)
+
+
+class _Net:
+    """Shared parameter plumbing.  ``ref_shapes`` maps Chainer keys to Chainer shapes."""
+
+    def _alloc(self, specs, device):
+        self.device = torch.device(device)
+        self.fp = FlatParams(specs, self.device)
+        self.t = 0                                             # Adam step counter of this net's optimizer
+        self.ws = torch.empty(hl.bn_workspace_floats(1024), dtype=torch.float32, device=self.device)
+
+    # ---- reference-layout import / export (also the .npz checkpoint format, train.py:139-144) ----
+    def load_reference_params(self, params):
+        for key in self.ref_shapes:
+            if key.endswith('/N'):
+                continue
+            v = _np_to(params[key], self.device)
+            assert tuple(v.shape) == tuple(self.ref_shapes[key]), (key, v.shape, self.ref_shapes[key])
+            self._set_from_ref(key, v)
+
+    def export_reference_params(self):
+        out = {}
+        for key in self.ref_shapes:
+            if key.endswith('/N'):
+                out[key] = np.asarray(self.bn_count.get(key[:-2], 0), dtype=np.int64)
+            else:
+                out[key] = self._get_as_ref(key).detach().cpu().numpy()
+        return out
+
+    def export_reference_grads(self):
+        return {k: self._get_as_ref(k, 'g').detach().cpu().numpy() for k in self.trainable_keys()}
+
+    def trainable_keys(self):
+        return [k for k in self.ref_shapes if k.endswith(('/W', '/b', '/gamma', '/beta'))]
+
+    # ---- optimizer state in the reference layout (part of a Chainer trainer snapshot, train.py:135-138) ----
+    def export_adam_state(self):
+        return {'t': self.t,
+                'm': {k: self._get_as_ref(k, 'm').detach().cpu().numpy() for k in self.trainable_keys()},
+                'v': {k: self._get_as_ref(k, 'v').detach().cpu().numpy() for k in self.trainable_keys()}}
+
+    def load_adam_state(self, state):
+        self.t = int(state['t'])
+        for k in self.trainable_keys():
+            self._set_from_ref(k, _np_to(state['m'][k], self.device), 'm')
+            self._set_from_ref(k, _np_to(state['v'][k], self.device), 'v')
+
+    def zero_grad(self):
+        self.fp.g.zero_()
+
+    def _bn_keys(self, name, c):
+        return {name + '/gamma': (c,), name + '/beta': (c,), name + '/avg_mean': (c,), name + '/avg_var': (c,),
+                name + '/N': ()}
+
+    def _init_bn(self, name):
+        self.fp.param(name + '/gamma').fill_(1.0)
+        self.running[name + '/avg_var'].fill_(1.0)
+
+
+# ==========================================================================================
+# Discriminators
+# ==========================================================================================
+class DisNet(_Net):
+    """ndim=2: ImageDiscriminator (model/net.py:119-158); ndim=3: VideoDiscriminator (:160-199)."""
+
+    def __init__(self, ndim, in_channels=3, out_channels=1, n_filters=64, use_noise=False, noise_sigma=0.2,
+                 video_len=16, device='cuda', seed=None):
+        self.ndim, self.in_channels, self.out_channels = ndim, in_channels, out_channels
+        self.n_filters, self.use_noise, self.noise_sigma = n_filters, use_noise, noise_sigma
+        self.kt = 4 if ndim == 3 else 1
+        self.T0 = video_len if ndim == 3 else 1
+        nf = n_filters
+        self.chans = [in_channels, nf, nf * 2, nf * 4, nf * 8, out_channels]
+        self.cp0 = lay.pad4(in_channels)
+        kshape = (4,) * ndim
+        self.ref_shapes = {}
+        specs = []
+        for l in range(1, 6):
+            co, ci = self.chans[l], self.chans[l - 1]
+            self.ref_shapes['dc%d/W' % l] = (co, ci) + kshape
+            self.ref_shapes['dc%d/b' % l] = (co,)
+            specs.append(('dc%d/W' % l, (co, self.kt, 4, 4, lay.pad4(ci))))
+            specs.append(('dc%d/b' % l, (co,)))
+        for l in (2, 3, 4):
+            self.ref_shapes.update(self._bn_keys('bn%d' % l, self.chans[l]))
+            specs.append(('bn%d/gamma' % l, (self.chans[l],)))
+            specs.append(('bn%d/beta' % l, (self.chans[l],)))
+        self._alloc(specs, device)
+        self.running = {}
+        self.bn_count = {}
+        for l in (2, 3, 4):
+            c = self.chans[l]
+            self.running['bn%d/avg_mean' % l] = torch.zeros(c, device=self.device)
+            self.running['bn%d/avg_var' % l] = torch.ones(c, device=self.device)
+            self.bn_count['bn%d' % l] = 0
+            self._init_bn('bn%d' % l)
+        if seed is not None:
+            self.init_weights(np.random.RandomState(seed))
+
+    def init_weights(self, rng):
+        """GlorotNormal conv weights, zero biases (model/net.py:131,172)."""
+        for l in range(1, 6):
+            shape = self.ref_shapes['dc%d/W' % l]
+            rf = int(np.prod(shape[2:]))
+            std = math.sqrt(2.0 / (shape[1] * rf + shape[0] * rf))
+            self._set_from_ref('dc%d/W' % l, _np_to(rng.normal(0, std, size=shape), self.device))
+
+    def _set_from_ref(self, key, v, buf='p'):
+        if key.endswith('/W'):
+            self.fp.view(buf, key).copy_(lay.conv_w_to_dev(v))
+        elif key in self.running:
+            self.running[key].copy_(v)
+        else:
+            self.fp.view(buf, key).copy_(v)
+
+    def _get_as_ref(self, key, buf='p'):
+        if key in self.running:
+            return self.running[key]
+        t = self.fp.view(buf, key)
+        if key.endswith('/W'):
+            return lay.conv_w_from_dev(t, self.ref_shapes[key][1], self.ndim)
+        return t
+
+    # ---- geometry -------------------------------------------------------------------------
+    def _extents(self, l):
+        """(T, H) of the INPUT of layer l (1..5)."""
+        return self.T0 - (self.kt - 1) * (l - 1), IMG >> (l - 1)
+
+    def _geom(self, l, n, x_stride0=None):
+        t, h = self._extents(l)
+        return hl.make_geom(n, t, h, h, lay.pad4(self.chans[l - 1]), self.chans[l], self.kt, x_stride0=x_stride0)
+
+    # ---- forward ---------------------------------------------------------------------------
+    def forward(self, n, first_input, noise=None, rng=None, update_stats=True):
+        """first_input: callable(out, addend, rng_args) that writes a1 = x + noise into `out`
+        ([n][T][64][64][cp0]).  noise: list of 4 device tensors in device layout (parity mode) or
+        None; rng: (seed, base_stream_id) for in-kernel Philox noise (perf mode) or None.
+        Returns (logits [n][out], saved)."""
+        train = config.train
+        noisy = train and self.use_noise
+        dev = self.device
+
+        def noise_args(l):
+            if not noisy:
+                return dict()
+            if noise is not None:
+                return dict(addend=noise[l - 1])
+            if rng is not None:
+                return dict(sigma=self.noise_sigma, seed=rng[0], stream_id=rng[1] + l - 1)
+            return dict()
+
+        saved = {'n': n, 'a': {}, 'y': {}, 'stats': {}}
+        t, h = self._extents(1)
+        a = torch.empty((n, t, h, h, self.cp0), device=dev)
+        first_input(a, noise_args(1))
+        saved['a'][1] = a
+        for l in (1, 2, 3, 4):
+            g = self._geom(l, n)
+            co = self.chans[l]
+            y = torch.empty((n, g.To, g.Ho, g.Wo, co), device=dev)
+            hl.conv_fprop(g, a, self.fp.param('dc%d/W' % l), self.fp.param('dc%d/b' % l), y)
+            saved['y'][l] = y
+            m = n * g.To * g.Ho * g.Wo
+            ss = None
+            if l >= 2:
+                name = 'bn%d' % l
+                if train:
+                    stats = torch.empty(4 * co, device=dev)
+                    hl.bn_stats(m, co, y, self.fp.param(name + '/gamma'), self.fp.param(name + '/beta'), stats,
+                                self.running[name + '/avg_mean'] if update_stats else None,
+                                self.running[name + '/avg_var'] if update_stats else None, self.ws)
+                    if update_stats:
+                        self.bn_count[name] += 1
+                    saved['stats'][l] = stats
+                    ss = stats[2 * co:]
+                else:
+                    ss = self._test_scale_shift(name)
+            a = torch.empty_like(y)
+            hl.bn_act_fwd(m, co, y, ss, hl.ACT_LRELU, a, **(noise_args(l + 1) if l < 4 else {}))
+            saved['a'][l + 1] = a
+        k = a[0].numel()
+        logits = torch.empty((n, self.out_channels), device=dev)
+        hl.fc_fprop(n, k, self.out_channels, a.view(n, k), self.fp.param('dc5/W').view(self.out_channels, k),
+                    self.fp.param('dc5/b'), logits)
+        return logits, saved
+
+    def _test_scale_shift(self, name):
+        """fixed_batch_normalization (test mode, reference util.py:92): scale/shift from running stats."""
+        inv = torch.rsqrt(self.running[name + '/avg_var'] + 2e-5)
+        scale = self.fp.param(name + '/gamma') * inv
+        return torch.cat((scale, self.fp.param(name + '/beta') - self.running[name + '/avg_mean'] * scale))
+
+    # ---- backward --------------------------------------------------------------------------
+    def backward(self, saved, g_logits, param_grads, gx=None, gx_geom=None, gx_accumulate=False):
+        """g_logits [n][out].  param_grads: accumulate dW/db/dgamma/dbeta into the flat gradient
+        (D's own loss).  gx: when given, the gradient w.r.t. the first conv's input is written
+        (or accumulated) there through gx_geom (G's loss through this D, current weights: Q5)."""
+        n = saved['n']
+        dev = self.device
+        fp = self.fp
+        a5 = saved['a'][5]
+        k = a5[0].numel()
+        co5 = self.out_channels
+        if param_grads:
+            hl.fc_wgrad(n, k, co5, a5.view(n, k), g_logits, fp.grad('dc5/W').view(co5, k), fp.grad('dc5/b'))
+        g = torch.empty_like(a5)
+        hl.fc_dgrad(n, k, co5, g_logits, fp.param('dc5/W').view(co5, k), None, 0, g.view(n, k))
+        for l in (4, 3, 2, 1):
+            geom = self._geom(l, n)
+            co = self.chans[l]
+            y = saved['y'][l]
+            m = n * geom.To * geom.Ho * geom.Wo
+            if l >= 2:
+                name = 'bn%d' % l
+                hl.bn_act_bwd(m, co, g, y, saved['stats'][l], fp.param(name + '/gamma'), hl.ACT_LRELU, g,
+                              fp.grad(name + '/gamma') if param_grads else None,
+                              fp.grad(name + '/beta') if param_grads else None, self.ws)
+            else:
+                hl.bn_act_bwd(m, co, g, y, None, None, hl.ACT_LRELU, g, None, None, self.ws)
+            if param_grads:
+                hl.colsum_acc(m, co, g, fp.grad('dc%d/b' % l), self.ws)
+                hl.conv_wgrad(geom, saved['a'][l], g, fp.grad('dc%d/W' % l))
+            if l > 1:
+                ga = torch.empty_like(saved['a'][l])
+                hl.conv_dgrad(geom, g, fp.param('dc%d/W' % l), None, ga)
+                g = ga
+            elif gx is not None:
+                hl.conv_dgrad(gx_geom if gx_geom is not None else geom, g, fp.param('dc1/W'), None, gx,
+                              accumulate=gx_accumulate)
+
+
+# ==========================================================================================
+# Generator
+# ==========================================================================================
+class GenNet(_Net):
+    """ImageGenerator (model/net.py:17-117): GRU motion codes + 5 transposed convolutions."""
+
+    def __init__(self, dim_zc=50, dim_zm=10, dim_zl=0, out_channels=3, n_filters=64, video_len=16,
+                 device='cuda', seed=None):
+        self.dim_zc, self.dim_zm, self.dim_zl = dim_zc, dim_zm, dim_zl
+        self.out_channels, self.n_filters, self.video_len = out_channels, n_filters, video_len
+        self.n_hidden = dim_zc + dim_zm
+        nf = n_filters
+        self.chans = [self.n_hidden, nf * 8, nf * 4, nf * 2, nf, out_channels]
+        self.cp_out = lay.pad4(out_channels)
+        self.ref_shapes = {}
+        nin = dim_zm + dim_zl
+        self.gru_size = 0
+        for k in lay.GRU_LINKS:
+            cols = dim_zm if k.startswith('U') else nin
+            self.ref_shapes['g0/%s/W' % k] = (dim_zm, cols)
+            self.ref_shapes['g0/%s/b' % k] = (dim_zm,)
+            self.gru_size += dim_zm * cols + dim_zm
+        specs = [('g0', (self.gru_size,))]
+        for l in range(1, 6):
+            ci, co = self.chans[l - 1], self.chans[l]
+            self.ref_shapes['dc%d/W' % l] = (ci, co, 4, 4)
+            self.ref_shapes['dc%d/b' % l] = (co,)
+            specs.append(('dc%d/W' % l, (ci, 1, 4, 4, lay.pad4(co))))
+            specs.append(('dc%d/b' % l, (lay.pad4(co),)))
+        for l in (1, 2, 3, 4):
+            self.ref_shapes.update(self._bn_keys('bn%d' % l, self.chans[l]))
+            specs.append(('bn%d/gamma' % l, (self.chans[l],)))
+            specs.append(('bn%d/beta' % l, (self.chans[l],)))
+        self._alloc(specs, device)
+        self.running, self.bn_count = {}, {}
+        for l in (1, 2, 3, 4):
+            c = self.chans[l]
+            self.running['bn%d/avg_mean' % l] = torch.zeros(c, device=self.device)
+            self.running['bn%d/avg_var' % l] = torch.ones(c, device=self.device)
+            self.bn_count['bn%d' % l] = 0
+            self._init_bn('bn%d' % l)
+        if seed is not None:
+            self.init_weights(np.random.RandomState(seed))
+
+    def init_weights(self, rng):
+        """GlorotNormal deconv weights (model/net.py:35), LeCunNormal GRU Linear weights (Chainer
+        Linear default), zero biases."""
+        for k in lay.GRU_LINKS:
+            shape = self.ref_shapes['g0/%s/W' % k]
+            self._set_from_ref('g0/%s/W' % k, _np_to(rng.normal(0, math.sqrt(1.0 / shape[1]), size=shape), self.device))
+        for l in range(1, 6):
+            shape = self.ref_shapes['dc%d/W' % l]
+            std = math.sqrt(2.0 / (shape[1] * 16 + shape[0] * 16))
+            self._set_from_ref('dc%d/W' % l, _np_to(rng.normal(0, std, size=shape), self.device))
+
+    def _gru_views(self, buf='p'):
+        return lay.gru_from_dev(self.fp.view(buf, 'g0'), self.dim_zm, self.dim_zl)
+
+    def _set_from_ref(self, key, v, buf='p'):
+        if key.startswith('g0/'):
+            self._gru_views(buf)[key].copy_(v)
+        elif key.endswith('/W'):
+            self.fp.view(buf, key).copy_(lay.deconv_w_to_dev(v))
+        elif key in self.running:
+            self.running[key].copy_(v)
+        elif key.startswith('dc') and key.endswith('/b'):
+            self.fp.view(buf, key).copy_(lay.vec_to_dev(v))
+        else:
+            self.fp.view(buf, key).copy_(v)
+
+    def _get_as_ref(self, key, buf='p'):
+        if key in self.running:
+            return self.running[key]
+        if key.startswith('g0/'):
+            return self._gru_views(buf)[key]
+        t = self.fp.view(buf, key)
+        if key.endswith('/W'):
+            return lay.deconv_w_from_dev(t, self.ref_shapes[key][1])
+        if key.startswith('dc') and key.endswith('/b'):
+            return t[:self.ref_shapes[key][0]]
+        return t
+
+    def _geom(self, l, frames, clip_order_n=0):
+        """Conv-form geometry of deconv layer l (2..5): x side = its OUTPUT, y side = its input.
+        clip_order_n = N makes the x side the clip tensor [N][T][H][W][C] (frame f = t*N + n lands at
+        clip n, time t): the (T,N)->(N,T) transpose of model/updater.py:102 costs nothing."""
+        h = 4 << (l - 1)
+        ci = lay.pad4(self.chans[l])
+        if clip_order_n:
+            T = frames // clip_order_n
+            return hl.make_geom(frames, 1, h, h, ci, self.chans[l - 1], 1, x_stride0=T * h * h * ci,
+                                x_perm_n=clip_order_n, x_stride1=h * h * ci)
+        return hl.make_geom(frames, 1, h, h, ci, self.chans[l - 1], 1)
+
+    # ---- latent draws (model/net.py:55-56,66,71,92,102) ------------------------------------------
+    def draw(self, n, rng):
+        """Perf-mode latent draw on the device: rng = (seed, base_stream_id)."""
+        dev = self.device
+        T, dz = self.video_len, self.dim_zm
+        d = {'labels': None}
+        if self.dim_zl:
+            gen = torch.Generator(device=dev)
+            gen.manual_seed((rng[0] * 1000003 + rng[1]) % (2 ** 63))
+            d['labels'] = torch.randint(0, self.dim_zl, (n,), device=dev, dtype=torch.int32, generator=gen)
+        d['h0'] = torch.empty((n, dz), device=dev)
+        d['e'] = torch.empty((T, n, dz), device=dev)
+        d['zc'] = torch.empty((n, self.dim_zc), device=dev)
+        hl.randn(d['h0'], NOISE_SIGMA_Z, rng[0], rng[1])
+        hl.randn(d['e'], NOISE_SIGMA_Z, rng[0], rng[1] + 1)
+        hl.randn(d['zc'], NOISE_SIGMA_Z, rng[0], rng[1] + 2)
+        return d
+
+    # ---- forward ---------------------------------------------------------------------------
+    def forward(self, n, draw, update_stats=True):
+        """draw: dict(h0 [n][dz], e [T][n][dz], zc [n][dc], labels int32 [n] | None) on the device.
+        Returns (x_fake clip tensor [n][T][64][64][cp_out], saved)."""
+        dev = self.device
+        T, dz, dl, dc = self.video_len, self.dim_zm, self.dim_zl, self.dim_zc
+        frames = T * n
+        fp = self.fp
+        train = config.train
+        saved = {'n': n, 'draw': draw, 'y': {}, 'a': {}, 'stats': {}}
+        z = torch.empty((frames, dc + dz), device=dev)
+        gsaved = torch.empty((T, n, 4 * dz), device=dev)
+        hl.gru_seq_fwd(n, T, dz, dl, dc, fp.param('g0'), draw['h0'], draw['e'], draw['labels'], draw['zc'], z, gsaved)
+        saved['z'], saved['gru'] = z, gsaved
+        c1 = self.chans[1]
+        k1 = 16 * c1
+        y = torch.empty((frames, 4, 4, c1), device=dev)
+        hl.fc_dgrad(frames, k1, self.n_hidden, z, fp.param('dc1/W').view(self.n_hidden, k1), fp.param('dc1/b'), c1,
+                    y.view(frames, k1))
+        for l in (1, 2, 3, 4):
+            co = self.chans[l]
+            m = y.numel() // co
+            name = 'bn%d' % l
+            if train:
+                stats = torch.empty(4 * co, device=dev)
+                hl.bn_stats(m, co, y, fp.param(name + '/gamma'), fp.param(name + '/beta'), stats,
+                            self.running[name + '/avg_mean'] if update_stats else None,
+                            self.running[name + '/avg_var'] if update_stats else None, self.ws)
+                if update_stats:
+                    self.bn_count[name] += 1
+                saved['stats'][l] = stats
+                ss = stats[2 * co:]
+            else:
+                inv = torch.rsqrt(self.running[name + '/avg_var'] + 2e-5)
+                scale = fp.param(name + '/gamma') * inv
+                ss = torch.cat((scale, fp.param(name + '/beta') - self.running[name + '/avg_mean'] * scale))
+            saved['y'][l] = y
+            a = torch.empty_like(y)
+            hl.bn_act_fwd(m, co, y, ss, hl.ACT_RELU, a)
+            saved['a'][l + 1] = a
+            h = 4 << l
+            if l < 4:
+                y = torch.empty((frames, h, h, self.chans[l + 1]), device=dev)
+                hl.conv_dgrad(self._geom(l + 1, frames), a, fp.param('dc%d/W' % (l + 1)), fp.param('dc%d/b' % (l + 1)), y)
+        x = torch.empty((n, T, IMG, IMG, self.cp_out), device=dev)
+        hl.conv_dgrad(self._geom(5, frames, clip_order_n=n), saved['a'][5], fp.param('dc5/W'), fp.param('dc5/b'), x,
+                      act=hl.ACT_TANH)
+        saved['x'] = x
+        return x, saved
+
+    # ---- backward --------------------------------------------------------------------------
+    def backward(self, saved, gx_clip):
+        """gx_clip: gradient w.r.t. the clip tensor [n][T][64][64][cp_out].  Accumulates into the flat gradient."""
+        n = saved['n']
+        T, dz, dl, dc = self.video_len, self.dim_zm, self.dim_zl, self.dim_zc
+        frames = T * n
+        fp = self.fp
+        dev = self.device
+        g = torch.empty((frames, IMG, IMG, self.cp_out), device=dev)
+        hl.tanh_bwd_to_frames(n, T, IMG * IMG * self.cp_out, gx_clip, saved['x'], g)
+        for l in (5, 4, 3, 2):
+            geom = self._geom(l, frames)
+            ci = lay.pad4(self.chans[l])
+            m = g.numel() // ci
+            if l < 5:
+                name = 'bn%d' % l
+                hl.bn_act_bwd(m, ci, g, saved['y'][l], saved['stats'][l], fp.param(name + '/gamma'), hl.ACT_RELU, g,
+                              fp.grad(name + '/gamma'), fp.grad(name + '/beta'), self.ws)
+            hl.colsum_acc(m, ci, g, fp.grad('dc%d/b' % l), self.ws)
+            hl.conv_wgrad(geom, g, saved['a'][l], fp.grad('dc%d/W' % l))
+            ga = torch.empty_like(saved['a'][l])
+            hl.conv_fprop(geom, g, fp.param('dc%d/W' % l), None, ga)
+            g = ga
+        c1 = self.chans[1]
+        k1 = 16 * c1
+        hl.bn_act_bwd(frames * 16, c1, g, saved['y'][1], saved['stats'][1], fp.param('bn1/gamma'), hl.ACT_RELU, g,
+                      fp.grad('bn1/gamma'), fp.grad('bn1/beta'), self.ws)
+        hl.colsum_acc(frames * 16, c1, g, fp.grad('dc1/b'), self.ws)
+        hl.fc_wgrad(frames, k1, self.n_hidden, g.view(frames, k1), saved['z'], fp.grad('dc1/W').view(self.n_hidden, k1))
+        gz = torch.empty_like(saved['z'])
+        hl.fc_fprop(frames, k1, self.n_hidden, g.view(frames, k1), fp.param('dc1/W').view(self.n_hidden, k1), None, gz)
+        d = saved['draw']
+        hl.gru_seq_bwd(n, T, dz, dl, dc, fp.param('g0'), d['e'], d['labels'], saved['gru'], gz, fp.grad('g0'))

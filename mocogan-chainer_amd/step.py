@@ -1,0 +1,212 @@
+"""One MoCoGAN training iteration on the device (reference model/updater.py:78-113) and the
+data-parallel gradient exchange.
+
+The kernel schedule reproduces the reference's observable ordering:
+  forwards with the OLD parameters: D_I(real), D_V(real), G, D_I(fake), D_V(fake)      (:97-108)
+  D_I: loss_dis -> backward(real)+backward(fake) -> [all-reduce] -> Adam              (:111)
+  D_V: the same                                                                         (:112)
+  G  : loss_gen -> gradient through the ALREADY UPDATED D_V and D_I (saved activations,
+       new weights / gamma: quirk Q5) -> G backward -> [all-reduce] -> Adam             (:113)
+Gradients Chainer computes into the other networks and then discards (Q6) are not computed.
+"""
+import math
+
+import torch
+
+from . import hiplib as hl
+from . import layout as lay
+from . import nets
+
+
+class AdamHyper:
+    """train.py:93-101 -- Chainer Adam(alpha=2e-4, beta1=5e-5) (beta2 0.999 / eps 1e-8 defaults)
+    plus the WeightDecay(1e-5) hook."""
+
+    def __init__(self, alpha=2e-4, beta1=5e-5, beta2=0.999, eps=1e-8, weight_decay=1e-5):
+        self.alpha, self.beta1, self.beta2, self.eps, self.weight_decay = alpha, beta1, beta2, eps, weight_decay
+
+    def lr(self, t):
+        return self.alpha * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
+
+
+def adam_update(net, hyper):
+    """optimizer.update() tail: hooks, t += 1, per-parameter Adam -- one launch over the flat buffers."""
+    net.t += 1
+    fp = net.fp
+    hl.adam_wd(fp.p, fp.g, fp.m, fp.v, hyper.lr(net.t), hyper.beta1, hyper.beta2, hyper.eps, hyper.weight_decay)
+
+
+class GradExchange:
+    """Data-parallel averaging of one network's flat gradient over the ranks of `group`
+    (RCCL over xGMI on the GPU box, gloo in the CPU tests).  No reference counterpart: the
+    reference is single-device (train.py:87-91).  Each rank runs the step on its own shard of
+    the batch with its own BatchNorm statistics; gradients are averaged, so every rank applies
+    the same Adam update and the replicas stay bit-identical."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+    def start(self, flat_grad):
+        if self.world == 1:
+            return None
+        return self.dist.all_reduce(flat_grad, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self, work, flat_grad):
+        if work is None:
+            return
+        work.wait()
+        flat_grad.mul_(1.0 / self.world)
+
+    def broadcast_params(self, tensors, src=0):
+        if self.world == 1:
+            return
+        for t in tensors:
+            self.dist.broadcast(t, src=src, group=self.group)
+
+
+class TrainStep:
+    """Holds the three networks, their Adam hyper-parameters and runs update_core on device data."""
+
+    def __init__(self, model, gen, dis_i, dis_v, hyper=None, exchange=None, seed=0, rank=0):
+        assert model in ('normal', 'cgan', 'infogan')
+        self.model, self.gen, self.dis_i, self.dis_v = model, gen, dis_i, dis_v
+        self.hyper = hyper or {'image_gen': AdamHyper(), 'image_dis': AdamHyper(), 'video_dis': AdamHyper()}
+        self.exchange = exchange
+        self.seed, self.rank = seed, rank
+        self.iteration = 0
+        self.device = gen.device
+        self.loss = torch.zeros(3, device=self.device)            # loss_dis_i, loss_dis_v, loss_gen
+
+    # ---- cgan label planes (model/updater.py:65-76) -------------------------------------------------
+    def _concat_label_clip(self, x_dev, labels):
+        """x_dev [n][T][H][W][4] with C=3 -> [n][T][H][W][pad4(3+dim_zl)] with -1/+1 label planes."""
+        n, T, H, W, _ = x_dev.shape
+        c, dl = self.gen.out_channels, self.gen.dim_zl
+        out = torch.zeros((n, T, H, W, lay.pad4(c + dl)), device=x_dev.device)
+        out[..., :c] = x_dev[..., :c]
+        planes = -torch.ones((n, dl), device=x_dev.device)
+        planes[torch.arange(n, device=x_dev.device), labels.long()] = 1.0
+        out[..., c:c + dl] = planes.view(n, 1, 1, 1, dl)
+        return out
+
+    # ---- one iteration -------------------------------------------------------------------------
+    def run(self, x_real, t_real=None, inject=None):
+        """x_real: device tensor in the reference layout (N,C,T,H,W) (model/updater.py:89-90).
+        t_real: int32 device tensor (N,) or None.
+        inject: parity mode -- dict with 't', 'noise_{i,v}_{real,fake}' (lists of 4 device tensors in
+        device layout, pre-scaled) and 'gen' (latent draw dict); None = perf mode (Philox in-kernel,
+        frame index from a seeded host generator shared by all ranks, quirk Q7)."""
+        gen, di, dv = self.gen, self.dis_i, self.dis_v
+        n, c_img, T, H, W = x_real.shape
+        hw = H * W
+        it = self.iteration
+        base = (it * 64 + 1) * 4096 + self.rank * 64                # Philox stream ids of this iteration / rank
+        seed = self.seed
+        if inject is not None:
+            t = int(inject['t'])
+        else:
+            g = torch.Generator()
+            g.manual_seed(seed * 7919 + it)                          # same on every rank: one t per iteration
+            t = int(torch.randint(0, T, (1,), generator=g))
+
+        def nz(key):
+            return inject[key] if inject is not None else None
+
+        def rngs(k):
+            return None if inject is not None else (seed, base + 8 * k)
+
+        cgan = self.model == 'cgan'
+        with_ce = self.model == 'infogan'
+        cp = dv.cp0
+
+        # ------------------------------------------------ forward: real
+        if cgan:
+            # label planes are part of D's input: build the device-layout clip once, then add noise
+            tmp = torch.empty((n, T, H, W, lay.pad4(c_img)), device=self.device)
+            hl.pack_clip(n, c_img, lay.pad4(c_img), T, hw, x_real, tmp)
+            xr = self._concat_label_clip(tmp, t_real)
+            c_valid = c_img + gen.dim_zl
+
+            def first_real_v(out, na):
+                hl.bn_act_fwd(n * T * hw, cp, xr, None, hl.ACT_NONE, out, c_valid=c_valid, **na)
+
+            def first_real_i(out, na):
+                hl.bn_act_fwd(n * hw, cp, xr[:, t], None, hl.ACT_NONE, out, c_valid=c_valid, rows_per_item=hw,
+                              item_stride=T * hw * cp, **na)
+        else:
+            def first_real_v(out, na):
+                hl.pack_clip(n, c_img, cp, T, hw, x_real, out, **na)
+
+            def first_real_i(out, na):
+                hl.pack_clip(n, c_img, cp, 1, hw, x_real[:, :, t], out, stride_n=c_img * T * hw, stride_c=T * hw, **na)
+
+        y_real_i, s_real_i = di.forward(n, first_real_i, nz('noise_i_real'), rngs(0))
+        y_real_v, s_real_v = dv.forward(n, first_real_v, nz('noise_v_real'), rngs(1))
+
+        # ------------------------------------------------ forward: fake
+        draw = inject['gen'] if inject is not None else gen.draw(n, (seed, base + 8 * 2))
+        x_fake, s_gen = gen.forward(n, draw)
+        t_fake = draw['labels']
+        xf = self._concat_label_clip(x_fake, t_fake) if cgan else x_fake
+        c_valid = c_img + (gen.dim_zl if cgan else 0)
+
+        def first_fake_v(out, na):
+            hl.bn_act_fwd(n * T * hw, cp, xf, None, hl.ACT_NONE, out, c_valid=c_valid, **na)
+
+        def first_fake_i(out, na):
+            hl.bn_act_fwd(n * hw, cp, xf[:, t], None, hl.ACT_NONE, out, c_valid=c_valid, rows_per_item=hw,
+                          item_stride=T * hw * cp, **na)
+
+        y_fake_i, s_fake_i = di.forward(n, first_fake_i, nz('noise_i_fake'), rngs(3))
+        y_fake_v, s_fake_v = dv.forward(n, first_fake_v, nz('noise_v_fake'), rngs(4))
+
+        cd = di.out_channels
+        gr = torch.empty((n, cd), device=self.device)
+        gf = torch.empty((n, cd), device=self.device)
+        ex = self.exchange
+
+        # ------------------------------------------------ image_dis_optimizer.update(loss_dis, ...)   :111
+        di.zero_grad()
+        hl.loss_dis(n, cd, y_real_i, y_fake_i, t_real, t_fake, False, self.loss[0:1], gr, gf)
+        di.backward(s_real_i, gr, True)
+        di.backward(s_fake_i, gf, True)
+        work_i = ex.start(di.fp.g) if ex else None
+        # ------------------------------------------------ video_dis_optimizer.update(loss_dis, ...)   :112
+        dv.zero_grad()
+        gr2, gf2 = torch.empty_like(gr), torch.empty_like(gf)
+        hl.loss_dis(n, cd, y_real_v, y_fake_v, t_real, t_fake, with_ce, self.loss[1:2], gr2, gf2)
+        dv.backward(s_real_v, gr2, True)
+        dv.backward(s_fake_v, gf2, True)
+        if ex:
+            ex.finish(work_i, di.fp.g)                               # D_I's exchange overlapped D_V's backward
+        adam_update(di, self.hyper['image_dis'])
+        if ex:
+            ex.finish(ex.start(dv.fp.g), dv.fp.g)
+        adam_update(dv, self.hyper['video_dis'])
+        # ------------------------------------------------ image_gen_optimizer.update(loss_gen, ...)   :113
+        gen.zero_grad()
+        gi, gv = gr, gf
+        hl.loss_gen(n, cd, y_fake_i, y_fake_v, t_fake, with_ce, self.loss[2:3], gi, gv)
+        gx = torch.empty_like(xf)
+        dv.backward(s_fake_v, gv, False, gx=gx)                      # new D_V weights, old activations (Q5)
+        gi_geom = hl.make_geom(n, 1, H, W, cp, di.chans[1], 1, x_stride0=T * hw * cp)
+        di.backward(s_fake_i, gi, False, gx=gx[:, t], gx_geom=gi_geom, gx_accumulate=True)
+        if cgan:
+            gxg = torch.zeros_like(x_fake)
+            gxg[..., :c_img] = gx[..., :c_img]                       # label planes carry no gradient to G
+            gx = gxg
+        gen.backward(s_gen, gx)
+        if ex:
+            ex.finish(ex.start(gen.fp.g), gen.fp.g)
+        adam_update(gen, self.hyper['image_gen'])
+        self.iteration += 1
+        return {'x_fake': x_fake, 't_fake': t_fake, 't': t, 'gx_fake': gx, 'saved_gen': s_gen, 'saved_fake_i': s_fake_i, 'saved_fake_v': s_fake_v,
+                'y_real_i': y_real_i, 'y_real_v': y_real_v, 'y_fake_i': y_fake_i, 'y_fake_v': y_fake_v}
+
+    def losses(self):
+        """(loss_dis_i, loss_dis_v, loss_gen) of the last iteration -- forces a host sync."""
+        l = self.loss.cpu().tolist()
+        return {'image_dis/loss': l[0], 'video_dis/loss': l[1], 'image_gen/loss': l[2]}

@@ -110,6 +110,7 @@ def dis_forward(p, x, noise=None, train=True, update_stats=True):
             else:
                 y = F.bn_test_fwd(y, p['bn%d/gamma' % l], p['bn%d/beta' % l],
                                   p['bn%d/avg_mean' % l], p['bn%d/avg_var' % l])
+        cache['min_margin'] = min(cache.get('min_margin', np.inf), float(np.abs(y).min()))
         h = F.leaky_relu_fwd(y, 0.2)
         cache['lrelu'][l] = h
     cache['a'][5] = h
@@ -207,6 +208,7 @@ def gen_forward(p, draw, video_len=16, train=True, update_stats=True):
             else:
                 y = F.bn_test_fwd(y, p['bn%d/gamma' % l], p['bn%d/beta' % l],
                                   p['bn%d/avg_mean' % l], p['bn%d/avg_var' % l])
+            cache['min_margin'] = min(cache.get('min_margin', np.inf), float(np.abs(y).min()))
             x = F.relu_fwd(y)
         else:
             x = np.tanh(y)

@@ -161,6 +161,12 @@ def update_core(model, gen, dis_i, dis_v, opt_g, opt_i, opt_v, x_real, t_real, r
                    y_fake_v=y_fake_v, gx_fake=gx)
     adam_wd_update(gen, g_g, opt_g)
     out.update(loss_dis_i=float(l_i), loss_dis_v=float(l_v), loss_gen=float(l_g), t_fake=t_fake)
+    # Distance of the closest pre-activation to the kink of its ReLU / LeakyReLU.  An fp32
+    # implementation computes these values with ~1e-7 relative rounding error, so an element closer
+    # than that to zero may take the other branch; with a handful of samples per BatchNorm channel a
+    # single flipped element moves the gradients behind it by O(1e-2).  Parity tests use this number
+    # to know whether a step is well conditioned for a tight comparison.
+    out['min_margin'] = min(c['min_margin'] for c in (c_real_i, c_real_v, c_fake_i, c_fake_v, c_gen))
     return out
 
 
