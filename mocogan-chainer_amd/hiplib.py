@@ -126,19 +126,59 @@ def make_geom(N, Ti, Hi, Wi, Ci, Co, kt, x_stride0=None, x_perm_n=0, x_stride1=0
 
 
 # ------------------------------------------------------------------------------------------
+# optional per-launch timing of the conv kernels with HIP events on the launch stream (bench.py's
+# roofline leg).  Off by default; costs two event records per conv launch when on.
+# ------------------------------------------------------------------------------------------
+_timing = None
+_tag = ""
+
+
+def set_tag(tag):
+    """Label (network name) attached to the conv launches that follow."""
+    global _tag
+    _tag = tag
+
+
+def timing_begin():
+    global _timing
+    _timing = {}
+
+
+def timing_end():
+    """-> {"<tag>.<pass>": (launches, total_ms)}; synchronises the device."""
+    global _timing
+    t, _timing = _timing, None
+    torch.cuda.synchronize()
+    return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in (t or {}).items()}
+
+
+def _launch(kind, fn, *args):
+    if _timing is None:
+        return fn(*args)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn(*args)
+    e1.record()
+    _timing.setdefault(_tag + "." + kind, []).append((e0, e1))
+    return r
+
+
+# ------------------------------------------------------------------------------------------
 # thin typed wrappers (tensors in, nothing allocated here)
 # ------------------------------------------------------------------------------------------
 def conv_fprop(g, x, w, bias, y):
-    _check(load().mcg_conv_fprop(C.byref(g), _p(x), _p(_dense(w)), _p(bias), _p(_dense(y)), _stream()), "mcg_conv_fprop")
+    _check(_launch("fprop", load().mcg_conv_fprop, C.byref(g), _p(x), _p(_dense(w)), _p(bias), _p(_dense(y)), _stream()),
+           "mcg_conv_fprop")
 
 
 def conv_dgrad(g, y, w, bias, x, act=ACT_NONE, accumulate=False):
-    _check(load().mcg_conv_dgrad(C.byref(g), _p(_dense(y)), _p(_dense(w)), _p(bias), _p(x), act, int(accumulate), _stream()),
-           "mcg_conv_dgrad")
+    _check(_launch("dgrad", load().mcg_conv_dgrad, C.byref(g), _p(_dense(y)), _p(_dense(w)), _p(bias), _p(x), act,
+                   int(accumulate), _stream()), "mcg_conv_dgrad")
 
 
 def conv_wgrad(g, x, y, dw):
-    _check(load().mcg_conv_wgrad(C.byref(g), _p(x), _p(_dense(y)), _p(_dense(dw)), _stream()), "mcg_conv_wgrad")
+    _check(_launch("wgrad", load().mcg_conv_wgrad, C.byref(g), _p(x), _p(_dense(y)), _p(_dense(dw)), _stream()),
+           "mcg_conv_wgrad")
 
 
 def fc_fprop(M, K, Co, x, w, bias, y):

@@ -133,6 +133,7 @@ class DisNet(_Net):
         self.n_filters, self.use_noise, self.noise_sigma = n_filters, use_noise, noise_sigma
         self.kt = 4 if ndim == 3 else 1
         self.T0 = video_len if ndim == 3 else 1
+        self.tag = 'D_V' if ndim == 3 else 'D_I'
         nf = n_filters
         self.chans = [in_channels, nf, nf * 2, nf * 4, nf * 8, out_channels]
         self.cp0 = lay.pad4(in_channels)
@@ -203,6 +204,7 @@ class DisNet(_Net):
         train = config.train
         noisy = train and self.use_noise
         dev = self.device
+        hl.set_tag(self.tag)
 
         def noise_args(l):
             if not noisy:
@@ -262,6 +264,7 @@ class DisNet(_Net):
         n = saved['n']
         dev = self.device
         fp = self.fp
+        hl.set_tag(self.tag)
         a5 = saved['a'][5]
         k = a5[0].numel()
         co5 = self.out_channels
@@ -414,6 +417,7 @@ class GenNet(_Net):
         frames = T * n
         fp = self.fp
         train = config.train
+        hl.set_tag('G')
         saved = {'n': n, 'draw': draw, 'y': {}, 'a': {}, 'stats': {}}
         z = torch.empty((frames, dc + dz), device=dev)
         gsaved = torch.empty((T, n, 4 * dz), device=dev)
@@ -463,6 +467,7 @@ class GenNet(_Net):
         frames = T * n
         fp = self.fp
         dev = self.device
+        hl.set_tag('G')
         g = torch.empty((frames, IMG, IMG, self.cp_out), device=dev)
         hl.tanh_bwd_to_frames(n, T, IMG * IMG * self.cp_out, gx_clip, saved['x'], g)
         for l in (5, 4, 3, 2):

@@ -210,3 +210,20 @@ class TrainStep:
         """(loss_dis_i, loss_dis_v, loss_gen) of the last iteration -- forces a host sync."""
         l = self.loss.cpu().tolist()
         return {'image_dis/loss': l[0], 'video_dis/loss': l[1], 'image_gen/loss': l[2]}
+
+
+def make_models(model='normal', num_labels=6, channel=3, dim_zc=50, dim_zm=10, n_filters=64, video_length=16,
+                use_noise=True, noise_sigma=0.2, device='cuda', seed=0):
+    """The three networks exactly as train.py:69-85 configures them for --model normal|cgan|infogan
+    (note: n_filters_gen is used for all three nets there, and on MUG num_labels = 6 makes the GRU
+    label-conditioned even for 'normal': quirk Q9)."""
+    if model not in ('normal', 'cgan', 'infogan'):
+        raise ValueError('unknown model %r' % model)
+    if model in ('cgan', 'infogan') and num_labels == 0:
+        raise ValueError('Called %s model, but dataset has no label.' % model)       # train.py:75,81
+    c_d = channel + (num_labels if model == 'cgan' else 0)
+    out_d = 1 + (num_labels if model == 'infogan' else 0)
+    gen = nets.GenNet(dim_zc, dim_zm, num_labels, channel, n_filters, video_length, device=device, seed=seed)
+    dis_i = nets.DisNet(2, c_d, out_d, n_filters, use_noise, noise_sigma, video_length, device=device, seed=seed + 1)
+    dis_v = nets.DisNet(3, c_d, out_d, n_filters, use_noise, noise_sigma, video_length, device=device, seed=seed + 2)
+    return gen, dis_i, dis_v
