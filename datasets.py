@@ -1,0 +1,115 @@
+"""Datasets with the reference's interface (raahii/mocogan-chainer datasets.py: MugDataset :29-107,
+MovingMnistDataset :109-167): ``len(ds)`` and ``ds[i] -> (video float32 (C,T,H,W) in [-1,1), label)``.
+``SyntheticDataset`` produces clips of the same shape and range without any files (benchmarks, smoke
+tests: there is no dataset in this environment)."""
+import glob
+import os
+import re
+from pathlib import Path
+
+import numpy as np
+
+_FRAME = re.compile(r'([0-9]+).jpg')
+MUG_CATEGORIES = {"anger": 0, "disgust": 1, "happiness": 2, "fear": 3, "sadness": 4, "surprise": 5}
+
+
+def _frame_number(name):
+    return int(_FRAME.search(str(name)).group(1))
+
+
+def read_video(paths):
+    from PIL import Image
+    frames = []
+    for p in paths:
+        with Image.open(p) as f:
+            frames.append(np.asarray(f, dtype=np.float32))
+    return np.asarray(frames, dtype=np.float32)
+
+
+class _FrameDirDataset:
+    video_length = 16
+
+    def __len__(self):
+        return len(self.videos)
+
+    def __getitem__(self, i):
+        return self.get_example(i)
+
+    def _load(self, frame_paths, extract_speed=None):
+        n, T = len(frame_paths), self.video_length
+        if n < T:
+            raise ValueError('invalid video length: {} < {}'.format(n, T))
+        if extract_speed and n > T * extract_speed:          # MUG: sample every 2nd frame when long enough
+            needed = extract_speed * (T - 1)
+            gap = n - needed
+            start = 0 if gap == 0 else np.random.randint(0, gap, 1)[0]
+            idx = np.linspace(start, start + needed, T, endpoint=True, dtype=np.int32)
+        else:
+            gap = n - T
+            start = 0 if gap == 0 else np.random.randint(0, gap, 1)[0]
+            idx = np.arange(start, start + T)
+        video = read_video(frame_paths[idx])
+        if video.ndim != 4:
+            raise ValueError('invalid video shape: {}'.format(video.shape))
+        video = (video - 128.) / 128.
+        return video.astype(np.float32).transpose(3, 0, 1, 2)         # (C,T,H,W)
+
+
+class MugDataset(_FrameDirDataset):
+    def __init__(self, root_path, video_length=16):
+        self.root_path, self.video_length, self.extract_speed = Path(root_path), video_length, 2
+        self.video_categories = list(self.root_path.glob("*"))
+        self.num_labels = len(self.video_categories)
+        self.videos = []
+        for cat in self.video_categories:
+            if not cat.is_dir():
+                continue
+            for vp in cat.glob("*"):
+                if vp.is_dir() and len(list(vp.glob("*.jpg"))) >= video_length:
+                    self.videos.append((vp, MUG_CATEGORIES[cat.name]))
+
+    def get_example(self, i):
+        vp, categ = self.videos[i]
+        paths = np.array(sorted(glob.glob(os.path.join(vp, '*.jpg')), key=_frame_number))
+        return self._load(paths, self.extract_speed), categ
+
+
+class MovingMnistDataset(_FrameDirDataset):
+    def __init__(self, dataset_path, video_length=16, save_path="data/dataset/moving_mnist/preprocessed"):
+        self.video_length = video_length
+        save_path = Path(save_path)
+        if not save_path.exists():
+            self.preprocess(dataset_path, save_path)
+        self.videos = [p for p in save_path.glob("*") if p.is_dir()]
+
+    def preprocess(self, dataset_path, save_path):
+        from PIL import Image
+        videos = np.load(dataset_path)                                  # (T, N, 64, 64) uint8
+        videos = np.tile(videos[:, :, :, :, None], (1, 1, 1, 1, 3)).transpose(1, 0, 2, 3, 4)
+        for i, video in enumerate(videos):
+            path = save_path / "{:05d}".format(i)
+            path.mkdir(parents=True, exist_ok=True)
+            for j, img in enumerate(video):
+                Image.fromarray(img).save(path / "{:02d}.jpg".format(j))
+
+    def get_example(self, i):
+        paths = np.array(sorted(self.videos[i].glob("*.jpg"), key=_frame_number))
+        return self._load(paths), None
+
+
+class SyntheticDataset:
+    """`size` clips ~ U(-1,1) of shape (channel, video_length, 64, 64); labels uniform in [0,num_labels)
+    (None when num_labels == 0).  Deterministic per index."""
+
+    def __init__(self, size=256, num_labels=6, channel=3, video_length=16, img_size=64, seed=0):
+        self.size, self.num_labels, self.shape, self.seed = size, num_labels, (channel, video_length, img_size, img_size), seed
+
+    def __len__(self):
+        return self.size
+
+    def __getitem__(self, i):
+        rng = np.random.RandomState(self.seed * 1000003 + int(i))
+        video = rng.uniform(-1, 1, self.shape).astype(np.float32)
+        return video, (int(rng.randint(0, self.num_labels)) if self.num_labels else None)
+
+    get_example = __getitem__

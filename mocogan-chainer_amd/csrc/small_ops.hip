@@ -127,13 +127,30 @@ PartPlan plan_partial(long long M, int C) {
     return p;
 }
 
-__global__ void bn_stats_finalize_kernel(int nblocks, int C, double inv_m, double adjust, const float* __restrict__ part,
+// Finalize kernels: block = FIN_CH channels x FIN_SL slices of the partial-block list; each thread
+// sums its slice in double, slices are combined through LDS in a fixed order (deterministic).
+constexpr int FIN_CH = 32, FIN_SL = 8;
+
+__device__ __forceinline__ bool reduce_partials(int nblocks, int C, const float* __restrict__ part, int& c, double& s, double& ss) {
+    __shared__ double red[2][FIN_SL][FIN_CH];
+    const int cl = threadIdx.x % FIN_CH, sl = threadIdx.x / FIN_CH;
+    c = blockIdx.x * FIN_CH + cl;
+    double a = 0, b2 = 0;
+    if (c < C)
+        for (int b = sl; b < nblocks; b += FIN_SL) { a += part[(long long)b * 2 * C + c]; b2 += part[(long long)b * 2 * C + C + c]; }
+    red[0][sl][cl] = a; red[1][sl][cl] = b2;
+    __syncthreads();
+    if (sl != 0 || c >= C) return false;
+    s = 0; ss = 0;
+    for (int k = 0; k < FIN_SL; ++k) { s += red[0][k][cl]; ss += red[1][k][cl]; }
+    return true;
+}
+
+__global__ __launch_bounds__(FIN_CH * FIN_SL) void bn_stats_finalize_kernel(int nblocks, int C, double inv_m, double adjust, const float* __restrict__ part,
                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                          float* __restrict__ stats, float* avg_mean, float* avg_var, float eps, float decay) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0, ss = 0;
-    for (int b = 0; b < nblocks; ++b) { s += part[(long long)b * 2 * C + c]; ss += part[(long long)b * 2 * C + C + c]; }
+    int c; double s, ss;
+    if (!reduce_partials(nblocks, C, part, c, s, ss)) return;
     double mean = s * inv_m;
     double var = ss * inv_m - mean * mean;
     if (var < 0) var = 0;
@@ -151,13 +168,11 @@ __global__ void bn_stats_finalize_kernel(int nblocks, int C, double inv_m, doubl
 }
 
 // coef[0..C) = gamma*inv_std, [C..2C) = ggamma/M, [2C..3C) = gbeta/M ; dgamma/dbeta accumulated
-__global__ void bn_bwd_finalize_kernel(int nblocks, int C, double inv_m, const float* __restrict__ part,
+__global__ __launch_bounds__(FIN_CH * FIN_SL) void bn_bwd_finalize_kernel(int nblocks, int C, double inv_m, const float* __restrict__ part,
                                        const float* __restrict__ stats, const float* __restrict__ gamma,
                                        float* __restrict__ coef, float* dgamma, float* dbeta) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double gb = 0, gg = 0;
-    for (int b = 0; b < nblocks; ++b) { gb += part[(long long)b * 2 * C + c]; gg += part[(long long)b * 2 * C + C + c]; }
+    int c; double gb, gg;
+    if (!reduce_partials(nblocks, C, part, c, gb, gg)) return;
     coef[c] = gamma[c] * stats[C + c];
     coef[C + c] = (float)(gg * inv_m);
     coef[2 * C + c] = (float)(gb * inv_m);
@@ -165,11 +180,9 @@ __global__ void bn_bwd_finalize_kernel(int nblocks, int C, double inv_m, const f
     if (dbeta) dbeta[c] += (float)gb;
 }
 
-__global__ void colsum_finalize_kernel(int nblocks, int C, const float* __restrict__ part, float* db) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0;
-    for (int b = 0; b < nblocks; ++b) s += part[(long long)b * 2 * C + c];
+__global__ __launch_bounds__(FIN_CH * FIN_SL) void colsum_finalize_kernel(int nblocks, int C, const float* __restrict__ part, float* db) {
+    int c; double s, unused;
+    if (!reduce_partials(nblocks, C, part, c, s, unused)) return;
     db[c] += (float)s;
 }
 
@@ -609,7 +622,7 @@ extern "C" int mcg_bn_stats(int64_t M, int C, const float* y, const float* gamma
     float* part = (float*)workspace;
     hipLaunchKernelGGL(col_partial_kernel<0>, dim3(pl.blocks), dim3(NT), 0, s, (long long)M, C, pl.rows_per_block, y, nullptr, nullptr, 0, part);
     double adjust = (double)M / (M - 1.0 > 1.0 ? M - 1.0 : 1.0);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, pl.blocks, C, 1.0 / (double)M, adjust,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, pl.blocks, C, 1.0 / (double)M, adjust,
                        part, gamma, beta, stats, avg_mean, avg_var, eps, decay);
     return launch_status();
 }
@@ -638,7 +651,7 @@ extern "C" int mcg_bn_act_bwd(int64_t M, int C, const float* g_out, const float*
         float* part = (float*)workspace;
         coef = part + (long long)MAX_PART * 2 * C;
         hipLaunchKernelGGL(col_partial_kernel<1>, dim3(pl.blocks), dim3(NT), 0, s, (long long)M, C, pl.rows_per_block, g_out, y, stats, act, part);
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, pl.blocks, C, 1.0 / (double)M, part, stats, gamma,
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, pl.blocks, C, 1.0 / (double)M, part, stats, gamma,
                            coef, dgamma, dbeta);
     }
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(NT), 0, s, n4, C, g_out, y, stats, coef, act, gx);
@@ -651,7 +664,7 @@ extern "C" int mcg_colsum_acc(int64_t M, int C, const float* g, float* db, void*
     PartPlan pl = plan_partial(M, C);
     float* part = (float*)workspace;
     hipLaunchKernelGGL(col_partial_kernel<2>, dim3(pl.blocks), dim3(NT), 0, s, (long long)M, C, pl.rows_per_block, g, nullptr, nullptr, 0, part);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, pl.blocks, C, part, db);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, pl.blocks, C, part, db);
     return launch_status();
 }
 

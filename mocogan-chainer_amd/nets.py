@@ -77,6 +77,8 @@ class _Net:
     def load_reference_params(self, params):
         for key in self.ref_shapes:
             if key.endswith('/N'):
+                if key in params:
+                    self.bn_count[key[:-2]] = int(params[key])
                 continue
             v = _np_to(params[key], self.device)
             assert tuple(v.shape) == tuple(self.ref_shapes[key]), (key, v.shape, self.ref_shapes[key])
@@ -111,6 +113,17 @@ class _Net:
 
     def zero_grad(self):
         self.fp.g.zero_()
+
+    def to(self, device):
+        """Move every buffer (chainer's to_gpu / to_cpu, train.py:87-91,185-188).  Only a 'cuda' device can
+        run the kernels; host placement exists for construction and checkpoint IO."""
+        device = torch.device(device)
+        for b in ('p', 'g', 'm', 'v'):
+            setattr(self.fp, b, getattr(self.fp, b).to(device))
+        self.running = {k: v.to(device) for k, v in self.running.items()}
+        self.ws = self.ws.to(device)
+        self.device = device
+        return self
 
     def _bn_keys(self, name, c):
         return {name + '/gamma': (c,), name + '/beta': (c,), name + '/avg_mean': (c,), name + '/avg_var': (c,),

@@ -92,6 +92,24 @@ class TrainStep:
         out[..., c:c + dl] = planes.view(n, 1, 1, 1, dl)
         return out
 
+    # ---- perf-mode randomness bookkeeping ----------------------------------------------------------
+    STREAMS_PER_RANK = 64        # Philox stream ids one rank may consume per iteration (uses 5 x 8)
+    MAX_RANKS = 64
+
+    def frame_index(self, it, T):
+        """The frame D_I looks at (model/updater.py:96).  One draw per iteration, shared by the whole
+        batch (quirk Q7) -- and, under data parallelism, by every rank: seeded by (seed, iteration) only."""
+        g = torch.Generator()
+        g.manual_seed(self.seed * 7919 + it)
+        return int(torch.randint(0, T, (1,), generator=g))
+
+    @classmethod
+    def stream_base(cls, it, rank):
+        """First Philox stream id of (iteration, rank): disjoint across both, so every rank adds
+        independent noise / latent codes while sharing the seed."""
+        assert 0 <= rank < cls.MAX_RANKS
+        return (it * cls.MAX_RANKS + rank + 1) * cls.STREAMS_PER_RANK
+
     # ---- one iteration -------------------------------------------------------------------------
     def run(self, x_real, t_real=None, inject=None):
         """x_real: device tensor in the reference layout (N,C,T,H,W) (model/updater.py:89-90).
@@ -103,14 +121,9 @@ class TrainStep:
         n, c_img, T, H, W = x_real.shape
         hw = H * W
         it = self.iteration
-        base = (it * 64 + 1) * 4096 + self.rank * 64                # Philox stream ids of this iteration / rank
+        base = self.stream_base(it, self.rank)
         seed = self.seed
-        if inject is not None:
-            t = int(inject['t'])
-        else:
-            g = torch.Generator()
-            g.manual_seed(seed * 7919 + it)                          # same on every rank: one t per iteration
-            t = int(torch.randint(0, T, (1,), generator=g))
+        t = int(inject['t']) if inject is not None else self.frame_index(it, T)
 
         def nz(key):
             return inject[key] if inject is not None else None

@@ -100,13 +100,17 @@ def zero_grads(p):
 # one iteration
 # ----------------------------------------------------------------------------------------
 def update_core(model, gen, dis_i, dis_v, opt_g, opt_i, opt_v, x_real, t_real, rnd,
-                dim_zl=0, video_len=16, keep=False):
+                dim_zl=0, video_len=16, keep=False, reduce=None):
     """model/updater.py:78-113 with injected randomness.
 
     gen/dis_i/dis_v: parameter dicts (updated IN PLACE, as Chainer does).
     x_real (N,C,T,H,W); t_real (N,) int or None.
     rnd: dict with 't' (frame index, :96), 'noise_i_real', 'noise_v_real', 'noise_i_fake',
          'noise_v_fake' (lists of 4 pre-scaled addends or None) and 'gen' (net.gen_draw()).
+    reduce: optional callable(name, grads_dict) applied in place to each network's gradients just
+         before its Adam update -- the hook the data-parallel tests use to average gradients over
+         ranks (the reference is single-device; SURVEY 8e defines DP as "mean of the per-shard
+         gradients, per-shard BatchNorm statistics").
     Returns dict(loss_dis_i, loss_dis_v, loss_gen [, intermediates when keep=True]).
 
     Ordering quirks reproduced: all four D forwards and the G forward run first with the OLD
@@ -137,6 +141,8 @@ def update_core(model, gen, dis_i, dis_v, opt_g, opt_i, opt_v, x_real, t_real, r
     net.dis_backward(dis_i, c_fake_i, gf, g_i)
     if keep:
         out['grads_dis_i'] = {k: v.copy() for k, v in g_i.items()}
+    if reduce is not None:
+        reduce('image_dis', g_i)
     adam_wd_update(dis_i, g_i, opt_i)
     # video_dis_optimizer.update(self.loss_dis, video_dis, ...)   :112
     l_v, gr, gf = loss_dis(model, True, y_real_v, y_fake_v, t_real, t_fake)
@@ -145,6 +151,8 @@ def update_core(model, gen, dis_i, dis_v, opt_g, opt_i, opt_v, x_real, t_real, r
     net.dis_backward(dis_v, c_fake_v, gf, g_v)
     if keep:
         out['grads_dis_v'] = {k: v.copy() for k, v in g_v.items()}
+    if reduce is not None:
+        reduce('video_dis', g_v)
     adam_wd_update(dis_v, g_v, opt_v)
     # image_gen_optimizer.update(self.loss_gen, image_gen, ...)   :113
     l_g, gi, gv = loss_gen(model, y_fake_i, y_fake_v, t_fake)
@@ -159,6 +167,8 @@ def update_core(model, gen, dis_i, dis_v, opt_g, opt_i, opt_v, x_real, t_real, r
         out['grads_gen'] = {k: v.copy() for k, v in g_g.items()}
         out.update(x_fake=x_fake, y_real_i=y_real_i, y_real_v=y_real_v, y_fake_i=y_fake_i,
                    y_fake_v=y_fake_v, gx_fake=gx)
+    if reduce is not None:
+        reduce('image_gen', g_g)
     adam_wd_update(gen, g_g, opt_g)
     out.update(loss_dis_i=float(l_i), loss_dis_v=float(l_v), loss_gen=float(l_g), t_fake=t_fake)
     # Distance of the closest pre-activation to the kink of its ReLU / LeakyReLU.  An fp32

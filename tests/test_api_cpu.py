@@ -1,0 +1,100 @@
+"""Host-side logic of the reference-facing surface (model.net / model.updater / train.py / util.py /
+datasets.py) that needs no GPU: construction, attributes, checkpoint key scheme, iterator, CLI."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_network_constructors_mirror_the_reference_signatures():
+    from model.net import ImageGenerator, ImageDiscriminator, VideoDiscriminator
+    g = ImageGenerator(dim_zl=6, n_filters=4, device='cpu')
+    assert (g.dim_zc, g.dim_zm, g.dim_zl, g.out_channels, g.n_filters, g.video_len) == (50, 10, 6, 3, 4, 16)
+    assert g.n_hidden == 60 and g.use_label and g.name == 'ImageGenerator'
+    assert g.make_hidden(5, 10).shape == (5, 10) and g.make_hidden(5, 10).dtype == np.float32
+    assert np.array_equal(g.to_one_hot([2, 0], np), np.eye(6, dtype=np.float32)[[2, 0]])
+    d = ImageDiscriminator(3, 7, 4, True, 0.2, device='cpu')
+    assert (d.in_channels, d.out_channels, d.n_filters, d.use_noise, d.noise_sigma, d.name) == (3, 7, 4, True, 0.2, 'ImageDiscriminator')
+    v = VideoDiscriminator(n_filters=4, device='cpu')
+    assert v.name == 'VideoDiscriminator' and v.use_noise is False
+    # Chainer child / parameter names and shapes (also the checkpoint keys)
+    gp, dp, vp = g.serialize_dict(), d.serialize_dict(), v.serialize_dict()
+    assert gp['g0/W_r/W'].shape == (10, 16) and gp['g0/U/W'].shape == (10, 10) and gp['dc1/W'].shape == (60, 32, 4, 4)
+    assert gp['dc5/W'].shape == (4, 3, 4, 4) and gp['dc5/b'].shape == (3,) and gp['bn1/avg_var'].shape == (32,)
+    assert dp['dc1/W'].shape == (4, 3, 4, 4) and dp['dc5/W'].shape == (7, 32, 4, 4) and 'bn1/gamma' not in dp
+    assert vp['dc1/W'].shape == (4, 3, 4, 4, 4) and vp['dc5/W'].shape == (1, 32, 4, 4, 4) and vp['bn4/N'].shape == ()
+    # GlorotNormal scale (model/net.py:35): std = sqrt(2 / (fan_in + fan_out))
+    w = ImageDiscriminator(3, 1, 64, device='cpu').serialize_dict()['dc4/W']
+    assert abs(w.std() / np.sqrt(2.0 / ((256 + 512) * 16)) - 1) < 0.02
+    assert np.all(dp['dc3/b'] == 0) and np.all(dp['bn2/gamma'] == 1)
+
+
+def test_product_path_has_no_cpu_fallback():
+    from model.net import ImageDiscriminator
+    import mocogan_chainer_amd.hiplib as hl
+    d = ImageDiscriminator(n_filters=4, device='cpu')
+    with pytest.raises(hl.McgError):
+        d(np.zeros((1, 3, 64, 64), np.float32))
+
+
+def test_npz_round_trip_uses_chainer_keys(tmp_path):
+    from model.net import ImageGenerator
+    from mocogan_chainer_amd.trainer import save_npz, load_npz
+    g = ImageGenerator(n_filters=4, device='cpu')
+    save_npz(tmp_path / 'gen.npz', g)
+    with np.load(tmp_path / 'gen.npz') as f:
+        keys = set(f.files)
+    assert {'dc1/W', 'dc1/b', 'bn1/gamma', 'bn1/beta', 'bn1/avg_mean', 'bn1/avg_var', 'bn1/N', 'g0/W_r/W', 'g0/U/b'} <= keys
+    g2 = ImageGenerator(n_filters=4, device='cpu')
+    load_npz(tmp_path / 'gen.npz', g2)
+    a, b = g.serialize_dict(), g2.serialize_dict()
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+
+
+def test_serial_iterator_epochs_and_batches():
+    from mocogan_chainer_amd.trainer import SerialIterator
+    from datasets import SyntheticDataset
+    ds = SyntheticDataset(10, num_labels=6)
+    v, l = ds[0]
+    assert v.shape == (3, 16, 64, 64) and v.dtype == np.float32 and -1 <= v.min() and v.max() < 1 and 0 <= l < 6
+    assert SyntheticDataset(3, num_labels=0)[1][1] is None
+    it = SerialIterator(ds, 4)
+    flags = []
+    for _ in range(5):
+        assert len(it.next()) == 4
+        flags.append((it.epoch, it.is_new_epoch))
+    assert flags == [(0, False), (0, False), (1, True), (1, False), (2, True)]
+
+
+def test_grid_and_sequence_helpers():
+    from util import to_grid, to_sequence
+    v = np.arange(2 * 3 * 1 * 2 * 2, dtype=np.uint8).reshape(2, 3, 1, 2, 2)
+    g = to_grid(v, 2)
+    assert g.shape == (2, 1, 4, 4)
+    assert np.array_equal(g[:, :, :2, 2:], v[:, 1]) and np.all(g[:, :, 2:, 2:] == 0)
+    assert to_sequence(v[:, 0]).shape == (1, 2, 4)
+
+
+def test_cli_flags_match_the_reference():
+    import train
+    a = train.parse_args([])
+    assert (a.gpu, a.dataset_type, a.batchsize, a.max_epoch, a.model, a.dim_zc, a.dim_zm) == (-1, 'mug', 100, 1000, 'normal', 50, 10)
+    assert (a.display_interval, a.snapshot_interval, a.log_tensorboard_interval, a.num_gen_samples) == (1, 10, 10, 36)
+    assert (a.n_filters_gen, a.n_filters_idis, a.n_filters_vdis, a.resume) == (64, 64, 64, '')
+    a = train.parse_args(['-g', '0', '--model', 'infogan', '-r', 'snap.npz'])
+    assert a.gpu == 0 and a.model == 'infogan' and a.resume == 'snap.npz'
+    with pytest.raises(SystemExit):
+        train.parse_args(['--model', 'wgan'])
+
+
+def test_optimizer_objects_carry_the_reference_hyperparameters():
+    from mocogan_chainer_amd import trainer as T
+    from model.net import ImageDiscriminator
+    d = ImageDiscriminator(n_filters=4, device='cpu')
+    opt = T.Adam(alpha=2e-4, beta1=5e-5)
+    opt.setup(d)
+    opt.add_hook(T.WeightDecay(1e-5), 'hook_dec')
+    h = opt.hyper()
+    assert (h.alpha, h.beta1, h.beta2, h.eps, h.weight_decay) == (2e-4, 5e-5, 0.999, 1e-8, 1e-5)
+    assert opt.t == 0

@@ -1,0 +1,154 @@
+#!/usr/bin/env python
+"""Training entry point with the reference's flags (raahii/mocogan-chainer train.py:25-45).
+
+Extensions over the reference: ``--dataset_type synthetic`` (no files needed) and, when launched
+through ``python -m torch.distributed.run``, data-parallel training with one process per GPU
+(gradients averaged over RCCL)."""
+import argparse
+import os
+from datetime import datetime
+from pathlib import Path
+
+import numpy as np
+
+from model.net import ImageGenerator, ImageDiscriminator, VideoDiscriminator
+from model.updater import Updater
+from datasets import MugDataset, MovingMnistDataset, SyntheticDataset
+from util import log_tensorboard
+from mocogan_chainer_amd import trainer as T
+
+
+def parse_args(argv=None):
+    try:
+        from pytz import timezone
+        default_name = datetime.now(timezone('Asia/Tokyo')).strftime("%Y_%m%d_%H%M")
+    except Exception:
+        default_name = datetime.now().strftime("%Y_%m%d_%H%M")
+    p = argparse.ArgumentParser(description='Train script')
+    p.add_argument('--gpu', '-g', type=int, default=-1, help='GPU ID (negative value indicates CPU)')
+    p.add_argument('--dataset_type', choices=['mug', 'mnist', 'synthetic'], default='mug', help="dataset type")
+    p.add_argument('--dataset', default='data/dataset/train', help="dataset root path")
+    p.add_argument('--batchsize', type=int, default=100, help="batchsize")
+    p.add_argument('--max_epoch', type=int, default=1000, help="num learning epochs")
+    p.add_argument('--model', type=str, choices=['normal', 'cgan', 'infogan'], default="normal", help="MoCoGAN model")
+    p.add_argument('--save_name', default=default_name, help="save path for log, snapshot etc")
+    p.add_argument('--display_interval', type=int, default=1, help='interval of displaying log to console')
+    p.add_argument('--snapshot_interval', type=int, default=10, help='interval of snapshot')
+    p.add_argument('--log_tensorboard_interval', type=int, default=10, help='interval of log to tensorboard (genenrate samples too)')
+    p.add_argument('--num_gen_samples', type=int, default=36, help='num generate samples')
+    p.add_argument('--dim_zc', type=int, default=50, help='number of dimensions of z content')
+    p.add_argument('--dim_zm', type=int, default=10, help='number of dimensions of z motion')
+    p.add_argument('--n_filters_gen', type=int, default=64, help='number of channelsof image generator')
+    p.add_argument('--n_filters_idis', type=int, default=64, help='number of channel of image discriminator')
+    p.add_argument('--n_filters_vdis', type=int, default=64, help='number of channel of video discriminator')
+    p.add_argument('--resume', '-r', default='', help='Resume the training from snapshot')
+    p.add_argument('--synthetic_size', type=int, default=256, help='clips in the synthetic dataset')
+    p.add_argument('--seed', type=int, default=0)
+    return p.parse_args(argv)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    size, channel, video_length = 64, 3, 16                     # train.py:48-50
+    use_noise, noise_sigma = True, 0.2                           # train.py:56-57
+    nf = args.n_filters_gen                                      # the reference passes n_filters_gen to all three nets
+
+    import torch
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('train.py needs an MI355X: the HIP path has no CPU fallback (the reference\'s --gpu -1 CPU mode '
+                         'is what oracle/ restates for tests)')
+    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', max(args.gpu, 0))))
+    exchange = None
+    if world > 1:
+        import torch.distributed as dist
+        from mocogan_chainer_amd.step import GradExchange
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+        exchange = GradExchange()
+    np.random.seed(args.seed)                                    # identical initial weights on every rank
+
+    if args.dataset_type == "mug":
+        num_labels, train_dataset = 6, MugDataset(args.dataset, video_length)
+    elif args.dataset_type == "mnist":
+        num_labels, train_dataset = 0, MovingMnistDataset(args.dataset, video_length)
+    else:
+        num_labels, train_dataset = 6, SyntheticDataset(args.synthetic_size, 6, channel, video_length, size, seed=rank)
+
+    if args.model == "normal":
+        use_label, c_d, out_d = False, channel, 1
+    elif args.model == "cgan":
+        if num_labels == 0:
+            raise ValueError("Called cgan model, but dataset has no label.")
+        use_label, c_d, out_d = True, channel + num_labels, 1
+    else:
+        if num_labels == 0:
+            raise ValueError("Called cgan model, but dataset has no label.")
+        use_label, c_d, out_d = True, channel, 1 + num_labels
+    image_gen = ImageGenerator(args.dim_zc, args.dim_zm, num_labels, channel, nf, video_length)
+    image_dis = ImageDiscriminator(c_d, out_d, nf, use_noise, noise_sigma)
+    video_dis = VideoDiscriminator(c_d, out_d, nf, use_noise, noise_sigma)
+    np.random.seed(args.seed + 1 + rank)                         # data order / sub-sequence offsets differ per rank
+    train_iter = T.SerialIterator(train_dataset, args.batchsize)
+
+    def make_optimizer(model, alpha=1e-3, beta1=0.9, beta2=0.999):
+        optimizer = T.Adam(alpha=alpha, beta1=beta1)              # beta2 is not forwarded (train.py:94)
+        optimizer.setup(model)
+        optimizer.add_hook(T.WeightDecay(1e-5), 'hook_dec')
+        return optimizer
+
+    opts = {'image_gen': make_optimizer(image_gen, 2e-4, 5e-5, 0.999),
+            'image_dis': make_optimizer(image_dis, 2e-4, 5e-5, 0.999),
+            'video_dis': make_optimizer(video_dis, 2e-4, 5e-5, 0.999)}
+    writer = T.make_summary_writer(Path('runs') / args.save_name) if rank == 0 else T.NullWriter()
+    updater = Updater(model=args.model, models=(image_gen, image_dis, video_dis), video_length=video_length,
+                      img_size=size, channel=channel, dim_zl=num_labels, iterator=train_iter,
+                      tensorboard_writer=writer, optimizer=opts, device=args.gpu, seed=args.seed, exchange=exchange, rank=rank)
+
+    save_path = Path('result') / args.save_name
+    trainer = T.Trainer(updater, (args.max_epoch, 'epoch'), out=save_path)
+    if rank == 0:
+        snap = (args.snapshot_interval, 'epoch')
+        trainer.extend(T.extensions.snapshot(filename='snapshot_epoch_{.updater.epoch}.npz'), trigger=snap)
+        trainer.extend(T.extensions.snapshot_object(image_gen, 'image_gen_epoch_{.updater.epoch}.npz'), trigger=snap)
+        trainer.extend(T.extensions.snapshot_object(image_dis, 'image_dis_epoch_{.updater.epoch}.npz'), trigger=snap)
+        trainer.extend(T.extensions.snapshot_object(video_dis, 'video_dis_epoch_{.updater.epoch}.npz'), trigger=snap)
+        disp = (args.display_interval, 'epoch')
+        trainer.extend(T.extensions.LogReport(trigger=disp), trigger=disp)
+        trainer.extend(T.extensions.PrintReport(['epoch', 'iteration', 'image_gen/loss', 'image_dis/loss', 'video_dis/loss']),
+                       trigger=disp)
+        if np.sqrt(args.num_gen_samples) % 1.0 != 0:
+            raise ValueError('--num_gen_samples must be n^2 (n: natural number).')
+        trainer.extend(log_tensorboard(image_gen, args.num_gen_samples, video_length, writer),
+                       trigger=(args.log_tensorboard_interval, 'epoch'))
+    if args.resume:
+        T.load_npz(args.resume, trainer)
+
+    if rank == 0:
+        print('[ Training configuration ]')
+        print('# gpu: {}  (world size {})'.format(args.gpu, world))
+        print('# minibatch size: {}'.format(args.batchsize))
+        print('# max epoch: {}'.format(args.max_epoch))
+        print('# num batches: {}'.format(len(train_dataset) // args.batchsize))
+        print('# data size: {}'.format(len(train_dataset)))
+        print('# data shape: {}'.format(train_dataset[0][0].shape))
+        print('# num filters igen: {}'.format(nf))
+        print('# num filters idis: {}'.format(args.n_filters_idis))
+        print('# num filters vdis: {}'.format(args.n_filters_vdis))
+        print('# use noise: {}(sigma={})'.format(use_noise, noise_sigma))
+        print('# use label: {}'.format(use_label))
+        print('# snapshot interval: {}'.format(args.snapshot_interval))
+        print('# log tensorboard interval: {}'.format(args.log_tensorboard_interval))
+        print('# num generate samples: {}'.format(args.num_gen_samples))
+        print('')
+    trainer.run()
+    if rank == 0:
+        T.save_npz(save_path / 'image_gen_epoch_fianl.npz', image_gen)     # (sic) train.py:190-192
+        T.save_npz(save_path / 'image_dis_epoch_fianl.npz', image_dis)
+        T.save_npz(save_path / 'video_dis_epoch_fianl.npz', video_dis)
+    return trainer
+
+
+if __name__ == '__main__':
+    main()
