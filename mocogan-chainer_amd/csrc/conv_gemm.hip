@@ -84,6 +84,7 @@ struct FpropP {
     }
     __device__ int k_begin(int) const { return 0; }
     __device__ int k_end(int) const { return K; }
+    __device__ int next_valid(int k0) const { return k0; }
     __device__ void load_a(int k0, f32x4 (&r)[NA]) const {
         int k = k0 + ak;
         int tap = k / g.Ci, ci = k - tap * g.Ci;
@@ -116,17 +117,26 @@ struct DgradP {
     long long abase[NA]; int at[NA], ah[NA], aw[NA]; bool arow_ok[NA];
     int ak;
     int bci; int bkrow[NB]; bool bok;
+    int tmin, tmax;               // range of input time steps covered by this block's rows
 
+    // Rows are ordered (t, n, h', w') -- t slowest -- so that the rows of one block share (almost) one
+    // t: a temporal tap `a` whose source frame t - a falls outside [0, To) is then invalid for the whole
+    // block and its K-steps are skipped (no loads, no MFMAs).  For D_V this removes 19..43 % of the work.
     __device__ void init(int m0, int n0, int tid, int z) {
         ph = z >> 1; pw = z & 1;
         ak = (tid & 7) * 4;
+        {
+            int mlast = m0 + BM - 1 < M ? m0 + BM - 1 : M - 1;
+            tmin = (m0 >> (g.lgWo + g.lgHo)) / g.N;
+            tmax = (mlast >> (g.lgWo + g.lgHo)) / g.N;
+        }
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             int m = m0 + (tid >> 3) + 32 * j;
             arow_ok[j] = m < M;
             int mm = arow_ok[j] ? m : 0;
             int w2 = mm & (g.Wo - 1), h2 = (mm >> g.lgWo) & (g.Ho - 1), q = mm >> (g.lgWo + g.lgHo);
-            int t = q % g.Ti, n = q / g.Ti;
+            int n = q % g.N, t = q / g.N;
             at[j] = t; ah[j] = h2 + ph; aw[j] = w2 + pw;
             abase[j] = (long long)n * g.To * g.Ho * g.Wo * g.Co;
         }
@@ -139,6 +149,17 @@ struct DgradP {
     }
     __device__ int k_begin(int) const { return 0; }
     __device__ int k_end(int) const { return K; }
+    // first K-step >= k0 that has a valid temporal tap for some row of this block
+    __device__ int next_valid(int k0) const {
+        if (g.kt == 1) return k0;
+        while (k0 < K) {
+            int a_lo = (k0 / g.Co) >> 2, a_hi = ((k0 + BK - 1) / g.Co) >> 2;
+            bool dead = a_lo > tmax || a_hi <= tmin - g.To;       // every t - a < 0, or every t - a >= To
+            if (!dead) break;
+            k0 += BK;
+        }
+        return k0;
+    }
     __device__ void load_a(int k0, f32x4 (&r)[NA]) const {
         int k = k0 + ak;
         int ts = k / g.Co, co = k - ts * g.Co;
@@ -163,7 +184,7 @@ struct DgradP {
     __device__ void store(int m, int n, float v) const {
         if (m >= M || n >= g.Ci) return;
         int w2 = m & (g.Wo - 1), h2 = (m >> g.lgWo) & (g.Ho - 1), q = m >> (g.lgWo + g.lgHo);
-        int t = q % g.Ti, nb = q / g.Ti;
+        int nb = q % g.N, t = q / g.N;
         long long o = x_batch_off(g, nb) + ((long long)(t * g.Hi + 2 * h2 + ph) * g.Wi + 2 * w2 + pw) * g.Ci + n;
         if (bias) v += bias[n];
         if (act == MCG_ACT_TANH) v = tanhf(v);
@@ -199,6 +220,7 @@ struct WgradP {
     }
     __device__ int k_begin(int z) const { return z * chunk; }
     __device__ int k_end(int z) const { int e = (z + 1) * chunk; return e < Mpix ? e : Mpix; }
+    __device__ int next_valid(int k0) const { return k0; }
     __device__ void load_a(int k0, f32x4 (&r)[NA]) const {
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
@@ -255,12 +277,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(P p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     f32x4 ra[NA], rb[NB];
-    int k0 = p.k_begin(z);
     const int kend = p.k_end(z);
+    int k0 = p.next_valid(p.k_begin(z));
     if (k0 < kend) { p.load_a(k0, ra); p.load_b(k0, rb); }
 
     constexpr int A_C4 = A_C / 4, B_C4 = B_C / 4;
-    for (; k0 < kend; k0 += BK) {
+    while (k0 < kend) {
         // registers -> LDS
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
@@ -273,7 +295,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(P p) {
             *reinterpret_cast<f32x4*>(&Bs[(q / B_C4) * B_LD + (q % B_C4) * 4]) = rb[j];
         }
         __syncthreads();
-        if (k0 + BK < kend) { p.load_a(k0 + BK, ra); p.load_b(k0 + BK, rb); }   // prefetch next step
+        const int kn = p.next_valid(k0 + BK);
+        if (kn < kend) { p.load_a(kn, ra); p.load_b(kn, rb); }                  // prefetch the next live step
 #pragma unroll
         for (int gk = 0; gk < BK / 8; ++gk) {
             float fa[TM][4], fb[TN][4];
@@ -306,6 +329,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(P p) {
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
         }
         __syncthreads();
+        k0 = kn;
     }
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -319,6 +343,99 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(P p) {
                 int col = n0 + wn0 + b * 32 + li;
                 p.store(row, col, acc[a][b][r]);
             }
+}
+
+// ------------------------------------------------------------------------------------------
+// dgrad for Ci == 4, Co == 64 (the 3-channel clip padded to 4: D's first layer backward and G's
+// last layer forward).  N = 4 output columns would waste 15/16 of a 64-wide MFMA tile, so this case
+// runs on the VALU with fully coalesced loads: a wave works on a run of 16 consecutive output pixels
+// of one parity class; lane = (pixel group pg = lane>>4, channel quad c4 = lane&15) so that the 16
+// lanes of a group read one y pixel's 64 channels as one 256-byte row.  Each lane accumulates, for its
+// 4 pixels (pg*4 + p), the partial sums over its 4 input channels; a 4-step reduce-scatter over the 16
+// lanes leaves lane c4 with output (p = c4>>2, ci = c4&3).  The class's KT*4 taps x 64 x 4 weights sit
+// in LDS as [tap][j][c4] float4 (conflict-free ds_read_b128).
+// ------------------------------------------------------------------------------------------
+constexpr int C4_RUNS_PER_WAVE = 8;
+
+template <int KT>
+__global__ __launch_bounds__(NTHREADS) void dgrad_c4_kernel(Geom g, const float* __restrict__ y, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ x, int act,
+                                                            int accumulate, int runs /* 16-pixel runs per class */) {
+    __shared__ f32x4 wl[KT * 4 * 64];
+    const int z = blockIdx.y, ph = z >> 1, pw = z & 1;
+    constexpr int Co = 64;
+    for (int i = threadIdx.x; i < KT * 4 * Co; i += NTHREADS) {
+        int ts = i >> 6, r = i & 63, jj = r >> 4, c4 = r & 15;        // LDS index (ts*4 + jj)*16 + c4 <- co = c4*4 + jj
+        int a = ts >> 2, bh = (ts >> 1) & 1, bw = ts & 1;
+        int tap = a * 16 + ((1 - ph) + 2 * bh) * 4 + (1 - pw) + 2 * bw;
+        wl[i] = *reinterpret_cast<const f32x4*>(w + ((long long)(c4 * 4 + jj) * g.taps + tap) * 4);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pg = lane >> 4, c4 = lane & 15;
+    const int lgR = g.lgWo - 4;                                       // runs per output row = Wo / 16
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const float bv = bias ? bias[c4 & 3] : 0.f;
+    for (int it = 0; it < C4_RUNS_PER_WAVE; ++it) {
+        const int run = (blockIdx.x * (NTHREADS / 64) + wave) * C4_RUNS_PER_WAVE + it;     // wave-uniform
+        if (run >= runs) break;
+        const int w0 = (run & ((1 << lgR) - 1)) << 4, h2 = (run >> lgR) & (g.Ho - 1), q = run >> (lgR + g.lgHo);
+        const int n = q % g.N, t = q / g.N;
+        const float* yb = y + (long long)n * g.To * g.Ho * g.Wo * Co + c4 * 4;
+        f32x4 acc[4] = {zero, zero, zero, zero};
+#pragma unroll
+        for (int a = 0; a < KT; ++a) {
+            const int to = t - a;
+            if ((unsigned)to >= (unsigned)g.To) continue;             // wave-uniform
+#pragma unroll
+            for (int bh = 0; bh < 2; ++bh) {
+                const int ho = h2 + ph - bh;
+                if ((unsigned)ho >= (unsigned)g.Ho) continue;         // wave-uniform
+                const float* yr = yb + (long long)(to * g.Ho + ho) * g.Wo * Co;
+#pragma unroll
+                for (int bw = 0; bw < 2; ++bw) {
+                    const int wob = w0 + pg * 4 + pw - bw;
+                    f32x4 yv[4];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const int wo = wob + p;
+                        const bool v = (unsigned)wo < (unsigned)g.Wo;
+                        f32x4 t4 = *reinterpret_cast<const f32x4*>(yr + (long long)(v ? wo : 0) * Co);
+                        yv[p] = v ? t4 : zero;
+                    }
+                    const f32x4* wp = wl + (a * 4 + bh * 2 + bw) * 64 + c4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 wv = wp[j * 16];
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) acc[p] += yv[p][j] * wv;
+                    }
+                }
+            }
+        }
+        // reduce-scatter over the 16 lanes of the group: value index v = p*4 + ci ends on lane c4 == v
+        float v16[16];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v16[p * 4 + c] = acc[p][c];
+#pragma unroll
+        for (int half = 8; half >= 1; half >>= 1) {
+            const bool up = (c4 & half) != 0;
+#pragma unroll
+            for (int i2 = 0; i2 < half; ++i2) {
+                const float lo = v16[i2], hi = v16[i2 + half];
+                const float send = up ? lo : hi, keep = up ? hi : lo;
+                v16[i2] = keep + __shfl_xor(send, half, 64);
+            }
+        }
+        float r = v16[0] + bv;
+        if (act == MCG_ACT_TANH) r = tanhf(r);
+        const int p = c4 >> 2, ci = c4 & 3;
+        const long long o = x_batch_off(g, n) + ((long long)(t * g.Hi + 2 * h2 + ph) * g.Wi + 2 * (w0 + pg * 4 + p) + pw) * 4 + ci;
+        if (accumulate) r += x[o];
+        x[o] = r;
+    }
 }
 
 int ilog2_exact(int v) {
@@ -396,8 +513,11 @@ extern "C" int mcg_conv_fprop(const mcg_conv_geom* c, const float* x, const floa
     if (!x || !w || !y) return MCG_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     long long M = (long long)g.N * g.To * g.Ho * g.Wo;
+    // Tile choice (measured on MI355X, tools/bench_layers.py): 128x128 only when there are enough tiles
+    // that the last partial round of blocks does not matter, else 128x64, else 64x64 to fill 256 CUs.
     int t = g_tile_override;
-    if (!t) t = g.Co <= 64 ? 2 : (M * ((g.Co + 127) / 128) / 128 >= 512 ? 1 : 3);
+    const long long mt = (M + 127) / 128;
+    if (!t) t = g.Co <= 64 ? 2 : (mt * ((g.Co + 127) / 128) >= 1024 ? 1 : (mt * ((g.Co + 63) / 64) >= 512 ? 2 : 3));
     if (t == 1) launch_fprop<128, 128>(g, x, w, bias, y, s);
     else if (t == 2) launch_fprop<128, 64>(g, x, w, bias, y, s);
     else launch_fprop<64, 64>(g, x, w, bias, y, s);
@@ -414,7 +534,19 @@ extern "C" int mcg_conv_dgrad(const mcg_conv_geom* c, const float* y, const floa
     hipStream_t s = (hipStream_t)stream;
     long long M = (long long)g.N * g.Ti * g.Ho * g.Wo;
     int t = g_tile_override;
-    if (!t) t = g.Ci <= 64 ? 2 : (4 * M * ((g.Ci + 127) / 128) / 128 >= 512 ? 1 : 3);
+    if (!t && g.Ci == 4 && g.Co == 64 && (g.Wo & 15) == 0) {      // VALU kernel for the padded 3-channel clip
+        const int runs = (int)(M / 16);
+        const int per_block = (NTHREADS / 64) * C4_RUNS_PER_WAVE;
+        dim3 grid((runs + per_block - 1) / per_block, 4, 1);
+        if (g.kt == 4) hipLaunchKernelGGL(dgrad_c4_kernel<4>, grid, dim3(NTHREADS), 0, s, g, y, w, bias, x, act, accumulate, runs);
+        else hipLaunchKernelGGL(dgrad_c4_kernel<1>, grid, dim3(NTHREADS), 0, s, g, y, w, bias, x, act, accumulate, runs);
+        return launch_status();
+    }
+    if (!t) {
+        const long long mt = (M + 127) / 128;
+        if (4 * mt * ((g.Ci + 63) / 64) < 256) t = 3;                       // tiny problem: fill the CUs first
+        else t = g.Ci <= 64 ? 2 : (4 * mt * ((g.Ci + 127) / 128) >= 1024 ? 1 : 2);
+    }
     if (t == 1) launch_dgrad<128, 128>(g, y, w, bias, x, act, accumulate, s);
     else if (t == 2) launch_dgrad<128, 64>(g, y, w, bias, x, act, accumulate, s);
     else launch_dgrad<64, 64>(g, y, w, bias, x, act, accumulate, s);

@@ -46,6 +46,8 @@ CONV_CASES = [
     (3, 1, 16, 16, 32, 1),     # 2-D, Co < tile
     (2, 4, 8, 64, 160, 4),     # Co not a multiple of the tile
     (5, 1, 4, 32, 256, 1),     # tiny spatial extent, M not a multiple of the tile
+    (2, 5, 32, 3, 64, 4),      # Ci = 4, Co = 64, Wo % 16 == 0: the VALU dgrad kernel (tile 0), 3-D
+    (3, 1, 32, 3, 64, 1),      # the same, 2-D
 ]
 
 
@@ -106,7 +108,11 @@ def test_conv_frame_view_and_frame_permutation(hl):
     assert rel_l2(lay.act_from_dev(yd, Co, 2), y_ref) < FWD_TOL
 
     # deconv forward of T*N frames written straight into clip order, with bias + tanh
-    Ci_d = 16
+    for Ci_d, H in ((16, 16), (64, 32)):                    # GEMM path / VALU path (Ci = 4, Co = 64, Wo = 16)
+        _deconv_into_clip_order(hl, lay, rng, N, T, H, C, Ci_d)
+
+
+def _deconv_into_clip_order(hl, lay, rng, N, T, H, C, Ci_d):
     xin = rng.randn(T * N, Ci_d, H // 2, H // 2)
     Wd = rng.randn(Ci_d, C, 4, 4) * 0.1
     bd = rng.randn(C) * 0.1

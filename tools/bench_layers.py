@@ -1,0 +1,75 @@
+#!/usr/bin/env python
+"""Per-layer timing of the implicit-GEMM conv kernels at the step's shapes (tuning aid).
+usage: python tools/bench_layers.py [--batch 32] [--tile T] [--only fprop|dgrad|wgrad]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import mocogan_chainer_amd.hiplib as hl
+
+
+def layers(B):
+    out = []
+    ch = [4, 64, 128, 256, 512]
+    real = [3, 64, 128, 256, 512]
+    t, h = 16, 64
+    for l in range(4):                                   # D_V dc1..dc4
+        out.append(('D_V.dc%d' % (l + 1), B, t, h, ch[l], ch[l + 1], 4, real[l]))
+        t, h = t - 3, h // 2
+    h = 64
+    for l in range(4):                                   # D_I dc1..dc4
+        out.append(('D_I.dc%d' % (l + 1), B, 1, h, ch[l], ch[l + 1], 1, real[l]))
+        h //= 2
+    gch = [512, 256, 128, 64, 4]
+    greal = [512, 256, 128, 64, 3]
+    for l in range(4):                                   # G dc2..dc5 in conv form: x side = output
+        out.append(('G.dc%d' % (l + 2), 16 * B, 1, 8 << l, gch[l + 1], gch[l], 1, greal[l + 1]))
+    return out
+
+
+def timeit(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--tile', type=int, default=0)
+    ap.add_argument('--only', default='')
+    args = ap.parse_args()
+    hl.load()
+    hl.set_tile_override(args.tile)
+    print('%-10s %-6s %10s %10s %8s' % ('layer', 'pass', 'ms', 'TFLOP/s', 'GFLOP'))
+    tot = {}
+    for name, N, T, H, Ci, Co, kt, ci_real in layers(args.batch):
+        g = hl.make_geom(N, T, H, H, Ci, Co, kt)
+        x = torch.randn((N, T, H, H, Ci), device='cuda')
+        y = torch.randn((N, g.To, g.Ho, g.Wo, Co), device='cuda')
+        w = torch.randn((Co, kt, 4, 4, Ci), device='cuda') * 0.05
+        dw = torch.zeros_like(w)
+        flops = 2.0 * N * g.To * g.Ho * g.Wo * kt * 16 * ci_real * Co
+        for p, fn in (('fprop', lambda: hl.conv_fprop(g, x, w, None, y)),
+                      ('dgrad', lambda: hl.conv_dgrad(g, y, w, None, x)),
+                      ('wgrad', lambda: hl.conv_wgrad(g, x, y, dw))):
+            if args.only and p != args.only:
+                continue
+            ms = timeit(fn)
+            tot[p] = tot.get(p, 0) + ms
+            print('%-10s %-6s %10.3f %10.1f %8.1f' % (name, p, ms, flops / ms / 1e9, flops / 1e9))
+    print('totals (ms):', {k: round(v, 3) for k, v in tot.items()})
+
+
+if __name__ == '__main__':
+    main()
