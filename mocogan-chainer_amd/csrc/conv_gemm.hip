@@ -27,6 +27,7 @@ constexpr int NTHREADS = 256;
 struct Geom {
     int N, Ti, Hi, Wi, Ci, To, Ho, Wo, Co, kt;
     int lgHo, lgWo;
+    int lgCi, lgCo;    // log2 when the channel count is a power of two, else -1 (division fallback)
     int perm_n;
     long long xs0, xs1;
     int taps;          // kt * 16
@@ -35,6 +36,13 @@ struct Geom {
 __device__ __forceinline__ long long x_batch_off(const Geom& g, int n) {
     if (g.perm_n) return (long long)(n % g.perm_n) * g.xs0 + (long long)(n / g.perm_n) * g.xs1;
     return (long long)n * g.xs0;
+}
+
+// k -> (k / C, k % C) with a shift when C is a power of two (every layer of the reference; cgan's 12
+// input channels take the division)
+__device__ __forceinline__ void divmod_c(int k, int C, int lgC, int& q, int& r) {
+    if (lgC >= 0) { q = k >> lgC; r = k & (C - 1); }
+    else { q = k / C; r = k - q * C; }
 }
 
 __device__ __forceinline__ f32x4 ld4(const float* p, bool valid) {
@@ -87,9 +95,10 @@ struct FpropP {
     __device__ int next_valid(int k0) const { return k0; }
     __device__ void load_a(int k0, f32x4 (&r)[NA]) const {
         int k = k0 + ak;
-        int tap = k / g.Ci, ci = k - tap * g.Ci;
+        int tap, ci;
+        divmod_c(k, g.Ci, g.lgCi, tap, ci);
         int a = tap >> 4, kh = (tap >> 2) & 3, kw = tap & 3;
-        long long off = ((long long)(a * g.Hi + kh) * g.Wi + kw) * g.Ci + ci;
+        int off = ((a * g.Hi + kh) * g.Wi + kw) * g.Ci + ci;          // < 2^31: checked in make_geom
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             bool ok = arow_ok[j] && (unsigned)(ahi[j] + kh) < (unsigned)g.Hi && (unsigned)(awi[j] + kw) < (unsigned)g.Wi;
@@ -98,7 +107,7 @@ struct FpropP {
     }
     __device__ void load_b(int k0, f32x4 (&r)[NB]) const {
 #pragma unroll
-        for (int j = 0; j < NB; ++j) r[j] = ld4(w + (long long)bco[j] * K + k0 + ak, bok[j]);
+        for (int j = 0; j < NB; ++j) r[j] = ld4(w + (bco[j] * K + k0 + ak), bok[j]);
     }
     __device__ void store(int m, int n, float v) const {
         if (m < M && n < g.Co) y[(long long)m * g.Co + n] = v + (bias ? bias[n] : 0.f);
@@ -153,7 +162,10 @@ struct DgradP {
     __device__ int next_valid(int k0) const {
         if (g.kt == 1) return k0;
         while (k0 < K) {
-            int a_lo = (k0 / g.Co) >> 2, a_hi = ((k0 + BK - 1) / g.Co) >> 2;
+            int q0, q1, r_;
+            divmod_c(k0, g.Co, g.lgCo, q0, r_);
+            divmod_c(k0 + BK - 1, g.Co, g.lgCo, q1, r_);
+            int a_lo = q0 >> 2, a_hi = q1 >> 2;
             bool dead = a_lo > tmax || a_hi <= tmin - g.To;       // every t - a < 0, or every t - a >= To
             if (!dead) break;
             k0 += BK;
@@ -162,23 +174,25 @@ struct DgradP {
     }
     __device__ void load_a(int k0, f32x4 (&r)[NA]) const {
         int k = k0 + ak;
-        int ts = k / g.Co, co = k - ts * g.Co;
+        int ts, co;
+        divmod_c(k, g.Co, g.lgCo, ts, co);
         int a = ts >> 2, bh = (ts >> 1) & 1, bw = ts & 1;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             int to = at[j] - a, ho = ah[j] - bh, wo = aw[j] - bw;
             bool ok = arow_ok[j] && (unsigned)to < (unsigned)g.To && (unsigned)ho < (unsigned)g.Ho && (unsigned)wo < (unsigned)g.Wo;
-            r[j] = ld4(y + abase[j] + ((long long)(to * g.Ho + ho) * g.Wo + wo) * g.Co + co, ok);
+            r[j] = ld4(y + abase[j] + (((to * g.Ho + ho) * g.Wo + wo) * g.Co + co), ok);
         }
     }
     __device__ void load_b(int k0, f32x4 (&r)[NB]) const {
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             int k = k0 + bkrow[j];
-            int ts = k / g.Co, co = k - ts * g.Co;
+            int ts, co;
+            divmod_c(k, g.Co, g.lgCo, ts, co);
             int a = ts >> 2, bh = (ts >> 1) & 1, bw = ts & 1;
             int tap = a * 16 + ((1 - ph) + 2 * bh) * 4 + (1 - pw) + 2 * bw;
-            r[j] = ld4(w + ((long long)co * g.taps + tap) * g.Ci + bci, bok);
+            r[j] = ld4(w + ((co * g.taps + tap) * g.Ci + bci), bok);
         }
     }
     __device__ void store(int m, int n, float v) const {
@@ -452,6 +466,7 @@ int make_geom(const mcg_conv_geom* c, Geom& g) {
     g.perm_n = c->x_perm_n; g.xs0 = c->x_stride0; g.xs1 = c->x_stride1;
     g.taps = c->kt * 16;
     g.lgHo = ilog2_exact(g.Ho); g.lgWo = ilog2_exact(g.Wo);
+    g.lgCi = ilog2_exact(g.Ci); g.lgCo = ilog2_exact(g.Co);
     if (g.N <= 0 || g.Ci <= 0 || g.Co <= 0) return MCG_ERR_BAD_ARG;
     if (g.lgHo < 0 || g.lgWo < 0) return MCG_ERR_BAD_ARG;
     if ((g.Ci & 3) || (g.Co & 3)) return MCG_ERR_BAD_ARG;
@@ -459,6 +474,10 @@ int make_geom(const mcg_conv_geom* c, Geom& g) {
     if (g.Hi != 2 * g.Ho || g.Wi != 2 * g.Wo || g.To != g.Ti - g.kt + 1 || g.To <= 0) return MCG_ERR_UNSUPPORTED;
     // element offsets inside one tensor are kept in 64 bit, pixel counts in 32 bit
     if ((long long)g.N * g.Ti * g.Hi * g.Wi >= (1ll << 31)) return MCG_ERR_UNSUPPORTED;
+    // in-tensor element offsets of y, w and of one batch item of x are computed in 32 bit
+    if ((long long)g.N * g.To * g.Ho * g.Wo * g.Co >= (1ll << 31)) return MCG_ERR_UNSUPPORTED;
+    if ((long long)g.Ti * g.Hi * g.Wi * g.Ci >= (1ll << 31)) return MCG_ERR_UNSUPPORTED;
+    if ((long long)g.Co * g.taps * g.Ci >= (1ll << 31)) return MCG_ERR_UNSUPPORTED;
     return MCG_OK;
 }
 
@@ -544,7 +563,7 @@ extern "C" int mcg_conv_dgrad(const mcg_conv_geom* c, const float* y, const floa
     }
     if (!t) {
         const long long mt = (M + 127) / 128;
-        if (4 * mt * ((g.Ci + 63) / 64) < 256) t = 3;                       // tiny problem: fill the CUs first
+        if (4 * mt * ((g.Ci + 63) / 64) < 512) t = 3;                       // few blocks: finer tiles balance the CUs
         else t = g.Ci <= 64 ? 2 : (4 * mt * ((g.Ci + 127) / 128) >= 1024 ? 1 : 2);
     }
     if (t == 1) launch_dgrad<128, 128>(g, y, w, bias, x, act, accumulate, s);

@@ -129,7 +129,7 @@ PartPlan plan_partial(long long M, int C) {
 
 // Finalize kernels: block = FIN_CH channels x FIN_SL slices of the partial-block list; each thread
 // sums its slice in double, slices are combined through LDS in a fixed order (deterministic).
-constexpr int FIN_CH = 32, FIN_SL = 8;
+constexpr int FIN_CH = 8, FIN_SL = 32;
 
 __device__ __forceinline__ bool reduce_partials(int nblocks, int C, const float* __restrict__ part, int& c, double& s, double& ss) {
     __shared__ double red[2][FIN_SL][FIN_CH];
@@ -455,6 +455,11 @@ __global__ __launch_bounds__(GRU_S * GRU_U) void gru_bwd_kernel(int N, int T, in
     const int in = dz + dl, zw = dc + dz;
     if (n < N) for (int c = j; c < dl; c += GRU_U) xs[s][c] = (c == labels[n]) ? 1.f : 0.f;
     float gh = 0.f;
+    float gW[3][GRU_MAXIN], gU[3][GRU_U], gb[3] = {0.f, 0.f, 0.f};       // d(W, W_z, W_r), d(U, U_z, U_r) rows, biases
+#pragma unroll
+    for (int c = 0; c < GRU_MAXIN; ++c) { gW[0][c] = 0.f; gW[1][c] = 0.f; gW[2][c] = 0.f; }
+#pragma unroll
+    for (int c = 0; c < GRU_U; ++c) { gU[0][c] = 0.f; gU[1][c] = 0.f; gU[2][c] = 0.f; }
     __syncthreads();
     for (int t = T - 1; t >= 0; --t) {
         float r = 0, zz = 0, hb = 0, h = 0, ga = 0, gaz = 0, ghn = 0;
@@ -484,24 +489,43 @@ __global__ __launch_bounds__(GRU_S * GRU_U) void gru_bwd_kernel(int N, int T, in
                 gh = fmaf(gaz_s[s][i], P[o.w[3] + i * dz + j], gh);
                 gh = fmaf(gar_s[s][i], P[o.w[1] + i * dz + j], gh);
             }
-            // parameter gradients of row j of each link
-            for (int c = 0; c < in; ++c) {
-                float xv = xs[s][c];
-                atomicAdd(&DP[o.w[4] + j * in + c], ga * xv);
-                atomicAdd(&DP[o.w[2] + j * in + c], gaz * xv);
-                atomicAdd(&DP[o.w[0] + j * in + c], gar * xv);
-            }
-            for (int c = 0; c < dz; ++c) {
-                atomicAdd(&DP[o.w[5] + j * dz + c], ga * rh_s[s][c]);
-                atomicAdd(&DP[o.w[3] + j * dz + c], gaz * h_s[s][c]);
-                atomicAdd(&DP[o.w[1] + j * dz + c], gar * h_s[s][c]);
-            }
-            atomicAdd(&DP[o.b[4] + j], ga); atomicAdd(&DP[o.b[5] + j], ga);
-            atomicAdd(&DP[o.b[2] + j], gaz); atomicAdd(&DP[o.b[3] + j], gaz);
-            atomicAdd(&DP[o.b[0] + j], gar); atomicAdd(&DP[o.b[1] + j], gar);
+            // parameter gradients of row j of each link: accumulated in registers over the 16 steps
+#pragma unroll
+            for (int c = 0; c < GRU_MAXIN; ++c)
+                if (c < in) {
+                    const float xv = xs[s][c];
+                    gW[0][c] = fmaf(ga, xv, gW[0][c]); gW[1][c] = fmaf(gaz, xv, gW[1][c]); gW[2][c] = fmaf(gar, xv, gW[2][c]);
+                }
+#pragma unroll
+            for (int c = 0; c < GRU_U; ++c)
+                if (c < dz) {
+                    gU[0][c] = fmaf(ga, rh_s[s][c], gU[0][c]); gU[1][c] = fmaf(gaz, h_s[s][c], gU[1][c]);
+                    gU[2][c] = fmaf(gar, h_s[s][c], gU[2][c]);
+                }
+            gb[0] += ga; gb[1] += gaz; gb[2] += gar;
         }
         __syncthreads();
     }
+    if (live) {                                    // one LDS reduction over the block's samples
+#pragma unroll
+        for (int c = 0; c < GRU_MAXIN; ++c)
+            if (c < in) {
+                atomicAdd(&DP[o.w[4] + j * in + c], gW[0][c]);
+                atomicAdd(&DP[o.w[2] + j * in + c], gW[1][c]);
+                atomicAdd(&DP[o.w[0] + j * in + c], gW[2][c]);
+            }
+#pragma unroll
+        for (int c = 0; c < GRU_U; ++c)
+            if (c < dz) {
+                atomicAdd(&DP[o.w[5] + j * dz + c], gU[0][c]);
+                atomicAdd(&DP[o.w[3] + j * dz + c], gU[1][c]);
+                atomicAdd(&DP[o.w[1] + j * dz + c], gU[2][c]);
+            }
+        atomicAdd(&DP[o.b[4] + j], gb[0]); atomicAdd(&DP[o.b[5] + j], gb[0]);
+        atomicAdd(&DP[o.b[2] + j], gb[1]); atomicAdd(&DP[o.b[3] + j], gb[1]);
+        atomicAdd(&DP[o.b[0] + j], gb[2]); atomicAdd(&DP[o.b[1] + j], gb[2]);
+    }
+    __syncthreads();
     for (int i = threadIdx.x; i < o.total; i += blockDim.x) atomicAdd(dparams + i, DP[i]);
 }
 

@@ -67,6 +67,13 @@ def _np_to(t, device):
 class _Net:
     """Shared parameter plumbing.  ``ref_shapes`` maps Chainer keys to Chainer shapes."""
 
+    # The gradient of a conv/deconv bias that feeds train-mode BatchNorm is exactly zero: with
+    # gx = gamma*inv_std*(g - (x_hat*ggamma + gbeta)/m),  sum_m gx = -gamma*inv_std*ggamma*sum_m(x_hat)/m and
+    # sum_m x_hat = 0.  Chainer (and oracle/) compute rounding noise there (~1e-9 in fp32), which Adam's
+    # sign-like update turns into an O(alpha) random walk of a parameter no output depends on.  The
+    # backward passes below leave that gradient at its exact value 0 instead of reducing gx again.
+    BIAS_NOTE = "pre-BatchNorm bias gradients are exactly zero"
+
     def _alloc(self, specs, device):
         self.device = torch.device(device)
         self.fp = FlatParams(specs, self.device)
@@ -298,7 +305,9 @@ class DisNet(_Net):
             else:
                 hl.bn_act_bwd(m, co, g, y, None, None, hl.ACT_LRELU, g, None, None, self.ws)
             if param_grads:
-                hl.colsum_acc(m, co, g, fp.grad('dc%d/b' % l), self.ws)
+                if l == 1:
+                    hl.colsum_acc(m, co, g, fp.grad('dc1/b'), self.ws)
+                # dc2..dc4 feed BatchNorm: sum_m gx == 0 exactly (see _Net.BIAS_NOTE), nothing to add
                 hl.conv_wgrad(geom, saved['a'][l], g, fp.grad('dc%d/W' % l))
             if l > 1:
                 ga = torch.empty_like(saved['a'][l])
@@ -491,7 +500,8 @@ class GenNet(_Net):
                 name = 'bn%d' % l
                 hl.bn_act_bwd(m, ci, g, saved['y'][l], saved['stats'][l], fp.param(name + '/gamma'), hl.ACT_RELU, g,
                               fp.grad(name + '/gamma'), fp.grad(name + '/beta'), self.ws)
-            hl.colsum_acc(m, ci, g, fp.grad('dc%d/b' % l), self.ws)
+            if l == 5:
+                hl.colsum_acc(m, ci, g, fp.grad('dc5/b'), self.ws)         # dc1..dc4 feed BatchNorm: exact zero
             hl.conv_wgrad(geom, g, saved['a'][l], fp.grad('dc%d/W' % l))
             ga = torch.empty_like(saved['a'][l])
             hl.conv_fprop(geom, g, fp.param('dc%d/W' % l), None, ga)
@@ -500,7 +510,6 @@ class GenNet(_Net):
         k1 = 16 * c1
         hl.bn_act_bwd(frames * 16, c1, g, saved['y'][1], saved['stats'][1], fp.param('bn1/gamma'), hl.ACT_RELU, g,
                       fp.grad('bn1/gamma'), fp.grad('bn1/beta'), self.ws)
-        hl.colsum_acc(frames * 16, c1, g, fp.grad('dc1/b'), self.ws)
         hl.fc_wgrad(frames, k1, self.n_hidden, g.view(frames, k1), saved['z'], fp.grad('dc1/W').view(self.n_hidden, k1))
         gz = torch.empty_like(saved['z'])
         hl.fc_fprop(frames, k1, self.n_hidden, g.view(frames, k1), fp.param('dc1/W').view(self.n_hidden, k1), None, gz)
