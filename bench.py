@@ -90,6 +90,9 @@ def main():
     ap.add_argument('--cpu-sample-steps', type=int, default=2)
     args = ap.parse_args()
 
+    if os.environ.get('MCG_DEBUG_HANG'):
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ['MCG_DEBUG_HANG']), exit=True)
     import torch
     import torch.distributed as dist
     import mocogan_chainer_amd.hiplib as hl
@@ -104,11 +107,14 @@ def main():
                              % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
-    torch.cuda.set_device(local_rank)
+    # MCG_SINGLE_DEVICE=1 + MCG_DIST_BACKEND=gloo: rehearse the N > 1 code path on a one-GPU box
+    # (every rank on cuda:0, gradients exchanged through gloo); never used for reported numbers.
+    rehearsal = os.environ.get('MCG_SINGLE_DEVICE') == '1'
+    torch.cuda.set_device(0 if rehearsal else local_rank)
     exchange = None
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get('MCG_DIST_BACKEND', 'nccl'), rank=rank, world_size=world)
         exchange = mstep.GradExchange()
     hl.load()
 
@@ -165,7 +171,7 @@ def main():
         out = {
             "metric": "training clips/sec (16x3x64x64)", "value": value, "unit": "clips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (single-device rehearsal)" if rehearsal else ""),
             "config": {"workload": "MUG-shape synthetic (B,3,16,64,64) U(-1,1), one update_core iteration per step "
                                    "(BASELINE.json configs[1])", "model": "mocogan-" + args.model,
                        "per_gpu_batch": B, "global_batch": B * world, "n_filters": 64, "dim_zl": 6,

@@ -58,7 +58,8 @@ typedef struct mcg_conv_geom {
 
 int mcg_version(void);
 /* test / tuning hook: force the GEMM block tile of the conv kernels (0 = auto, 1 = 128x128,
- * 2 = 128x64, 3 = 64x64).  Process-global; not part of the reference-facing surface. */
+ * 2 = 128x64, 3 = 64x64); adding 100 / 200 also forces the K-step depth to 32 / 64.
+ * Process-global; not part of the reference-facing surface. */
 void mcg_set_tile_override(int tile);
 
 /* ---- implicit-GEMM convolution on the fp32 MFMA (v_mfma_f32_32x32x2_f32) ------------------- */

@@ -20,7 +20,6 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BK = 32;
 constexpr int PAD = 4;
 constexpr int NTHREADS = 256;
 
@@ -59,9 +58,10 @@ __device__ __forceinline__ f32x4 ld4(const float* p, bool valid) {
 // ------------------------------------------------------------------------------------------
 
 // ---------------- fprop ----------------
-template <int BM, int BN>
+template <int BM, int BN, int BK>
 struct FpropP {
     static constexpr bool A_KC = true, B_KC = true;
+    static constexpr int ORDER = 0;
     static constexpr int NA = BM * BK / 4 / NTHREADS, NB = BN * BK / 4 / NTHREADS;
     Geom g;
     const float* x; const float* w; const float* bias; float* y;
@@ -73,10 +73,11 @@ struct FpropP {
 
     __device__ int m_tiles() const { return (M + BM - 1) / BM; }
     __device__ void init(int m0, int n0, int tid, int /*z*/) {
-        ak = (tid & 7) * 4;
+        constexpr int KC4 = BK / 4, RSTEP = NTHREADS / KC4;        // float4 slots per tile row, rows per pass
+        ak = (tid % KC4) * 4;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-            int m = m0 + (tid >> 3) + 32 * j;
+            int m = m0 + tid / KC4 + RSTEP * j;
             arow_ok[j] = m < M;
             int mm = arow_ok[j] ? m : 0;
             int wo = mm & (g.Wo - 1), ho = (mm >> g.lgWo) & (g.Ho - 1), q = mm >> (g.lgWo + g.lgHo);
@@ -86,7 +87,7 @@ struct FpropP {
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            bco[j] = n0 + (tid >> 3) + 32 * j;
+            bco[j] = n0 + tid / KC4 + RSTEP * j;
             bok[j] = bco[j] < g.Co;
         }
     }
@@ -115,9 +116,10 @@ struct FpropP {
 };
 
 // ---------------- dgrad (one output-parity class per blockIdx.z) ----------------
-template <int BM, int BN>
+template <int BM, int BN, int BK>
 struct DgradP {
     static constexpr bool A_KC = true, B_KC = false;
+    static constexpr int ORDER = 1;
     static constexpr int NA = BM * BK / 4 / NTHREADS, NB = BN * BK / 4 / NTHREADS;
     Geom g;
     const float* y; const float* w; const float* bias; float* x;
@@ -132,8 +134,9 @@ struct DgradP {
     // t: a temporal tap `a` whose source frame t - a falls outside [0, To) is then invalid for the whole
     // block and its K-steps are skipped (no loads, no MFMAs).  For D_V this removes 19..43 % of the work.
     __device__ void init(int m0, int n0, int tid, int z) {
+        constexpr int KC4 = BK / 4, RSTEP = NTHREADS / KC4;
         ph = z >> 1; pw = z & 1;
-        ak = (tid & 7) * 4;
+        ak = (tid % KC4) * 4;
         {
             int mlast = m0 + BM - 1 < M ? m0 + BM - 1 : M - 1;
             tmin = (m0 >> (g.lgWo + g.lgHo)) / g.N;
@@ -141,7 +144,7 @@ struct DgradP {
         }
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-            int m = m0 + (tid >> 3) + 32 * j;
+            int m = m0 + tid / KC4 + RSTEP * j;
             arow_ok[j] = m < M;
             int mm = arow_ok[j] ? m : 0;
             int w2 = mm & (g.Wo - 1), h2 = (mm >> g.lgWo) & (g.Ho - 1), q = mm >> (g.lgWo + g.lgHo);
@@ -208,9 +211,10 @@ struct DgradP {
 };
 
 // ---------------- wgrad (blockIdx.z = pixel split) ----------------
-template <int BM, int BN>
+template <int BM, int BN, int BK>
 struct WgradP {
     static constexpr bool A_KC = false, B_KC = false;
+    static constexpr int ORDER = 2;
     static constexpr int NA = BM * BK / 4 / NTHREADS, NB = BN * BK / 4 / NTHREADS;
     Geom g;
     const float* x; const float* y; float* dw;
@@ -263,7 +267,7 @@ struct WgradP {
 // ------------------------------------------------------------------------------------------
 // The GEMM core
 // ------------------------------------------------------------------------------------------
-template <class P, int BM, int BN>
+template <class P, int BM, int BN, int BK>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(P p) {
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int A_R = P::A_KC ? BM : BK, A_C = P::A_KC ? BK : BM;
@@ -278,7 +282,29 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(P p) {
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, z = blockIdx.z;
+    // XCD-aware tile mapping.  Workgroups are dealt round-robin over the 8 XCDs (each with its own 4 MiB
+    // L2), so workgroup ids L and L+8 share an L2.  Re-label them so that every XCD works on one
+    // contiguous range of logical tiles, ordered such that consecutive logical tiles share operand rows
+    // (policy ORDER below): the gathered activations are then fetched into one L2 instead of eight.
+    // Placement affects speed only; the remap is a bijection for any grid size.
+    int bx, by, bz;
+    {
+        const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+        const int nwg = gx * gy * gz;
+        const int L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const int xcd = L & 7, q = nwg >> 3, r = nwg & 7;
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+        if (P::ORDER == 0) {            // fprop: N tile fastest, then M tile (same activations, next filters)
+            by = t % gy; bx = t / gy; bz = 0;
+        } else if (P::ORDER == 1) {     // dgrad: dispatch order.  Its rows are time-major and blocks near the temporal
+            // boundary skip most K-steps, so a contiguous range per XCD would give the XCDs unequal work
+            // (measured: dc2 0.81 -> 0.97 ms with a contiguous mapping); round-robin interleaves light and heavy.
+            bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+        } else {                        // wgrad: all (Co, tap*Ci) tiles of one pixel chunk together
+            bx = t % gx; by = (t / gx) % gy; bz = t / (gx * gy);
+        }
+    }
+    const int m0 = bx * BM, n0 = by * BN, z = bz;
 
     p.init(m0, n0, tid, z);
 
@@ -483,27 +509,27 @@ int make_geom(const mcg_conv_geom* c, Geom& g) {
 
 int launch_status() { return hipGetLastError() == hipSuccess ? MCG_OK : MCG_ERR_LAUNCH; }
 
-template <int BM, int BN>
+template <int BM, int BN, int BK>
 void launch_fprop(const Geom& g, const float* x, const float* w, const float* bias, float* y, hipStream_t s) {
-    FpropP<BM, BN> p;
+    FpropP<BM, BN, BK> p;
     p.g = g; p.x = x; p.w = w; p.bias = bias; p.y = y;
     p.M = g.N * g.To * g.Ho * g.Wo; p.K = g.taps * g.Ci;
     dim3 grid((p.M + BM - 1) / BM, (g.Co + BN - 1) / BN, 1);
-    hipLaunchKernelGGL((gemm_kernel<FpropP<BM, BN>, BM, BN>), grid, dim3(NTHREADS), 0, s, p);
+    hipLaunchKernelGGL((gemm_kernel<FpropP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int BK>
 void launch_dgrad(const Geom& g, const float* y, const float* w, const float* bias, float* x, int act, int acc, hipStream_t s) {
-    DgradP<BM, BN> p;
+    DgradP<BM, BN, BK> p;
     p.g = g; p.y = y; p.w = w; p.bias = bias; p.x = x; p.act = act; p.accumulate = acc;
     p.M = g.N * g.Ti * g.Ho * g.Wo; p.K = g.kt * 4 * g.Co;
     dim3 grid((p.M + BM - 1) / BM, (g.Ci + BN - 1) / BN, 4);
-    hipLaunchKernelGGL((gemm_kernel<DgradP<BM, BN>, BM, BN>), grid, dim3(NTHREADS), 0, s, p);
+    hipLaunchKernelGGL((gemm_kernel<DgradP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int BK>
 void launch_wgrad(const Geom& g, const float* x, const float* y, float* dw, hipStream_t s) {
-    WgradP<BM, BN> p;
+    WgradP<BM, BN, BK> p;
     p.g = g; p.x = x; p.y = y; p.dw = dw;
     p.Mpix = g.N * g.To * g.Ho * g.Wo; p.Kf = g.taps * g.Ci;
     int tiles = ((g.Co + BM - 1) / BM) * ((p.Kf + BN - 1) / BN);
@@ -515,14 +541,15 @@ void launch_wgrad(const Geom& g, const float* x, const float* y, float* dw, hipS
     p.chunk = steps_per * BK;
     splits = (p.Mpix + p.chunk - 1) / p.chunk;
     dim3 grid((g.Co + BM - 1) / BM, (p.Kf + BN - 1) / BN, splits);
-    hipLaunchKernelGGL((gemm_kernel<WgradP<BM, BN>, BM, BN>), grid, dim3(NTHREADS), 0, s, p);
+    hipLaunchKernelGGL((gemm_kernel<WgradP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
 }
 
 int g_tile_override = 0;   // 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64 (tests / tuning)
+int g_bk_override = 0;     // 0 auto, 32 or 64
 
 }  // namespace
 
-extern "C" void mcg_set_tile_override(int t) { g_tile_override = t; }
+extern "C" void mcg_set_tile_override(int t) { g_tile_override = t % 100; g_bk_override = t >= 100 ? (t / 100) * 32 : 0; }
 
 extern "C" int mcg_conv_fprop(const mcg_conv_geom* c, const float* x, const float* w, const float* bias,
                               float* y, void* stream) {
@@ -537,9 +564,19 @@ extern "C" int mcg_conv_fprop(const mcg_conv_geom* c, const float* x, const floa
     int t = g_tile_override;
     const long long mt = (M + 127) / 128;
     if (!t) t = g.Co <= 64 ? 2 : (mt * ((g.Co + 127) / 128) >= 1024 ? 1 : (mt * ((g.Co + 63) / 64) >= 512 ? 2 : 3));
-    if (t == 1) launch_fprop<128, 128>(g, x, w, bias, y, s);
-    else if (t == 2) launch_fprop<128, 64>(g, x, w, bias, y, s);
-    else launch_fprop<64, 64>(g, x, w, bias, y, s);
+    // 64-deep K-steps halve the per-step overhead (barriers, LDS refill, address math) and pay off when the
+    // grid is small (few resident waves to hide it: measured on dc4); big grids prefer the higher occupancy of 32.
+    const long long nblk = ((M + (t == 3 ? 63 : 127)) / (t == 3 ? 64 : 128)) * ((g.Co + (t == 1 ? 127 : 63)) / (t == 1 ? 128 : 64));
+    const bool bk64 = (g.taps * g.Ci) % 64 == 0 && (g_bk_override ? g_bk_override == 64 : nblk < 1024);
+    if (bk64) {
+        if (t == 1) launch_fprop<128, 128, 64>(g, x, w, bias, y, s);
+        else if (t == 2) launch_fprop<128, 64, 64>(g, x, w, bias, y, s);
+        else launch_fprop<64, 64, 64>(g, x, w, bias, y, s);
+    } else {
+        if (t == 1) launch_fprop<128, 128, 32>(g, x, w, bias, y, s);
+        else if (t == 2) launch_fprop<128, 64, 32>(g, x, w, bias, y, s);
+        else launch_fprop<64, 64, 32>(g, x, w, bias, y, s);
+    }
     return launch_status();
 }
 
@@ -566,9 +603,17 @@ extern "C" int mcg_conv_dgrad(const mcg_conv_geom* c, const float* y, const floa
         if (4 * mt * ((g.Ci + 63) / 64) < 512) t = 3;                       // few blocks: finer tiles balance the CUs
         else t = g.Ci <= 64 ? 2 : (4 * mt * ((g.Ci + 127) / 128) >= 1024 ? 1 : 2);
     }
-    if (t == 1) launch_dgrad<128, 128>(g, y, w, bias, x, act, accumulate, s);
-    else if (t == 2) launch_dgrad<128, 64>(g, y, w, bias, x, act, accumulate, s);
-    else launch_dgrad<64, 64>(g, y, w, bias, x, act, accumulate, s);
+    const long long nblk = 4 * ((M + (t == 3 ? 63 : 127)) / (t == 3 ? 64 : 128)) * ((g.Ci + (t == 1 ? 127 : 63)) / (t == 1 ? 128 : 64));
+    const bool bk64 = (g.kt * 4 * g.Co) % 64 == 0 && (g_bk_override ? g_bk_override == 64 : nblk < 1024);
+    if (bk64) {
+        if (t == 1) launch_dgrad<128, 128, 64>(g, y, w, bias, x, act, accumulate, s);
+        else if (t == 2) launch_dgrad<128, 64, 64>(g, y, w, bias, x, act, accumulate, s);
+        else launch_dgrad<64, 64, 64>(g, y, w, bias, x, act, accumulate, s);
+    } else {
+        if (t == 1) launch_dgrad<128, 128, 32>(g, y, w, bias, x, act, accumulate, s);
+        else if (t == 2) launch_dgrad<128, 64, 32>(g, y, w, bias, x, act, accumulate, s);
+        else launch_dgrad<64, 64, 32>(g, y, w, bias, x, act, accumulate, s);
+    }
     return launch_status();
 }
 
@@ -581,8 +626,14 @@ extern "C" int mcg_conv_wgrad(const mcg_conv_geom* c, const float* x, const floa
     int Kf = g.taps * g.Ci;
     int t = g_tile_override;
     if (!t) t = (g.Co <= 64 || Kf <= 64) ? 3 : 1;
-    if (t == 1) launch_wgrad<128, 128>(g, x, y, dw, s);
-    else if (t == 2) launch_wgrad<128, 64>(g, x, y, dw, s);
-    else launch_wgrad<64, 64>(g, x, y, dw, s);
+    if (g_bk_override == 64) {
+        if (t == 1) launch_wgrad<128, 128, 64>(g, x, y, dw, s);
+        else if (t == 2) launch_wgrad<128, 64, 64>(g, x, y, dw, s);
+        else launch_wgrad<64, 64, 64>(g, x, y, dw, s);
+    } else {
+        if (t == 1) launch_wgrad<128, 128, 32>(g, x, y, dw, s);
+        else if (t == 2) launch_wgrad<128, 64, 32>(g, x, y, dw, s);
+        else launch_wgrad<64, 64, 32>(g, x, y, dw, s);
+    }
     return launch_status();
 }

@@ -52,7 +52,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 101, 103, 201, 202, 203])     # 1xx / 2xx force BK = 32 / 64
 def test_conv_three_passes(hl, case, tile):
     N, Ti, H, Ci, Co, kt = case
     rng = np.random.RandomState(hash(case) % 2**31)

@@ -48,12 +48,15 @@ def main():
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--tile', type=int, default=0)
     ap.add_argument('--only', default='')
+    ap.add_argument('--net', default='', help='restrict to layers whose name starts with this (e.g. D_V)')
     args = ap.parse_args()
     hl.load()
     hl.set_tile_override(args.tile)
     print('%-10s %-6s %10s %10s %8s' % ('layer', 'pass', 'ms', 'TFLOP/s', 'GFLOP'))
     tot = {}
     for name, N, T, H, Ci, Co, kt, ci_real in layers(args.batch):
+        if args.net and not name.startswith(args.net):
+            continue
         g = hl.make_geom(N, T, H, H, Ci, Co, kt)
         x = torch.randn((N, T, H, H, Ci), device='cuda')
         y = torch.randn((N, g.To, g.Ho, g.Wo, Co), device='cuda')
