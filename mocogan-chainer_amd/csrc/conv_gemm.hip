@@ -6,11 +6,19 @@
 //   dgrad : x[pix_i][ci]       = sum_{tap,co} y[pix_o(tap)][co] * w[co][tap][ci]   (4 output-parity classes)
 //   wgrad : dw[co][tap][ci]   += sum_{pix}    y[pix_o][co]      * x[pix_i(tap)][ci] (split over pixels)
 // Activations are channels-last so every gathered operand row is a contiguous run of channels:
-// global loads are 16-byte, LDS tiles keep the global orientation ([row][32+4] when the row is
+// global loads are 16-byte, LDS tiles keep the global orientation ([row][BK+4] when the row is
 // K-contiguous, [k][cols+4] otherwise) and the MFMA operands are read with ds_read_b128 /
 // conflict-free ds_read_b32.  Block = 256 threads = 2x2 waves, each wave owns (BM/2)x(BN/2)
-// outputs as 32x32 accumulator tiles; BK = 32.  Global loads of K-step s+1 are issued before the
-// MFMAs of step s (register staging), so their latency hides under the 64-cycle MFMAs.
+// outputs as 32x32 accumulator tiles.  Global loads of K-step s+1 are issued before the MFMAs of
+// step s (register staging).
+//
+// What bounds these kernels (measured with in-kernel stamps, tools/stamp_phases.py, and
+// tools/mfma_probe.hip): the f32 MFMA runs at the f32 vector rate and shares the SIMD with the VALU,
+// so every vector instruction of the loaders is time taken from the matrix pipe.  The MFMA + LDS-read
+// + barrier skeleton alone sustains 150 TFLOP/s; the K-loop's address arithmetic is what costs.  The
+// loaders therefore use raw buffer loads (hardware range check: an out-of-range offset returns 0, so
+// padding / tile edges need one v_cndmask, no exec-mask branches), 32-bit byte offsets, and per-row
+// validity bit-masks over the 16 taps precomputed once per block.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "mocogan_hip.h"
@@ -19,9 +27,21 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32;
 
 constexpr int PAD = 4;
 constexpr int NTHREADS = 256;
+constexpr u32 OOB = 0x80000000u;   // byte offsets >= 2 GiB are outside every buffer (make_geom checks sizes)
+
+// Diagnostic build only (-DMCG_STAMPS, tools/stamp_phases.py): per-phase shader-cycle totals of the K-loop.
+// Stamps serialise the schedule, so only the SHARES are meaningful, never this build's run time.
+#ifdef MCG_STAMPS
+__device__ unsigned long long g_stamp[8];
+#define MCG_T(var) do { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define MCG_T(var) do { } while (0)
+#endif
 
 struct Geom {
     int N, Ti, Hi, Wi, Ci, To, Ho, Wo, Co, kt;
@@ -30,6 +50,8 @@ struct Geom {
     int perm_n;
     long long xs0, xs1;
     int taps;          // kt * 16
+    u32 x_bytes, y_bytes, w_bytes;   // buffer extents for the hardware range check
+    u32 magic_To;      // floor(2^32 / To) + 1:  q / To == umulhi(q, magic_To) for q < 2^32 / To
 };
 
 __device__ __forceinline__ long long x_batch_off(const Geom& g, int n) {
@@ -44,15 +66,19 @@ __device__ __forceinline__ void divmod_c(int k, int C, int lgC, int& q, int& r) 
     else { q = k / C; r = k - q * C; }
 }
 
-__device__ __forceinline__ f32x4 ld4(const float* p, bool valid) {
-    f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    return valid ? *reinterpret_cast<const f32x4*>(p) : z;
+// q / To by multiplication (To = 1 has no 32-bit magic number)
+__device__ __forceinline__ int div_To(const Geom& g, int q) { return g.To == 1 ? q : (int)__umulhi((u32)q, g.magic_To); }
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const float* p, u32 bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t r, u32 byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
 }
 
 // ------------------------------------------------------------------------------------------
-// Problem policies.  Each provides:
-//   M(), Nn(), ksteps range, tile loaders for A (rows = M side) and B (rows = N side) and the
-//   epilogue store.  A_KC / B_KC say whether the operand's global rows are K-contiguous.
+// Problem policies.  Each provides the K range, tile loaders for A (rows = M side) and B (rows = N
+// side) and the epilogue store.  A_KC / B_KC say whether the operand's global rows are K-contiguous.
 // Loader slot convention: a tile of R rows x C floats holds R*C/4 float4 "slots"; thread `tid`
 // owns slots q = tid + 256*j, row = q / (C/4), c4 = q % (C/4).
 // ------------------------------------------------------------------------------------------
@@ -67,28 +93,37 @@ struct FpropP {
     const float* x; const float* w; const float* bias; float* y;
     int M, K;
     // per-thread state
-    long long abase[NA]; int ahi[NA], awi[NA]; bool arow_ok[NA];
-    int ak;            // this thread's k offset inside a K-step (c4*4)
-    int bco[NB]; bool bok[NB];
+    __amdgpu_buffer_rsrc_t xr, wr;
+    int abase[NA];      // element offset of the window origin (may be negative: padding)
+    u32 amask[NA];      // bit kh*4+kw set <=> that tap of the row reads inside the image
+    int ak;             // this thread's k offset inside a K-step (c4*4)
+    u32 bbase[NB];      // byte offset of the filter row, OOB for rows beyond Co
 
-    __device__ int m_tiles() const { return (M + BM - 1) / BM; }
     __device__ void init(int m0, int n0, int tid, int /*z*/) {
         constexpr int KC4 = BK / 4, RSTEP = NTHREADS / KC4;        // float4 slots per tile row, rows per pass
+        xr = make_srd(x, g.x_bytes); wr = make_srd(w, g.w_bytes);
         ak = (tid % KC4) * 4;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             int m = m0 + tid / KC4 + RSTEP * j;
-            arow_ok[j] = m < M;
-            int mm = arow_ok[j] ? m : 0;
+            bool ok = m < M;
+            int mm = ok ? m : 0;
             int wo = mm & (g.Wo - 1), ho = (mm >> g.lgWo) & (g.Ho - 1), q = mm >> (g.lgWo + g.lgHo);
-            int to = q % g.To, n = q / g.To;
-            ahi[j] = 2 * ho - 1; awi[j] = 2 * wo - 1;
-            abase[j] = x_batch_off(g, n) + ((long long)(to * g.Hi + ahi[j]) * g.Wi + awi[j]) * g.Ci;
+            int n = div_To(g, q), to = q - n * g.To;
+            int hi0 = 2 * ho - 1, wi0 = 2 * wo - 1;
+            abase[j] = (int)x_batch_off(g, n) + ((to * g.Hi + hi0) * g.Wi + wi0) * g.Ci;
+            u32 mk = 0;
+#pragma unroll
+            for (int kh = 0; kh < 4; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 4; ++kw)
+                    if (ok && (unsigned)(hi0 + kh) < (unsigned)g.Hi && (unsigned)(wi0 + kw) < (unsigned)g.Wi) mk |= 1u << (kh * 4 + kw);
+            amask[j] = mk;
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            bco[j] = n0 + tid / KC4 + RSTEP * j;
-            bok[j] = bco[j] < g.Co;
+            int co = n0 + tid / KC4 + RSTEP * j;
+            bbase[j] = co < g.Co ? (u32)(co * K + ak) * 4u : OOB;
         }
     }
     __device__ int k_begin(int) const { return 0; }
@@ -98,17 +133,17 @@ struct FpropP {
         int k = k0 + ak;
         int tap, ci;
         divmod_c(k, g.Ci, g.lgCi, tap, ci);
-        int a = tap >> 4, kh = (tap >> 2) & 3, kw = tap & 3;
-        int off = ((a * g.Hi + kh) * g.Wi + kw) * g.Ci + ci;          // < 2^31: checked in make_geom
+        int sp = tap & 15;
+        int off = (((tap >> 4) * g.Hi + (sp >> 2)) * g.Wi + (sp & 3)) * g.Ci + ci;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-            bool ok = arow_ok[j] && (unsigned)(ahi[j] + kh) < (unsigned)g.Hi && (unsigned)(awi[j] + kw) < (unsigned)g.Wi;
-            r[j] = ld4(x + abase[j] + off, ok);
+            u32 vo = (u32)(abase[j] + off) * 4u;
+            r[j] = bload(xr, (amask[j] >> sp) & 1u ? vo : OOB);
         }
     }
     __device__ void load_b(int k0, f32x4 (&r)[NB]) const {
 #pragma unroll
-        for (int j = 0; j < NB; ++j) r[j] = ld4(w + (bco[j] * K + k0 + ak), bok[j]);
+        for (int j = 0; j < NB; ++j) r[j] = bload(wr, bbase[j] + (u32)k0 * 4u);
     }
     __device__ void store(int m, int n, float v) const {
         if (m < M && n < g.Co) y[(long long)m * g.Co + n] = v + (bias ? bias[n] : 0.f);
@@ -125,16 +160,19 @@ struct DgradP {
     const float* y; const float* w; const float* bias; float* x;
     int M, K, act, accumulate;   // M = N*Ti*Ho*Wo pixels of ONE parity class; K = kt*4*Co
     int ph, pw;
-    long long abase[NA]; int at[NA], ah[NA], aw[NA]; bool arow_ok[NA];
+    __amdgpu_buffer_rsrc_t yr, wr;
+    int abase[NA];      // element offset of y[n][t][h2+ph][w2+pw][0]  (tap offsets are subtracted)
+    u32 amask[NA];      // bit a*4+bh*2+bw set <=> that sub-filter tap of the row reads inside y
     int ak;
     int bci; int bkrow[NB]; bool bok;
-    int tmin, tmax;               // range of input time steps covered by this block's rows
+    int tmin, tmax;     // range of input time steps covered by this block's rows
 
     // Rows are ordered (t, n, h', w') -- t slowest -- so that the rows of one block share (almost) one
     // t: a temporal tap `a` whose source frame t - a falls outside [0, To) is then invalid for the whole
     // block and its K-steps are skipped (no loads, no MFMAs).  For D_V this removes 19..43 % of the work.
     __device__ void init(int m0, int n0, int tid, int z) {
         constexpr int KC4 = BK / 4, RSTEP = NTHREADS / KC4;
+        yr = make_srd(y, g.y_bytes); wr = make_srd(w, g.w_bytes);
         ph = z >> 1; pw = z & 1;
         ak = (tid % KC4) * 4;
         {
@@ -145,12 +183,19 @@ struct DgradP {
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             int m = m0 + tid / KC4 + RSTEP * j;
-            arow_ok[j] = m < M;
-            int mm = arow_ok[j] ? m : 0;
+            bool ok = m < M;
+            int mm = ok ? m : 0;
             int w2 = mm & (g.Wo - 1), h2 = (mm >> g.lgWo) & (g.Ho - 1), q = mm >> (g.lgWo + g.lgHo);
-            int n = q % g.N, t = q / g.N;
-            at[j] = t; ah[j] = h2 + ph; aw[j] = w2 + pw;
-            abase[j] = (long long)n * g.To * g.Ho * g.Wo * g.Co;
+            int t = q / g.N, n = q - t * g.N;
+            int hh = h2 + ph, ww = w2 + pw;
+            abase[j] = (((n * g.To + t) * g.Ho + hh) * g.Wo + ww) * g.Co;
+            u32 mk = 0;
+            for (int a = 0; a < g.kt; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (ok && (unsigned)(t - a) < (unsigned)g.To && (unsigned)(hh - (b >> 1)) < (unsigned)g.Ho &&
+                        (unsigned)(ww - (b & 1)) < (unsigned)g.Wo) mk |= 1u << (a * 4 + b);
+            amask[j] = mk;
         }
         // B tile: rows = k (BK), cols = ci (BN); BN/4 float4 per row
         constexpr int C4 = BN / 4;
@@ -179,12 +224,11 @@ struct DgradP {
         int k = k0 + ak;
         int ts, co;
         divmod_c(k, g.Co, g.lgCo, ts, co);
-        int a = ts >> 2, bh = (ts >> 1) & 1, bw = ts & 1;
+        int off = co - (((ts >> 2) * g.Ho + ((ts >> 1) & 1)) * g.Wo + (ts & 1)) * g.Co;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-            int to = at[j] - a, ho = ah[j] - bh, wo = aw[j] - bw;
-            bool ok = arow_ok[j] && (unsigned)to < (unsigned)g.To && (unsigned)ho < (unsigned)g.Ho && (unsigned)wo < (unsigned)g.Wo;
-            r[j] = ld4(y + abase[j] + (((to * g.Ho + ho) * g.Wo + wo) * g.Co + co), ok);
+            u32 vo = (u32)(abase[j] + off) * 4u;
+            r[j] = bload(yr, (amask[j] >> ts) & 1u ? vo : OOB);
         }
     }
     __device__ void load_b(int k0, f32x4 (&r)[NB]) const {
@@ -193,9 +237,9 @@ struct DgradP {
             int k = k0 + bkrow[j];
             int ts, co;
             divmod_c(k, g.Co, g.lgCo, ts, co);
-            int a = ts >> 2, bh = (ts >> 1) & 1, bw = ts & 1;
-            int tap = a * 16 + ((1 - ph) + 2 * bh) * 4 + (1 - pw) + 2 * bw;
-            r[j] = ld4(w + ((co * g.taps + tap) * g.Ci + bci), bok);
+            int tap = (ts >> 2) * 16 + ((1 - ph) + (ts & 2)) * 4 + (1 - pw) + 2 * (ts & 1);
+            u32 vo = (u32)((co * g.taps + tap) * g.Ci + bci) * 4u;
+            r[j] = bload(wr, bok ? vo : OOB);
         }
     }
     __device__ void store(int m, int n, float v) const {
@@ -219,20 +263,22 @@ struct WgradP {
     Geom g;
     const float* x; const float* y; float* dw;
     int Mpix, Kf, chunk;          // Kf = taps*Ci ; chunk = pixels per split (multiple of BK)
-    int aco; bool aok; int akrow[NA];
-    int bkf; bool bok; int btoff_t, bkh, bkw, bci; int bkrow[NB];
-    int zsplit;
+    __amdgpu_buffer_rsrc_t xr, yr;
+    u32 aoff; int akrow[NA];      // A: byte offset of this thread's 4 output channels (OOB beyond Co)
+    bool bok; int bt, bkh, bkw, bci; int bkrow[NB];
 
-    __device__ void init(int m0, int n0, int tid, int z) {
-        zsplit = z;
+    __device__ void init(int m0, int n0, int tid, int /*z*/) {
         constexpr int AC4 = BM / 4, BC4 = BN / 4;
-        aco = m0 + (tid % AC4) * 4; aok = aco < g.Co;
+        xr = make_srd(x, g.x_bytes); yr = make_srd(y, g.y_bytes);
+        int aco = m0 + (tid % AC4) * 4;
+        aoff = aco < g.Co ? (u32)aco * 4u : OOB;
 #pragma unroll
         for (int j = 0; j < NA; ++j) akrow[j] = tid / AC4 + (NTHREADS / AC4) * j;
-        bkf = n0 + (tid % BC4) * 4; bok = bkf < Kf;
-        int kk = bok ? bkf : 0;
-        int tap = kk / g.Ci; bci = kk - tap * g.Ci;
-        btoff_t = tap >> 4; bkh = (tap >> 2) & 3; bkw = tap & 3;
+        int bkf = n0 + (tid % BC4) * 4;
+        bok = bkf < Kf;
+        int kk = bok ? bkf : 0, tap;
+        divmod_c(kk, g.Ci, g.lgCi, tap, bci);
+        bt = tap >> 4; bkh = (tap >> 2) & 3; bkw = tap & 3;
 #pragma unroll
         for (int j = 0; j < NB; ++j) bkrow[j] = tid / BC4 + (NTHREADS / BC4) * j;
     }
@@ -240,23 +286,22 @@ struct WgradP {
     __device__ int k_end(int z) const { int e = (z + 1) * chunk; return e < Mpix ? e : Mpix; }
     __device__ int next_valid(int k0) const { return k0; }
     __device__ void load_a(int k0, f32x4 (&r)[NA]) const {
+        // rows beyond Mpix fall outside the buffer: the range check returns zeros
 #pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            int pix = k0 + akrow[j];
-            r[j] = ld4(y + (long long)pix * g.Co + aco, aok && pix < Mpix);
-        }
+        for (int j = 0; j < NA; ++j) r[j] = bload(yr, aoff + (u32)((k0 + akrow[j]) * g.Co) * 4u);
     }
     __device__ void load_b(int k0, f32x4 (&r)[NB]) const {
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             int pix = k0 + bkrow[j];
             bool ok = bok && pix < Mpix;
-            int pp = ok ? pix : 0;
-            int wo = pp & (g.Wo - 1), ho = (pp >> g.lgWo) & (g.Ho - 1), q = pp >> (g.lgWo + g.lgHo);
-            int to = q % g.To, n = q / g.To;
+            int wo = pix & (g.Wo - 1), ho = (pix >> g.lgWo) & (g.Ho - 1), q = pix >> (g.lgWo + g.lgHo);
+            int n = div_To(g, q), to = q - n * g.To;
             int hi = 2 * ho - 1 + bkh, wi = 2 * wo - 1 + bkw;
             ok = ok && (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)g.Wi;
-            r[j] = ld4(x + x_batch_off(g, n) + ((long long)((to + btoff_t) * g.Hi + hi) * g.Wi + wi) * g.Ci + bci, ok);
+            int base = g.perm_n ? (int)x_batch_off(g, n) : n * (int)g.xs0;
+            u32 vo = (u32)(base + (((to + bt) * g.Hi + hi) * g.Wi + wi) * g.Ci + bci) * 4u;
+            r[j] = bload(xr, ok ? vo : OOB);
         }
     }
     __device__ void store(int m, int n, float v) const {
@@ -322,7 +367,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(P p) {
     if (k0 < kend) { p.load_a(k0, ra); p.load_b(k0, rb); }
 
     constexpr int A_C4 = A_C / 4, B_C4 = B_C / 4;
+#ifdef MCG_STAMPS
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, acc_w = 0, acc_l = 0, acc_c = 0, acc_b = 0;
+#endif
     while (k0 < kend) {
+        MCG_T(ts0);
         // registers -> LDS
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
@@ -335,8 +384,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(P p) {
             *reinterpret_cast<f32x4*>(&Bs[(q / B_C4) * B_LD + (q % B_C4) * 4]) = rb[j];
         }
         __syncthreads();
+        MCG_T(ts1);
         const int kn = p.next_valid(k0 + BK);
-        if (kn < kend) { p.load_a(kn, ra); p.load_b(kn, rb); }                  // prefetch the next live step
+        // prefetch the next live step; past the end the offsets are forced out of range (loads return 0,
+        // nothing is consumed), which keeps the loop body free of divergent branches
+        { const int kl = kn < kend ? kn : kend - BK; p.load_a(kl, ra); p.load_b(kl, rb); }
+        MCG_T(ts2);
 #pragma unroll
         for (int gk = 0; gk < BK / 8; ++gk) {
             float fa[TM][4], fb[TN][4];
@@ -368,10 +421,21 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(P p) {
                     for (int b = 0; b < TN; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
         }
+        MCG_T(ts3);
         __syncthreads();
+        MCG_T(ts4);
+#ifdef MCG_STAMPS
+        acc_w += ts1 - ts0; acc_l += ts2 - ts1; acc_c += ts3 - ts2; acc_b += ts4 - ts3;
+#endif
         k0 = kn;
     }
 
+#ifdef MCG_STAMPS
+    if (lane == 0) {
+        atomicAdd(&g_stamp[0], acc_w); atomicAdd(&g_stamp[1], acc_l); atomicAdd(&g_stamp[2], acc_c); atomicAdd(&g_stamp[3], acc_b);
+        atomicAdd(&g_stamp[4], 1ull);
+    }
+#endif
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
     for (int a = 0; a < TM; ++a)
@@ -498,12 +562,17 @@ int make_geom(const mcg_conv_geom* c, Geom& g) {
     if ((g.Ci & 3) || (g.Co & 3)) return MCG_ERR_BAD_ARG;
     if (g.kt != 1 && g.kt != 4) return MCG_ERR_UNSUPPORTED;
     if (g.Hi != 2 * g.Ho || g.Wi != 2 * g.Wo || g.To != g.Ti - g.kt + 1 || g.To <= 0) return MCG_ERR_UNSUPPORTED;
-    // element offsets inside one tensor are kept in 64 bit, pixel counts in 32 bit
-    if ((long long)g.N * g.Ti * g.Hi * g.Wi >= (1ll << 31)) return MCG_ERR_UNSUPPORTED;
-    // in-tensor element offsets of y, w and of one batch item of x are computed in 32 bit
-    if ((long long)g.N * g.To * g.Ho * g.Wo * g.Co >= (1ll << 31)) return MCG_ERR_UNSUPPORTED;
-    if ((long long)g.Ti * g.Hi * g.Wi * g.Ci >= (1ll << 31)) return MCG_ERR_UNSUPPORTED;
-    if ((long long)g.Co * g.taps * g.Ci >= (1ll << 31)) return MCG_ERR_UNSUPPORTED;
+    if (g.perm_n < 0 || (g.perm_n && g.N % g.perm_n) || g.xs0 < 0 || g.xs1 < 0) return MCG_ERR_BAD_ARG;
+    // Loader offsets are 32-bit byte offsets checked by the buffer hardware against the tensor extent;
+    // 2 GiB and above is the "out of range" marker, so each tensor must stay below 2 GiB.
+    const long long frame = (long long)g.Ti * g.Hi * g.Wi * g.Ci;
+    const long long x_elems = (g.perm_n ? (long long)(g.perm_n - 1) * g.xs0 + (long long)(g.N / g.perm_n - 1) * g.xs1
+                                        : (long long)(g.N - 1) * g.xs0) + frame;
+    const long long y_elems = (long long)g.N * g.To * g.Ho * g.Wo * g.Co;
+    const long long w_elems = (long long)g.Co * g.taps * g.Ci;
+    if (x_elems * 4 >= (1ll << 31) || y_elems * 4 >= (1ll << 31) || w_elems * 4 >= (1ll << 31)) return MCG_ERR_UNSUPPORTED;
+    g.x_bytes = (u32)(x_elems * 4); g.y_bytes = (u32)(y_elems * 4); g.w_bytes = (u32)(w_elems * 4);
+    g.magic_To = (u32)((1ull << 32) / (unsigned)g.To) + 1u;
     return MCG_OK;
 }
 
@@ -549,7 +618,17 @@ int g_bk_override = 0;     // 0 auto, 32 or 64
 
 }  // namespace
 
-extern "C" void mcg_set_tile_override(int t) { g_tile_override = t % 100; g_bk_override = t >= 100 ? (t / 100) * 32 : 0; }
+#ifdef MCG_STAMPS
+extern "C" void mcg_debug_stamps(unsigned long long* out, int reset) {
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 8);
+    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)); }
+}
+#endif
+
+extern "C" void mcg_set_tile_override(int t) {
+    t %= 1000;
+    g_tile_override = t % 100; g_bk_override = t >= 100 ? (t / 100) * 32 : 0;
+}
 
 extern "C" int mcg_conv_fprop(const mcg_conv_geom* c, const float* x, const float* w, const float* bias,
                               float* y, void* stream) {
