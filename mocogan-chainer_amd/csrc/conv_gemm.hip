@@ -94,7 +94,7 @@ struct FpropP {
     int M, K;
     // per-thread state
     __amdgpu_buffer_rsrc_t xr, wr;
-    int abase[NA];      // element offset of the window origin (may be negative: padding)
+    int abase[NA];      // BYTE offset of the window origin (may be negative: padding)
     u32 amask[NA];      // bit kh*4+kw set <=> that tap of the row reads inside the image
     int ak;             // this thread's k offset inside a K-step (c4*4)
     u32 bbase[NB];      // byte offset of the filter row, OOB for rows beyond Co
@@ -111,7 +111,7 @@ struct FpropP {
             int wo = mm & (g.Wo - 1), ho = (mm >> g.lgWo) & (g.Ho - 1), q = mm >> (g.lgWo + g.lgHo);
             int n = div_To(g, q), to = q - n * g.To;
             int hi0 = 2 * ho - 1, wi0 = 2 * wo - 1;
-            abase[j] = (int)x_batch_off(g, n) + ((to * g.Hi + hi0) * g.Wi + wi0) * g.Ci;
+            abase[j] = ((int)x_batch_off(g, n) + ((to * g.Hi + hi0) * g.Wi + wi0) * g.Ci) * 4;
             u32 mk = 0;
 #pragma unroll
             for (int kh = 0; kh < 4; ++kh)
@@ -134,12 +134,9 @@ struct FpropP {
         int tap, ci;
         divmod_c(k, g.Ci, g.lgCi, tap, ci);
         int sp = tap & 15;
-        int off = (((tap >> 4) * g.Hi + (sp >> 2)) * g.Wi + (sp & 3)) * g.Ci + ci;
+        int off = ((((tap >> 4) * g.Hi + (sp >> 2)) * g.Wi + (sp & 3)) * g.Ci + ci) * 4;
 #pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            u32 vo = (u32)(abase[j] + off) * 4u;
-            r[j] = bload(xr, (amask[j] >> sp) & 1u ? vo : OOB);
-        }
+        for (int j = 0; j < NA; ++j) r[j] = bload(xr, (amask[j] >> sp) & 1u ? (u32)(abase[j] + off) : OOB);
     }
     __device__ void load_b(int k0, f32x4 (&r)[NB]) const {
 #pragma unroll
@@ -161,10 +158,11 @@ struct DgradP {
     int M, K, act, accumulate;   // M = N*Ti*Ho*Wo pixels of ONE parity class; K = kt*4*Co
     int ph, pw;
     __amdgpu_buffer_rsrc_t yr, wr;
-    int abase[NA];      // element offset of y[n][t][h2+ph][w2+pw][0]  (tap offsets are subtracted)
+    int abase[NA];      // BYTE offset of y[n][t][h2+ph][w2+pw][0]  (tap offsets are subtracted)
     u32 amask[NA];      // bit a*4+bh*2+bw set <=> that sub-filter tap of the row reads inside y
     int ak;
     int bci; int bkrow[NB]; bool bok;
+    u32 bfast[NB];      // fast path (Co % BK == 0): byte offset of w[co = bkrow[j]][tap 0][bci], OOB beyond Ci
     int tmin, tmax;     // range of input time steps covered by this block's rows
 
     // Rows are ordered (t, n, h', w') -- t slowest -- so that the rows of one block share (almost) one
@@ -188,7 +186,7 @@ struct DgradP {
             int w2 = mm & (g.Wo - 1), h2 = (mm >> g.lgWo) & (g.Ho - 1), q = mm >> (g.lgWo + g.lgHo);
             int t = q / g.N, n = q - t * g.N;
             int hh = h2 + ph, ww = w2 + pw;
-            abase[j] = (((n * g.To + t) * g.Ho + hh) * g.Wo + ww) * g.Co;
+            abase[j] = ((((n * g.To + t) * g.Ho + hh) * g.Wo + ww) * g.Co) * 4;
             u32 mk = 0;
             for (int a = 0; a < g.kt; ++a)
 #pragma unroll
@@ -202,7 +200,10 @@ struct DgradP {
         bci = n0 + (tid % C4) * 4;
         bok = bci < g.Ci;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) bkrow[j] = tid / C4 + (NTHREADS / C4) * j;
+        for (int j = 0; j < NB; ++j) {
+            bkrow[j] = tid / C4 + (NTHREADS / C4) * j;
+            bfast[j] = bok ? (u32)(bkrow[j] * g.taps * g.Ci + bci) * 4u : OOB;
+        }
     }
     __device__ int k_begin(int) const { return 0; }
     __device__ int k_end(int) const { return K; }
@@ -224,14 +225,20 @@ struct DgradP {
         int k = k0 + ak;
         int ts, co;
         divmod_c(k, g.Co, g.lgCo, ts, co);
-        int off = co - (((ts >> 2) * g.Ho + ((ts >> 1) & 1)) * g.Wo + (ts & 1)) * g.Co;
+        int off = (co - (((ts >> 2) * g.Ho + ((ts >> 1) & 1)) * g.Wo + (ts & 1)) * g.Co) * 4;
 #pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            u32 vo = (u32)(abase[j] + off) * 4u;
-            r[j] = bload(yr, (amask[j] >> ts) & 1u ? vo : OOB);
-        }
+        for (int j = 0; j < NA; ++j) r[j] = bload(yr, (amask[j] >> ts) & 1u ? (u32)(abase[j] + off) : OOB);
     }
     __device__ void load_b(int k0, f32x4 (&r)[NB]) const {
+        if (g.lgCo >= 0 && (g.Co & (BK - 1)) == 0) {
+            // every k of this K-step shares one sub-filter tap: the tap part of the address is wave-uniform
+            int ts = k0 >> g.lgCo, co0 = k0 & (g.Co - 1);
+            int tap = (ts >> 2) * 16 + ((1 - ph) + (ts & 2)) * 4 + (1 - pw) + 2 * (ts & 1);
+            u32 base = (u32)((co0 * g.taps + tap) * g.Ci) * 4u;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) r[j] = bload(wr, bfast[j] + base);
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             int k = k0 + bkrow[j];
@@ -290,6 +297,8 @@ struct WgradP {
 #pragma unroll
         for (int j = 0; j < NA; ++j) r[j] = bload(yr, aoff + (u32)((k0 + akrow[j]) * g.Co) * 4u);
     }
+    // (An incremental per-slot pixel decode -- wo/ho/q advanced by BK with carries -- was measured 3-8 %
+    // slower than re-decoding with shifts and the multiply-high division: it costs 12 VGPRs.)
     __device__ void load_b(int k0, f32x4 (&r)[NB]) const {
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
