@@ -217,58 +217,83 @@ class DisNet(_Net):
 
     # ---- forward ---------------------------------------------------------------------------
     def forward(self, n, first_input, noise=None, rng=None, update_stats=True):
-        """first_input: callable(out, addend, rng_args) that writes a1 = x + noise into `out`
+        """One call of the discriminator on n samples (reference __call__).
+        first_input: callable(out, noise_kwargs) that writes a1 = x + noise into `out`
         ([n][T][64][64][cp0]).  noise: list of 4 device tensors in device layout (parity mode) or
         None; rng: (seed, base_stream_id) for in-kernel Philox noise (perf mode) or None.
         Returns (logits [n][out], saved)."""
+        return self.forward_groups(n, [dict(first_input=first_input, noise=noise, rng=rng)], update_stats)
+
+    def forward_groups(self, n, groups, update_stats=True):
+        """Several independent calls (e.g. the real and the fake batch of one iteration) run as ONE
+        batch of len(groups)*n samples through the convolutions -- twice the rows per launch fills the GPU
+        better on the small late layers -- while everything that is per call in the reference stays per
+        group: BatchNorm statistics (and the order of their running-average updates), noise, activations.
+        groups: list of dict(first_input=..., noise=..., rng=...) as in forward().
+        Returns (logits [G*n][out], saved); group i owns rows [i*n, (i+1)*n)."""
         train = config.train
         noisy = train and self.use_noise
         dev = self.device
         hl.set_tag(self.tag)
+        G = len(groups)
+        N = G * n
 
-        def noise_args(l):
+        def noise_args(grp, l):
             if not noisy:
                 return dict()
-            if noise is not None:
-                return dict(addend=noise[l - 1])
-            if rng is not None:
-                return dict(sigma=self.noise_sigma, seed=rng[0], stream_id=rng[1] + l - 1)
+            if grp.get('noise') is not None:
+                return dict(addend=grp['noise'][l - 1])
+            if grp.get('rng') is not None:
+                return dict(sigma=self.noise_sigma, seed=grp['rng'][0], stream_id=grp['rng'][1] + l - 1)
             return dict()
 
-        saved = {'n': n, 'a': {}, 'y': {}, 'stats': {}}
+        saved = {'n': n, 'G': G, 'a': {}, 'y': {}, 'stats': {}}
         t, h = self._extents(1)
-        a = torch.empty((n, t, h, h, self.cp0), device=dev)
-        first_input(a, noise_args(1))
+        a = torch.empty((N, t, h, h, self.cp0), device=dev)
+        for gi, grp in enumerate(groups):
+            grp['first_input'](a[gi * n:(gi + 1) * n], noise_args(grp, 1))
         saved['a'][1] = a
         for l in (1, 2, 3, 4):
-            g = self._geom(l, n)
+            g = self._geom(l, N)
             co = self.chans[l]
-            y = torch.empty((n, g.To, g.Ho, g.Wo, co), device=dev)
+            y = torch.empty((N, g.To, g.Ho, g.Wo, co), device=dev)
             hl.conv_fprop(g, a, self.fp.param('dc%d/W' % l), self.fp.param('dc%d/b' % l), y)
             saved['y'][l] = y
-            m = n * g.To * g.Ho * g.Wo
-            ss = None
-            if l >= 2:
-                name = 'bn%d' % l
-                if train:
-                    stats = torch.empty(4 * co, device=dev)
-                    hl.bn_stats(m, co, y, self.fp.param(name + '/gamma'), self.fp.param(name + '/beta'), stats,
-                                self.running[name + '/avg_mean'] if update_stats else None,
-                                self.running[name + '/avg_var'] if update_stats else None, self.ws)
-                    if update_stats:
-                        self.bn_count[name] += 1
-                    saved['stats'][l] = stats
-                    ss = stats[2 * co:]
-                else:
-                    ss = self._test_scale_shift(name)
+            m = n * g.To * g.Ho * g.Wo                       # rows of ONE group
             a = torch.empty_like(y)
-            hl.bn_act_fwd(m, co, y, ss, hl.ACT_LRELU, a, **(noise_args(l + 1) if l < 4 else {}))
+            if l >= 2:
+                saved['stats'][l] = []
+            for gi, grp in enumerate(groups):
+                yg, ag = y[gi * n:(gi + 1) * n], a[gi * n:(gi + 1) * n]
+                ss = None
+                if l >= 2:
+                    name = 'bn%d' % l
+                    if train:
+                        stats = torch.empty(4 * co, device=dev)
+                        hl.bn_stats(m, co, yg, self.fp.param(name + '/gamma'), self.fp.param(name + '/beta'), stats,
+                                    self.running[name + '/avg_mean'] if update_stats else None,
+                                    self.running[name + '/avg_var'] if update_stats else None, self.ws)
+                        if update_stats:
+                            self.bn_count[name] += 1
+                        saved['stats'][l].append(stats)
+                        ss = stats[2 * co:]
+                    else:
+                        ss = self._test_scale_shift(name)
+                hl.bn_act_fwd(m, co, yg, ss, hl.ACT_LRELU, ag, **(noise_args(grp, l + 1) if l < 4 else {}))
             saved['a'][l + 1] = a
         k = a[0].numel()
-        logits = torch.empty((n, self.out_channels), device=dev)
-        hl.fc_fprop(n, k, self.out_channels, a.view(n, k), self.fp.param('dc5/W').view(self.out_channels, k),
+        logits = torch.empty((N, self.out_channels), device=dev)
+        hl.fc_fprop(N, k, self.out_channels, a.view(N, k), self.fp.param('dc5/W').view(self.out_channels, k),
                     self.fp.param('dc5/b'), logits)
         return logits, saved
+
+    @staticmethod
+    def select_group(saved, gi):
+        """The saved state of group gi alone (views, no copies)."""
+        n = saved['n']
+        sl = slice(gi * n, (gi + 1) * n)
+        return {'n': n, 'G': 1, 'a': {l: v[sl] for l, v in saved['a'].items()}, 'y': {l: v[sl] for l, v in saved['y'].items()},
+                'stats': {l: [v[gi]] for l, v in saved['stats'].items()}}
 
     def _test_scale_shift(self, name):
         """fixed_batch_normalization (test mode, reference util.py:92): scale/shift from running stats."""
@@ -278,35 +303,39 @@ class DisNet(_Net):
 
     # ---- backward --------------------------------------------------------------------------
     def backward(self, saved, g_logits, param_grads, gx=None, gx_geom=None, gx_accumulate=False):
-        """g_logits [n][out].  param_grads: accumulate dW/db/dgamma/dbeta into the flat gradient
-        (D's own loss).  gx: when given, the gradient w.r.t. the first conv's input is written
-        (or accumulated) there through gx_geom (G's loss through this D, current weights: Q5)."""
-        n = saved['n']
-        dev = self.device
+        """g_logits [G*n][out] for the G groups of `saved`.  param_grads: accumulate dW/db/dgamma/dbeta into
+        the flat gradient (D's own loss: all groups in one set of launches).  gx (single group only): the
+        gradient w.r.t. the first conv's input is written (or accumulated) there through gx_geom (G's loss
+        through this D, current weights: Q5)."""
+        n, G = saved['n'], saved['G']
+        N = n * G
         fp = self.fp
         hl.set_tag(self.tag)
+        assert gx is None or G == 1
         a5 = saved['a'][5]
         k = a5[0].numel()
         co5 = self.out_channels
         if param_grads:
-            hl.fc_wgrad(n, k, co5, a5.view(n, k), g_logits, fp.grad('dc5/W').view(co5, k), fp.grad('dc5/b'))
+            hl.fc_wgrad(N, k, co5, a5.view(N, k), g_logits, fp.grad('dc5/W').view(co5, k), fp.grad('dc5/b'))
         g = torch.empty_like(a5)
-        hl.fc_dgrad(n, k, co5, g_logits, fp.param('dc5/W').view(co5, k), None, 0, g.view(n, k))
+        hl.fc_dgrad(N, k, co5, g_logits, fp.param('dc5/W').view(co5, k), None, 0, g.view(N, k))
         for l in (4, 3, 2, 1):
-            geom = self._geom(l, n)
+            geom = self._geom(l, N)
             co = self.chans[l]
             y = saved['y'][l]
-            m = n * geom.To * geom.Ho * geom.Wo
-            if l >= 2:
-                name = 'bn%d' % l
-                hl.bn_act_bwd(m, co, g, y, saved['stats'][l], fp.param(name + '/gamma'), hl.ACT_LRELU, g,
-                              fp.grad(name + '/gamma') if param_grads else None,
-                              fp.grad(name + '/beta') if param_grads else None, self.ws)
-            else:
-                hl.bn_act_bwd(m, co, g, y, None, None, hl.ACT_LRELU, g, None, None, self.ws)
+            m = n * geom.To * geom.Ho * geom.Wo                  # rows of ONE group
+            for gi in range(G):
+                gg, yg = g[gi * n:(gi + 1) * n], y[gi * n:(gi + 1) * n]
+                if l >= 2:
+                    name = 'bn%d' % l
+                    hl.bn_act_bwd(m, co, gg, yg, saved['stats'][l][gi], fp.param(name + '/gamma'), hl.ACT_LRELU, gg,
+                                  fp.grad(name + '/gamma') if param_grads else None,
+                                  fp.grad(name + '/beta') if param_grads else None, self.ws)
+                else:
+                    hl.bn_act_bwd(m, co, gg, yg, None, None, hl.ACT_LRELU, gg, None, None, self.ws)
             if param_grads:
                 if l == 1:
-                    hl.colsum_acc(m, co, g, fp.grad('dc1/b'), self.ws)
+                    hl.colsum_acc(m * G, co, g, fp.grad('dc1/b'), self.ws)
                 # dc2..dc4 feed BatchNorm: sum_m gx == 0 exactly (see _Net.BIAS_NOTE), nothing to add
                 hl.conv_wgrad(geom, saved['a'][l], g, fp.grad('dc%d/W' % l))
             if l > 1:

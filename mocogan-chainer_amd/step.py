@@ -156,10 +156,7 @@ class TrainStep:
             def first_real_i(out, na):
                 hl.pack_clip(n, c_img, cp, 1, hw, x_real[:, :, t], out, stride_n=c_img * T * hw, stride_c=T * hw, **na)
 
-        y_real_i, s_real_i = di.forward(n, first_real_i, nz('noise_i_real'), rngs(0))
-        y_real_v, s_real_v = dv.forward(n, first_real_v, nz('noise_v_real'), rngs(1))
-
-        # ------------------------------------------------ forward: fake
+        # ------------------------------------------------ forward: fake (G needs nothing from D)
         draw = inject['gen'] if inject is not None else gen.draw(n, (seed, base + 8 * 2))
         x_fake, s_gen = gen.forward(n, draw)
         t_fake = draw['labels']
@@ -173,26 +170,28 @@ class TrainStep:
             hl.bn_act_fwd(n * hw, cp, xf[:, t], None, hl.ACT_NONE, out, c_valid=c_valid, rows_per_item=hw,
                           item_stride=T * hw * cp, **na)
 
-        y_fake_i, s_fake_i = di.forward(n, first_fake_i, nz('noise_i_fake'), rngs(3))
-        y_fake_v, s_fake_v = dv.forward(n, first_fake_v, nz('noise_v_fake'), rngs(4))
+        # ------------------------------------------------ forward: both discriminators on [real | fake]
+        # (model/updater.py:97-98,107-108 as one 2n batch per net; per-call BatchNorm statistics, real first)
+        y_i, s_i = di.forward_groups(n, [dict(first_input=first_real_i, noise=nz('noise_i_real'), rng=rngs(0)),
+                                         dict(first_input=first_fake_i, noise=nz('noise_i_fake'), rng=rngs(3))])
+        y_v, s_v = dv.forward_groups(n, [dict(first_input=first_real_v, noise=nz('noise_v_real'), rng=rngs(1)),
+                                         dict(first_input=first_fake_v, noise=nz('noise_v_fake'), rng=rngs(4))])
+        y_real_i, y_fake_i, y_real_v, y_fake_v = y_i[:n], y_i[n:], y_v[:n], y_v[n:]
 
         cd = di.out_channels
-        gr = torch.empty((n, cd), device=self.device)
-        gf = torch.empty((n, cd), device=self.device)
+        g_i = torch.empty((2 * n, cd), device=self.device)          # [d loss / d logits] of (real | fake)
+        g_v = torch.empty((2 * n, cd), device=self.device)
         ex = self.exchange
 
         # ------------------------------------------------ image_dis_optimizer.update(loss_dis, ...)   :111
         di.zero_grad()
-        hl.loss_dis(n, cd, y_real_i, y_fake_i, t_real, t_fake, False, self.loss[0:1], gr, gf)
-        di.backward(s_real_i, gr, True)
-        di.backward(s_fake_i, gf, True)
+        hl.loss_dis(n, cd, y_real_i, y_fake_i, t_real, t_fake, False, self.loss[0:1], g_i[:n], g_i[n:])
+        di.backward(s_i, g_i, True)
         work_i = ex.start(di.fp.g) if ex else None
         # ------------------------------------------------ video_dis_optimizer.update(loss_dis, ...)   :112
         dv.zero_grad()
-        gr2, gf2 = torch.empty_like(gr), torch.empty_like(gf)
-        hl.loss_dis(n, cd, y_real_v, y_fake_v, t_real, t_fake, with_ce, self.loss[1:2], gr2, gf2)
-        dv.backward(s_real_v, gr2, True)
-        dv.backward(s_fake_v, gf2, True)
+        hl.loss_dis(n, cd, y_real_v, y_fake_v, t_real, t_fake, with_ce, self.loss[1:2], g_v[:n], g_v[n:])
+        dv.backward(s_v, g_v, True)
         if ex:
             ex.finish(work_i, di.fp.g)                               # D_I's exchange overlapped D_V's backward
         adam_update(di, self.hyper['image_dis'])
@@ -201,9 +200,10 @@ class TrainStep:
         adam_update(dv, self.hyper['video_dis'])
         # ------------------------------------------------ image_gen_optimizer.update(loss_gen, ...)   :113
         gen.zero_grad()
-        gi, gv = gr, gf
+        gi, gv = g_i[:n], g_v[:n]                                    # buffers reused: D's backward has consumed them
         hl.loss_gen(n, cd, y_fake_i, y_fake_v, t_fake, with_ce, self.loss[2:3], gi, gv)
         gx = torch.empty_like(xf)
+        s_fake_v, s_fake_i = dv.select_group(s_v, 1), di.select_group(s_i, 1)
         dv.backward(s_fake_v, gv, False, gx=gx)                      # new D_V weights, old activations (Q5)
         gi_geom = hl.make_geom(n, 1, H, W, cp, di.chans[1], 1, x_stride0=T * hw * cp)
         di.backward(s_fake_i, gi, False, gx=gx[:, t], gx_geom=gi_geom, gx_accumulate=True)
