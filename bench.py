@@ -48,6 +48,18 @@ def dv_conv_flops_per_step(batch):
     return batch * (fwd + wgrad + dgrad), batch * fwd, batch * wgrad, batch * dgrad
 
 
+def pmc_traffic(batch):
+    """HBM-side traffic of the D_V conv launches of one step, from the committed rocprofv3 --pmc summary
+    (FETCH_SIZE / WRITE_SIZE cannot be read from inside the process; tools/pmc_traffic.py documents the
+    collection).  Scaled linearly from the profiled batch.  Returns (bytes_per_step | None, source)."""
+    path = os.path.join(ROOT, 'profiles', 'r01_dv_conv_traffic.json')
+    try:
+        d = json.load(open(path))
+        return d['dv_conv_hbm_bytes_per_step'] * batch / d['batch'], 'profiles/r01_dv_conv_traffic.json (PMC, batch %d)' % d['batch']
+    except Exception:
+        return None, None
+
+
 def cpu_baseline(sample_batch, steps):
     """Times the fp32 NumPy port (oracle/) on a bounded sample: `steps` iterations at batch
     `sample_batch`, full width.  Returns the JSON object."""
@@ -168,6 +180,7 @@ def main():
             kern[k] = {"launches_per_step": n_l / args.steps, "ms_per_step": ms / args.steps,
                        "tflops": fl / (ms / args.steps * 1e-3) / 1e12 if ms > 0 else 0.0}
         all_conv_ms = sum(v[1] for v in timing.values()) / args.steps
+        traffic, traffic_src = pmc_traffic(B)
         out = {
             "metric": "training clips/sec (16x3x64x64)", "value": value, "unit": "clips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -177,7 +190,8 @@ def main():
                        "per_gpu_batch": B, "global_batch": B * world, "n_filters": 64, "dim_zl": 6,
                        "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "bytes per step (memory side of L2, incl. Infinity-Cache hits)",
+                         "traffic_source": traffic_src,
                          "kernel": "VideoDiscriminator Conv3d implicit-GEMM family (gemm_kernel<FpropP|DgradP|WgradP>), "
                                    "dc1..dc4, all launches of one step",
                          "algorithmic_gflop_per_step": tot / 1e9, "kernel_ms_per_step": dv_total_ms, "by_pass": kern,
