@@ -302,11 +302,18 @@ class DisNet(_Net):
         return torch.cat((scale, self.fp.param(name + '/beta') - self.running[name + '/avg_mean'] * scale))
 
     # ---- backward --------------------------------------------------------------------------
-    def backward(self, saved, g_logits, param_grads, gx=None, gx_geom=None, gx_accumulate=False):
+    def grad_bucket_late(self):
+        """(start, end) of the flat-gradient range holding dc4/W .. dc5/b: 76 % of the bytes, and complete
+        right after layer 4 of the backward pass -- the data-parallel exchange starts it early."""
+        o = self.fp.offsets
+        return o['dc4/W'], o['bn2/gamma']
+
+    def backward(self, saved, g_logits, param_grads, gx=None, gx_geom=None, gx_accumulate=False, on_late_bucket=None):
         """g_logits [G*n][out] for the G groups of `saved`.  param_grads: accumulate dW/db/dgamma/dbeta into
         the flat gradient (D's own loss: all groups in one set of launches).  gx (single group only): the
         gradient w.r.t. the first conv's input is written (or accumulated) there through gx_geom (G's loss
-        through this D, current weights: Q5)."""
+        through this D, current weights: Q5).  on_late_bucket: called once the gradients of dc5 and dc4
+        are final (see grad_bucket_late)."""
         n, G = saved['n'], saved['G']
         N = n * G
         fp = self.fp
@@ -338,6 +345,8 @@ class DisNet(_Net):
                     hl.colsum_acc(m * G, co, g, fp.grad('dc1/b'), self.ws)
                 # dc2..dc4 feed BatchNorm: sum_m gx == 0 exactly (see _Net.BIAS_NOTE), nothing to add
                 hl.conv_wgrad(geom, saved['a'][l], g, fp.grad('dc%d/W' % l))
+                if l == 4 and on_late_bucket is not None:
+                    on_late_bucket()
             if l > 1:
                 ga = torch.empty_like(saved['a'][l])
                 hl.conv_dgrad(geom, g, fp.param('dc%d/W' % l), None, ga)

@@ -50,15 +50,18 @@ class GradExchange:
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
     def start(self, flat_grad):
+        """Asynchronous SUM all-reduce of a (slice of a) flat gradient; returns a handle for finish()."""
         if self.world == 1:
             return None
-        return self.dist.all_reduce(flat_grad, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return (self.dist.all_reduce(flat_grad, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True), flat_grad)
 
-    def finish(self, work, flat_grad):
-        if work is None:
+    def finish(self, handle, flat_grad=None):
+        """Wait for the collective and turn the sum into the mean."""
+        if handle is None:
             return
+        work, buf = handle
         work.wait()
-        flat_grad.mul_(1.0 / self.world)
+        buf.mul_(1.0 / self.world)
 
     def broadcast_params(self, tensors, src=0):
         if self.world == 1:
@@ -191,12 +194,18 @@ class TrainStep:
         # ------------------------------------------------ video_dis_optimizer.update(loss_dis, ...)   :112
         dv.zero_grad()
         hl.loss_dis(n, cd, y_real_v, y_fake_v, t_real, t_fake, with_ce, self.loss[1:2], g_v[:n], g_v[n:])
-        dv.backward(s_v, g_v, True)
+        # D_V's gradient is exchanged in two buckets: dc4/W..dc5/b (76 % of the bytes) is final after the
+        # first two layers of the backward pass and travels while dc3..dc1 are still being computed
+        late = []
+        lo, hi = dv.grad_bucket_late()
+        dv.backward(s_v, g_v, True, on_late_bucket=(lambda: late.append(ex.start(dv.fp.g[lo:hi]))) if ex else None)
         if ex:
-            ex.finish(work_i, di.fp.g)                               # D_I's exchange overlapped D_V's backward
+            ex.finish(work_i)                                        # D_I's exchange overlapped D_V's backward
         adam_update(di, self.hyper['image_dis'])
         if ex:
-            ex.finish(ex.start(dv.fp.g), dv.fp.g)
+            rest = [ex.start(dv.fp.g[:lo]), ex.start(dv.fp.g[hi:])]
+            for h in late + rest:
+                ex.finish(h)
         adam_update(dv, self.hyper['video_dis'])
         # ------------------------------------------------ image_gen_optimizer.update(loss_gen, ...)   :113
         gen.zero_grad()
@@ -213,7 +222,7 @@ class TrainStep:
             gx = gxg
         gen.backward(s_gen, gx)
         if ex:
-            ex.finish(ex.start(gen.fp.g), gen.fp.g)
+            ex.finish(ex.start(gen.fp.g))
         adam_update(gen, self.hyper['image_gen'])
         self.iteration += 1
         return {'x_fake': x_fake, 't_fake': t_fake, 't': t, 'gx_fake': gx, 'saved_gen': s_gen, 'saved_fake_i': s_fake_i, 'saved_fake_v': s_fake_v,

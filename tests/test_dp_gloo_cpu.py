@@ -49,8 +49,10 @@ def _worker(rank, world, port, q):
 
     def reduce(name, grads):
         keys, flat = _flatten(grads)
-        work = ex.start(flat)                               # async all-reduce (SUM) ...
-        ex.finish(work, flat)                               # ... wait, then / world
+        half = flat.numel() // 2                            # two buckets in flight, like D_V's gradient
+        handles = [ex.start(flat[:half]), ex.start(flat[half:])]   # async all-reduce (SUM) ...
+        for h in handles:
+            ex.finish(h)                                    # ... wait, then / world
         o = 0
         for k in keys:
             n = grads[k].size
