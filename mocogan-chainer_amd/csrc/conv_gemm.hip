@@ -52,6 +52,7 @@ struct Geom {
     int taps;          // kt * 16
     u32 x_bytes, y_bytes, w_bytes;   // buffer extents for the hardware range check
     u32 magic_To;      // floor(2^32 / To) + 1:  q / To == umulhi(q, magic_To) for q < 2^32 / To
+    u32 magic_N;       // the same for the batch size N
 };
 
 __device__ __forceinline__ long long x_batch_off(const Geom& g, int n) {
@@ -68,6 +69,8 @@ __device__ __forceinline__ void divmod_c(int k, int C, int lgC, int& q, int& r) 
 
 // q / To by multiplication (To = 1 has no 32-bit magic number)
 __device__ __forceinline__ int div_To(const Geom& g, int q) { return g.To == 1 ? q : (int)__umulhi((u32)q, g.magic_To); }
+
+__device__ __forceinline__ int div_N(const Geom& g, int q) { return g.N == 1 ? q : (int)__umulhi((u32)q, g.magic_N); }
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const float* p, u32 bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, bytes, 0x00020000);
@@ -175,8 +178,8 @@ struct DgradP {
         ak = (tid % KC4) * 4;
         {
             int mlast = m0 + BM - 1 < M ? m0 + BM - 1 : M - 1;
-            tmin = (m0 >> (g.lgWo + g.lgHo)) / g.N;
-            tmax = (mlast >> (g.lgWo + g.lgHo)) / g.N;
+            tmin = div_N(g, m0 >> (g.lgWo + g.lgHo));
+            tmax = div_N(g, mlast >> (g.lgWo + g.lgHo));
         }
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
@@ -184,7 +187,7 @@ struct DgradP {
             bool ok = m < M;
             int mm = ok ? m : 0;
             int w2 = mm & (g.Wo - 1), h2 = (mm >> g.lgWo) & (g.Ho - 1), q = mm >> (g.lgWo + g.lgHo);
-            int t = q / g.N, n = q - t * g.N;
+            int t = div_N(g, q), n = q - t * g.N;
             int hh = h2 + ph, ww = w2 + pw;
             abase[j] = ((((n * g.To + t) * g.Ho + hh) * g.Wo + ww) * g.Co) * 4;
             u32 mk = 0;
@@ -252,7 +255,7 @@ struct DgradP {
     __device__ void store(int m, int n, float v) const {
         if (m >= M || n >= g.Ci) return;
         int w2 = m & (g.Wo - 1), h2 = (m >> g.lgWo) & (g.Ho - 1), q = m >> (g.lgWo + g.lgHo);
-        int nb = q % g.N, t = q / g.N;
+        int t = div_N(g, q), nb = q - t * g.N;
         long long o = x_batch_off(g, nb) + ((long long)(t * g.Hi + 2 * h2 + ph) * g.Wi + 2 * w2 + pw) * g.Ci + n;
         if (bias) v += bias[n];
         if (act == MCG_ACT_TANH) v = tanhf(v);
@@ -493,7 +496,7 @@ __global__ __launch_bounds__(NTHREADS) void dgrad_c4_kernel(Geom g, const float*
         const int run = (blockIdx.x * (NTHREADS / 64) + wave) * C4_RUNS_PER_WAVE + it;     // wave-uniform
         if (run >= runs) break;
         const int w0 = (run & ((1 << lgR) - 1)) << 4, h2 = (run >> lgR) & (g.Ho - 1), q = run >> (lgR + g.lgHo);
-        const int n = q % g.N, t = q / g.N;
+        const int t = div_N(g, q), n = q - t * g.N;
         const float* yb = y + (long long)n * g.To * g.Ho * g.Wo * Co + c4 * 4;
         f32x4 acc[4] = {zero, zero, zero, zero};
 #pragma unroll
@@ -582,6 +585,7 @@ int make_geom(const mcg_conv_geom* c, Geom& g) {
     if (x_elems * 4 >= (1ll << 31) || y_elems * 4 >= (1ll << 31) || w_elems * 4 >= (1ll << 31)) return MCG_ERR_UNSUPPORTED;
     g.x_bytes = (u32)(x_elems * 4); g.y_bytes = (u32)(y_elems * 4); g.w_bytes = (u32)(w_elems * 4);
     g.magic_To = (u32)((1ull << 32) / (unsigned)g.To) + 1u;
+    g.magic_N = (u32)((1ull << 32) / (unsigned)g.N) + 1u;
     return MCG_OK;
 }
 

@@ -123,3 +123,35 @@ def test_trainer_snapshot_resume_round_trip(tmp_path):
     assert all(np.array_equal(sa['v'][k], sb['v'][k]) for k in sa['v'])
     tr2.run()
     assert u2.iteration == 3
+
+
+def test_train_and_generate_entry_points(tmp_path, monkeypatch):
+    """train.py (synthetic data, 2 epochs) writes Chainer-keyed checkpoints and a log; generate_samples.py loads
+    the generator back and writes frames (reference train.py:132-192, generate_samples.py:17-58)."""
+    import json
+    import train
+    import generate_samples
+    monkeypatch.chdir(tmp_path)
+    tr = train.main(['--dataset_type', 'synthetic', '--synthetic_size', '8', '--batchsize', '4', '--max_epoch', '2',
+                     '--n_filters_gen', '8', '--snapshot_interval', '1', '--log_tensorboard_interval', '1',
+                     '--num_gen_samples', '4', '--save_name', 'run', '--model', 'infogan'])
+    out = tmp_path / 'result' / 'run'
+    assert tr.updater.iteration == 4 and tr.updater.epoch == 2
+    for f in ('snapshot_epoch_2.npz', 'image_gen_epoch_1.npz', 'video_dis_epoch_2.npz', 'image_gen_epoch_fianl.npz', 'log'):
+        assert (out / f).exists(), f
+    log = json.load(open(out / 'log'))
+    assert len(log) == 2 and {'epoch', 'iteration', 'image_gen/loss', 'image_dis/loss', 'video_dis/loss'} <= set(log[-1])
+    assert all(np.isfinite(e['image_gen/loss']) for e in log)
+    with np.load(out / 'image_gen_epoch_fianl.npz') as f:
+        assert f['dc1/W'].shape == (60, 64, 4, 4) and f['g0/W_r/W'].shape == (10, 16)
+    # resume: one more epoch from the snapshot
+    tr2 = train.main(['--dataset_type', 'synthetic', '--synthetic_size', '8', '--batchsize', '4', '--max_epoch', '3',
+                      '--n_filters_gen', '8', '--save_name', 'run2', '--model', 'infogan',
+                      '--resume', str(out / 'snapshot_epoch_2.npz')])
+    assert tr2.updater.iteration == 6 and tr2.updater.epoch == 3
+    generate_samples.main([str(out / 'image_gen_epoch_fianl.npz'), str(tmp_path / 'samples'), '--num', '4',
+                           '--dim_zl', '6', '--n_filters', '8'])
+    frames = sorted((tmp_path / 'samples' / 'grid').glob('*.jpg'))
+    assert len(frames) == 16
+    from PIL import Image
+    assert Image.open(frames[0]).size == (128, 128)
