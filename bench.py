@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2516.8         # MI355X_MICROARCH.md: bf16 MFMA, dense (16x the f32 MFMA rate)
 
 
 def dv_conv_flops_per_clip():
@@ -97,6 +98,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=32, help='clips per GPU (BASELINE config C2: 32)')
     ap.add_argument('--model', default='normal', choices=['normal', 'cgan', 'infogan'])
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+                    help="MFMA operand type of the conv GEMMs: f32 = BASELINE configs[1] (the headline); "
+                         "bf16 = configs[2] (use with --batch 256), fp32 accumulation / parameters / Adam")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-batch', type=int, default=4)
     ap.add_argument('--cpu-sample-steps', type=int, default=2)
@@ -131,7 +135,7 @@ def main():
     hl.load()
 
     gen, di, dv = mstep.make_models(args.model, num_labels=6, seed=0)         # identical init on every rank
-    ts = mstep.TrainStep(args.model, gen, di, dv, exchange=exchange, seed=1234, rank=rank)
+    ts = mstep.TrainStep(args.model, gen, di, dv, exchange=exchange, seed=1234, rank=rank, precision=args.dtype)
     B = args.batch
     g = torch.Generator(device='cuda')
     g.manual_seed(rank)
@@ -180,19 +184,23 @@ def main():
             kern[k] = {"launches_per_step": n_l / args.steps, "ms_per_step": ms / args.steps,
                        "tflops": fl / (ms / args.steps * 1e-3) / 1e12 if ms > 0 else 0.0}
         all_conv_ms = sum(v[1] for v in timing.values()) / args.steps
-        traffic, traffic_src = pmc_traffic(B)
+        traffic, traffic_src = pmc_traffic(B) if args.dtype == 'f32' else (None, None)
+        peak = PEAK_FP32_MFMA_TFLOPS if args.dtype == 'f32' else PEAK_BF16_MFMA_TFLOPS
+        cfg_name = "configs[2]" if (args.dtype == 'bf16' and B == 256) else "configs[1]" if (args.dtype == 'f32' and B == 32) else \
+            "off-list variant of configs[1]"
         out = {
             "metric": "training clips/sec (16x3x64x64)", "value": value, "unit": "clips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (single-device rehearsal)" if rehearsal else ""),
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic" + (" (single-device rehearsal)" if rehearsal else ""),
             "config": {"workload": "MUG-shape synthetic (B,3,16,64,64) U(-1,1), one update_core iteration per step "
-                                   "(BASELINE.json configs[1])", "model": "mocogan-" + args.model,
+                                   "(BASELINE.json %s)" % cfg_name, "model": "mocogan-" + args.model,
                        "per_gpu_batch": B, "global_batch": B * world, "n_filters": 64, "dim_zl": 6,
                        "parallelism": "dp%d" % world},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "bytes per step (memory side of L2, incl. Infinity-Cache hits)",
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic, "traffic_unit": "bytes per step (memory side of L2, incl. Infinity-Cache hits)",
                          "traffic_source": traffic_src,
-                         "kernel": "VideoDiscriminator Conv3d implicit-GEMM family (gemm_kernel<FpropP|DgradP|WgradP>), "
+                         "kernel": "VideoDiscriminator Conv3d implicit-GEMM family (%s<FpropP|DgradP|WgradP>), "
+                                   % ("gemm_kernel" if args.dtype == 'f32' else "gemm_bf16_kernel") +
                                    "dc1..dc4, all launches of one step",
                          "algorithmic_gflop_per_step": tot / 1e9, "kernel_ms_per_step": dv_total_ms, "by_pass": kern,
                          "all_conv_kernels_ms_per_step": all_conv_ms,

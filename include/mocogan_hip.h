@@ -39,6 +39,11 @@ typedef enum mcg_status {
 
 enum { MCG_ACT_NONE = 0, MCG_ACT_RELU = 1, MCG_ACT_LRELU = 2, MCG_ACT_TANH = 3 };
 
+/* MFMA operand type of the convolution GEMMs.  Tensors are fp32 in memory either way and products are
+ * accumulated in fp32; MCG_PREC_BF16 rounds both operands to bf16 (round-to-nearest-even) inside the
+ * kernel and multiplies them on v_mfma_f32_32x32x16_bf16 (BASELINE config "bf16 MFMA tiles"). */
+enum { MCG_PREC_F32 = 0, MCG_PREC_BF16 = 1 };
+
 /* Geometry of one 4x4(x4) stride-(1,2,2) pad-(0,1,1) convolution, i.e. every strided layer of
  * the reference: L.ConvolutionND / L.Convolution2D dc1..dc4 (model/net.py:133-136,174-177) and,
  * read backwards, L.DeconvolutionND dc2..dc5 (model/net.py:45-48).
@@ -53,6 +58,7 @@ typedef struct mcg_conv_geom {
     int32_t To, Ho, Wo, Co;
     int32_t kt;
     int32_t x_perm_n;
+    int32_t precision;         /* MCG_PREC_F32 or MCG_PREC_BF16 */
     int64_t x_stride0, x_stride1;
 } mcg_conv_geom;
 

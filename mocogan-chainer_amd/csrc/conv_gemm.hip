@@ -53,6 +53,7 @@ struct Geom {
     u32 x_bytes, y_bytes, w_bytes;   // buffer extents for the hardware range check
     u32 magic_To;      // floor(2^32 / To) + 1:  q / To == umulhi(q, magic_To) for q < 2^32 / To
     u32 magic_N;       // the same for the batch size N
+    int prec;          // MCG_PREC_F32 / MCG_PREC_BF16
 };
 
 __device__ __forceinline__ long long x_batch_off(const Geom& g, int n) {
@@ -462,6 +463,138 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(P p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// The same GEMM on the bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 accumulation.
+//
+// Tensors stay fp32 in HBM (master weights, activations, gradients: BN statistics, Adam and every
+// elementwise pass are unchanged); the operands are rounded to bf16 (round-to-nearest-even,
+// v_cvt_pk_bf16_f32) on their way from the staging registers into LDS, so the policies above -- and
+// with them every address computation -- are shared with the fp32 kernel.  LDS tiles:
+//   K-contiguous operand : [row][BK + 8] bf16; a lane's MFMA operand (8 consecutive k) is one ds_read_b128;
+//   other operands       : [k][cols + 32] bf16 in global orientation; the MFMA operand is gathered with
+//                          the transposing LDS read ds_read_b64_tr_b16 (a group of 16 lanes reads a
+//                          4 (k) x 16 (col) block and each lane receives the 4 k-values of its column).
+// The paddings make both access patterns bank-conflict free (row stride = 16 or 48 dwords mod 64 for the
+// transposed read, 36 / 20 dwords for the b128 read).
+// ------------------------------------------------------------------------------------------
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+__device__ __forceinline__ s16x4 lds_tr16(const u16* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p);
+}
+
+template <class P, int BM, int BN, int BK>
+__global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(P p) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int KPAD = 8, CPAD = 32;
+    constexpr int A_R = P::A_KC ? BM : BK, A_C = P::A_KC ? BK : BM;
+    constexpr int B_R = P::B_KC ? BN : BK, B_C = P::B_KC ? BK : BN;
+    constexpr int A_LD = A_C + (P::A_KC ? KPAD : CPAD), B_LD = B_C + (P::B_KC ? KPAD : CPAD);
+    constexpr int NA = P::NA, NB = P::NB;
+    __shared__ __attribute__((aligned(16))) u16 lds[A_R * A_LD + B_R * B_LD];
+    u16* As = lds;
+    u16* Bs = lds + A_R * A_LD;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    // transposed-read coordinates: 16-lane group `lane>>4` = (k half lh, column half), lane 4q+p of the
+    // group addresses row q, columns 4p..4p+3 of the 4x16 block
+    const int tr_row = 8 * lh + ((lane & 15) >> 2), tr_col = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
+    const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
+    int bx, by, bz;
+    {   // XCD-aware tile mapping, as in gemm_kernel
+        const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+        const int nwg = gx * gy * gz;
+        const int L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const int xcd = L & 7, q = nwg >> 3, r = nwg & 7;
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+        if (P::ORDER == 0) { by = t % gy; bx = t / gy; bz = 0; }
+        else if (P::ORDER == 1) { bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z; }
+        else { bx = t % gx; by = (t / gx) % gy; bz = t / (gx * gy); }
+    }
+    const int m0 = bx * BM, n0 = by * BN, z = bz;
+
+    p.init(m0, n0, tid, z);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[NA], rb[NB];
+    const int kend = p.k_end(z);
+    int k0 = p.next_valid(p.k_begin(z));
+    if (k0 < kend) { p.load_a(k0, ra); p.load_b(k0, rb); }
+
+    constexpr int A_C4 = A_C / 4, B_C4 = B_C / 4;
+    while (k0 < kend) {
+        // registers -> bf16 -> LDS
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            int q = tid + NTHREADS * j;
+            *reinterpret_cast<bf16x4*>(&As[(q / A_C4) * A_LD + (q % A_C4) * 4]) = __builtin_convertvector(ra[j], bf16x4);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            int q = tid + NTHREADS * j;
+            *reinterpret_cast<bf16x4*>(&Bs[(q / B_C4) * B_LD + (q % B_C4) * 4]) = __builtin_convertvector(rb[j], bf16x4);
+        }
+        __syncthreads();
+        const int kn = p.next_valid(k0 + BK);
+        { const int kl = kn < kend ? kn : kend - BK; p.load_a(kl, ra); p.load_b(kl, rb); }
+#pragma unroll
+        for (int kc = 0; kc < BK / 16; ++kc) {
+            bf16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if constexpr (P::A_KC) {
+                    fa[i] = *reinterpret_cast<const bf16x8*>(&As[(wm0 + i * 32 + li) * A_LD + kc * 16 + 8 * lh]);
+                } else {
+                    const u16* b = &As[(kc * 16 + tr_row) * A_LD + wm0 + i * 32 + tr_col];
+                    s16x4 lo = lds_tr16(b), hi = lds_tr16(b + 4 * A_LD);
+                    fa[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                if constexpr (P::B_KC) {
+                    fb[i] = *reinterpret_cast<const bf16x8*>(&Bs[(wn0 + i * 32 + li) * B_LD + kc * 16 + 8 * lh]);
+                } else {
+                    const u16* b = &Bs[(kc * 16 + tr_row) * B_LD + wn0 + i * 32 + tr_col];
+                    s16x4 lo = lds_tr16(b), hi = lds_tr16(b + 4 * B_LD);
+                    fb[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        }
+        __syncthreads();
+        k0 = kn;
+    }
+
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                int col = n0 + wn0 + b * 32 + li;
+                p.store(row, col, acc[a][b][r]);
+            }
+}
+
+// ------------------------------------------------------------------------------------------
 // dgrad for Ci == 4, Co == 64 (the 3-channel clip padded to 4: D's first layer backward and G's
 // last layer forward).  N = 4 output columns would waste 15/16 of a 64-wide MFMA tile, so this case
 // runs on the VALU with fully coalesced loads: a wave works on a run of 16 consecutive output pixels
@@ -567,6 +700,8 @@ int make_geom(const mcg_conv_geom* c, Geom& g) {
     g.To = c->To; g.Ho = c->Ho; g.Wo = c->Wo; g.Co = c->Co; g.kt = c->kt;
     g.perm_n = c->x_perm_n; g.xs0 = c->x_stride0; g.xs1 = c->x_stride1;
     g.taps = c->kt * 16;
+    g.prec = c->precision;
+    if (g.prec != MCG_PREC_F32 && g.prec != MCG_PREC_BF16) return MCG_ERR_BAD_ARG;
     g.lgHo = ilog2_exact(g.Ho); g.lgWo = ilog2_exact(g.Wo);
     g.lgCi = ilog2_exact(g.Ci); g.lgCo = ilog2_exact(g.Co);
     if (g.N <= 0 || g.Ci <= 0 || g.Co <= 0) return MCG_ERR_BAD_ARG;
@@ -591,25 +726,27 @@ int make_geom(const mcg_conv_geom* c, Geom& g) {
 
 int launch_status() { return hipGetLastError() == hipSuccess ? MCG_OK : MCG_ERR_LAUNCH; }
 
-template <int BM, int BN, int BK>
+template <int BM, int BN, int BK, bool BF = false>
 void launch_fprop(const Geom& g, const float* x, const float* w, const float* bias, float* y, hipStream_t s) {
     FpropP<BM, BN, BK> p;
     p.g = g; p.x = x; p.w = w; p.bias = bias; p.y = y;
     p.M = g.N * g.To * g.Ho * g.Wo; p.K = g.taps * g.Ci;
     dim3 grid((p.M + BM - 1) / BM, (g.Co + BN - 1) / BN, 1);
-    hipLaunchKernelGGL((gemm_kernel<FpropP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
+    if (BF) hipLaunchKernelGGL((gemm_bf16_kernel<FpropP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
+    else hipLaunchKernelGGL((gemm_kernel<FpropP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
 }
 
-template <int BM, int BN, int BK>
+template <int BM, int BN, int BK, bool BF = false>
 void launch_dgrad(const Geom& g, const float* y, const float* w, const float* bias, float* x, int act, int acc, hipStream_t s) {
     DgradP<BM, BN, BK> p;
     p.g = g; p.y = y; p.w = w; p.bias = bias; p.x = x; p.act = act; p.accumulate = acc;
     p.M = g.N * g.Ti * g.Ho * g.Wo; p.K = g.kt * 4 * g.Co;
     dim3 grid((p.M + BM - 1) / BM, (g.Ci + BN - 1) / BN, 4);
-    hipLaunchKernelGGL((gemm_kernel<DgradP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
+    if (BF) hipLaunchKernelGGL((gemm_bf16_kernel<DgradP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
+    else hipLaunchKernelGGL((gemm_kernel<DgradP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
 }
 
-template <int BM, int BN, int BK>
+template <int BM, int BN, int BK, bool BF = false>
 void launch_wgrad(const Geom& g, const float* x, const float* y, float* dw, hipStream_t s) {
     WgradP<BM, BN, BK> p;
     p.g = g; p.x = x; p.y = y; p.dw = dw;
@@ -623,8 +760,22 @@ void launch_wgrad(const Geom& g, const float* x, const float* y, float* dw, hipS
     p.chunk = steps_per * BK;
     splits = (p.Mpix + p.chunk - 1) / p.chunk;
     dim3 grid((g.Co + BM - 1) / BM, (p.Kf + BN - 1) / BN, splits);
-    hipLaunchKernelGGL((gemm_kernel<WgradP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
+    if (BF) hipLaunchKernelGGL((gemm_bf16_kernel<WgradP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
+    else hipLaunchKernelGGL((gemm_kernel<WgradP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
 }
+
+// tile / K-depth / MFMA-type dispatch of the launch_* templates
+#define MCG_TILES(fn, t, BK, BF, ...)                                   \
+    do {                                                                \
+        if ((t) == 1) fn<128, 128, BK, BF>(__VA_ARGS__);                \
+        else if ((t) == 2) fn<128, 64, BK, BF>(__VA_ARGS__);            \
+        else fn<64, 64, BK, BF>(__VA_ARGS__);                           \
+    } while (0)
+#define MCG_DISPATCH(fn, t, bk64, bf, ...)                              \
+    do {                                                                \
+        if (bf) { if (bk64) MCG_TILES(fn, t, 64, true, __VA_ARGS__); else MCG_TILES(fn, t, 32, true, __VA_ARGS__); }      \
+        else    { if (bk64) MCG_TILES(fn, t, 64, false, __VA_ARGS__); else MCG_TILES(fn, t, 32, false, __VA_ARGS__); }    \
+    } while (0)
 
 int g_tile_override = 0;   // 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64 (tests / tuning)
 int g_bk_override = 0;     // 0 auto, 32 or 64
@@ -659,16 +810,8 @@ extern "C" int mcg_conv_fprop(const mcg_conv_geom* c, const float* x, const floa
     // 64-deep K-steps halve the per-step overhead (barriers, LDS refill, address math) and pay off when the
     // grid is small (few resident waves to hide it: measured on dc4); big grids prefer the higher occupancy of 32.
     const long long nblk = ((M + (t == 3 ? 63 : 127)) / (t == 3 ? 64 : 128)) * ((g.Co + (t == 1 ? 127 : 63)) / (t == 1 ? 128 : 64));
-    const bool bk64 = (g.taps * g.Ci) % 64 == 0 && (g_bk_override ? g_bk_override == 64 : nblk < 1024);
-    if (bk64) {
-        if (t == 1) launch_fprop<128, 128, 64>(g, x, w, bias, y, s);
-        else if (t == 2) launch_fprop<128, 64, 64>(g, x, w, bias, y, s);
-        else launch_fprop<64, 64, 64>(g, x, w, bias, y, s);
-    } else {
-        if (t == 1) launch_fprop<128, 128, 32>(g, x, w, bias, y, s);
-        else if (t == 2) launch_fprop<128, 64, 32>(g, x, w, bias, y, s);
-        else launch_fprop<64, 64, 32>(g, x, w, bias, y, s);
-    }
+    const bool bk64 = (g.taps * g.Ci) % 64 == 0 && (g_bk_override ? g_bk_override == 64 : (nblk < 1024 || g.prec == MCG_PREC_BF16));
+    MCG_DISPATCH(launch_fprop, t, bk64, g.prec == MCG_PREC_BF16, g, x, w, bias, y, s);
     return launch_status();
 }
 
@@ -696,16 +839,8 @@ extern "C" int mcg_conv_dgrad(const mcg_conv_geom* c, const float* y, const floa
         else t = g.Ci <= 64 ? 2 : (4 * mt * ((g.Ci + 127) / 128) >= 1024 ? 1 : 2);
     }
     const long long nblk = 4 * ((M + (t == 3 ? 63 : 127)) / (t == 3 ? 64 : 128)) * ((g.Ci + (t == 1 ? 127 : 63)) / (t == 1 ? 128 : 64));
-    const bool bk64 = (g.kt * 4 * g.Co) % 64 == 0 && (g_bk_override ? g_bk_override == 64 : nblk < 1024);
-    if (bk64) {
-        if (t == 1) launch_dgrad<128, 128, 64>(g, y, w, bias, x, act, accumulate, s);
-        else if (t == 2) launch_dgrad<128, 64, 64>(g, y, w, bias, x, act, accumulate, s);
-        else launch_dgrad<64, 64, 64>(g, y, w, bias, x, act, accumulate, s);
-    } else {
-        if (t == 1) launch_dgrad<128, 128, 32>(g, y, w, bias, x, act, accumulate, s);
-        else if (t == 2) launch_dgrad<128, 64, 32>(g, y, w, bias, x, act, accumulate, s);
-        else launch_dgrad<64, 64, 32>(g, y, w, bias, x, act, accumulate, s);
-    }
+    const bool bk64 = (g.kt * 4 * g.Co) % 64 == 0 && (g_bk_override ? g_bk_override == 64 : (nblk < 1024 || g.prec == MCG_PREC_BF16));
+    MCG_DISPATCH(launch_dgrad, t, bk64, g.prec == MCG_PREC_BF16, g, y, w, bias, x, act, accumulate, s);
     return launch_status();
 }
 
@@ -718,14 +853,7 @@ extern "C" int mcg_conv_wgrad(const mcg_conv_geom* c, const float* x, const floa
     int Kf = g.taps * g.Ci;
     int t = g_tile_override;
     if (!t) t = (g.Co <= 64 || Kf <= 64) ? 3 : 1;
-    if (g_bk_override == 64) {
-        if (t == 1) launch_wgrad<128, 128, 64>(g, x, y, dw, s);
-        else if (t == 2) launch_wgrad<128, 64, 64>(g, x, y, dw, s);
-        else launch_wgrad<64, 64, 64>(g, x, y, dw, s);
-    } else {
-        if (t == 1) launch_wgrad<128, 128, 32>(g, x, y, dw, s);
-        else if (t == 2) launch_wgrad<128, 64, 32>(g, x, y, dw, s);
-        else launch_wgrad<64, 64, 32>(g, x, y, dw, s);
-    }
+    const bool bk64 = g_bk_override ? g_bk_override == 64 : g.prec == MCG_PREC_BF16;
+    MCG_DISPATCH(launch_wgrad, t, bk64, g.prec == MCG_PREC_BF16, g, x, y, dw, s);
     return launch_status();
 }

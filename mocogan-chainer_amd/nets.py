@@ -74,6 +74,11 @@ class _Net:
     # backward passes below leave that gradient at its exact value 0 instead of reducing gx again.
     BIAS_NOTE = "pre-BatchNorm bias gradients are exactly zero"
 
+    # MFMA operand type of this network's convolution GEMMs: 'f32' (default, the parity configuration) or
+    # 'bf16' (operands rounded to bf16 in-kernel, fp32 accumulation; parameters, activations, BN statistics
+    # and Adam stay fp32).  BASELINE.json configs[2].
+    precision = 'f32'
+
     def _alloc(self, specs, device):
         self.device = torch.device(device)
         self.fp = FlatParams(specs, self.device)
@@ -213,7 +218,8 @@ class DisNet(_Net):
 
     def _geom(self, l, n, x_stride0=None):
         t, h = self._extents(l)
-        return hl.make_geom(n, t, h, h, lay.pad4(self.chans[l - 1]), self.chans[l], self.kt, x_stride0=x_stride0)
+        return hl.make_geom(n, t, h, h, lay.pad4(self.chans[l - 1]), self.chans[l], self.kt, x_stride0=x_stride0,
+                            precision=self.precision)
 
     # ---- forward ---------------------------------------------------------------------------
     def forward(self, n, first_input, noise=None, rng=None, update_stats=True):
@@ -447,8 +453,8 @@ class GenNet(_Net):
         if clip_order_n:
             T = frames // clip_order_n
             return hl.make_geom(frames, 1, h, h, ci, self.chans[l - 1], 1, x_stride0=T * h * h * ci,
-                                x_perm_n=clip_order_n, x_stride1=h * h * ci)
-        return hl.make_geom(frames, 1, h, h, ci, self.chans[l - 1], 1)
+                                x_perm_n=clip_order_n, x_stride1=h * h * ci, precision=self.precision)
+        return hl.make_geom(frames, 1, h, h, ci, self.chans[l - 1], 1, precision=self.precision)
 
     # ---- latent draws (model/net.py:55-56,66,71,92,102) ------------------------------------------
     def draw(self, n, rng):

@@ -73,9 +73,13 @@ class GradExchange:
 class TrainStep:
     """Holds the three networks, their Adam hyper-parameters and runs update_core on device data."""
 
-    def __init__(self, model, gen, dis_i, dis_v, hyper=None, exchange=None, seed=0, rank=0):
+    def __init__(self, model, gen, dis_i, dis_v, hyper=None, exchange=None, seed=0, rank=0, precision=None):
         assert model in ('normal', 'cgan', 'infogan')
         self.model, self.gen, self.dis_i, self.dis_v = model, gen, dis_i, dis_v
+        if precision is not None:                                 # 'f32' | 'bf16': MFMA operand type of every conv GEMM
+            assert precision in ('f32', 'bf16')
+            for net in (gen, dis_i, dis_v):
+                net.precision = precision
         self.hyper = hyper or {'image_gen': AdamHyper(), 'image_dis': AdamHyper(), 'video_dis': AdamHyper()}
         self.exchange = exchange
         self.seed, self.rank = seed, rank
@@ -214,7 +218,7 @@ class TrainStep:
         gx = torch.empty_like(xf)
         s_fake_v, s_fake_i = dv.select_group(s_v, 1), di.select_group(s_i, 1)
         dv.backward(s_fake_v, gv, False, gx=gx)                      # new D_V weights, old activations (Q5)
-        gi_geom = hl.make_geom(n, 1, H, W, cp, di.chans[1], 1, x_stride0=T * hw * cp)
+        gi_geom = hl.make_geom(n, 1, H, W, cp, di.chans[1], 1, x_stride0=T * hw * cp, precision=di.precision)
         di.backward(s_fake_i, gi, False, gx=gx[:, t], gx_geom=gi_geom, gx_accumulate=True)
         if cgan:
             gxg = torch.zeros_like(x_fake)

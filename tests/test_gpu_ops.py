@@ -92,6 +92,55 @@ def test_conv_three_passes(hl, case, tile):
         hl.set_tile_override(0)
 
 
+def _bf16_round(a):
+    """round-to-nearest-even to bf16, returned as float64 (what v_cvt_pk_bf16_f32 does to an fp32 operand)"""
+    return torch.tensor(np.asarray(a, np.float32)).to(torch.bfloat16).double().numpy()
+
+
+BF16_TOL = 2e-2      # SURVEY 8c: bf16 configuration, forward rel-L2 <= 2e-2
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 101, 102, 103, 201, 202, 203])
+def test_conv_three_passes_bf16_mfma(hl, case, tile):
+    """precision = bf16: operands are rounded to bf16 in the kernel, products accumulate in fp32.
+    (1) On inputs that are already bf16-representable the rounding is the identity, so the result must
+    match the float64 oracle as tightly as the fp32 path does -- this pins the operand layout of the
+    32x32x16 MFMA and of the transposing LDS reads.  (2) On general fp32 inputs the result is within the
+    bf16 tolerance of the oracle."""
+    N, Ti, H, Ci, Co, kt = case
+    rng = np.random.RandomState(hash(case) % 2**31 + 1)
+    stride, pad = (1, 2, 2), (0, 1, 1)
+    lay = L()
+    hl.set_tile_override(tile)
+    try:
+        for exact in (True, False):
+            x = rng.uniform(-1, 1, (N, Ci, Ti, H, H))
+            W = rng.randn(Co, Ci, kt, 4, 4) * 0.1
+            b = rng.randn(Co)
+            gy = rng.randn(N, Co, Ti - kt + 1, H // 2, H // 2)
+            if exact:
+                x, W, gy = _bf16_round(x), _bf16_round(W), _bf16_round(gy)
+            y_ref = F.conv3d_fwd(x, W, b, stride, pad)
+            gx_ref, gW_ref, _ = F.conv3d_bwd(x, W, gy, stride, pad)
+            ftol, btol = (FWD_TOL, BWD_TOL) if exact else (BF16_TOL, BF16_TOL)
+
+            xd, wd, bd = lay.act_to_dev(dev(x)), lay.conv_w_to_dev(dev(W)), dev(b)
+            g = hl.make_geom(N, Ti, H, H, xd.shape[-1], Co, kt, precision='bf16')
+            yd = torch.empty((N, g.To, g.Ho, g.Wo, Co), device="cuda")
+            hl.conv_fprop(g, xd, wd, bd, yd)
+            assert rel_l2(lay.act_from_dev(yd, Co), y_ref) < ftol
+            gyd = lay.act_to_dev(dev(gy))
+            gxd = torch.full_like(xd, 7.0)
+            hl.conv_dgrad(g, gyd, wd, None, gxd)
+            assert rel_l2(lay.act_from_dev(gxd, Ci), gx_ref) < btol
+            dwd = torch.zeros_like(wd)
+            hl.conv_wgrad(g, xd, gyd, dwd)
+            assert rel_l2(lay.conv_w_from_dev(dwd, Ci, 3), gW_ref) < btol
+    finally:
+        hl.set_tile_override(0)
+
+
 def test_conv_frame_view_and_frame_permutation(hl):
     """x[:, :, t] as the x side (model/updater.py:97) and the (T,N)->(N,T) output permutation of the
     generator's last layer (model/updater.py:102)."""

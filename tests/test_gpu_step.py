@@ -224,3 +224,58 @@ def test_update_core_full_width_one_step(pkg):
     K = 4096 .. 16384 shapes of the VideoDiscriminator.  With ~2e7 activations per iteration some
     pre-activation always lies within rounding of a kink, so gradients get the relaxed bound."""
     _run_steps(pkg, "normal", 6, nf=64, n=2, steps=1, seed=999, min_tight_steps=0)
+
+
+def test_update_core_bf16_mfma_one_step(pkg):
+    """BASELINE configs[2] arithmetic: conv operands rounded to bf16 inside the kernels, fp32 accumulation,
+    parameters / BN statistics / Adam in fp32.  The oracle stays the float64 restatement; tolerances are the
+    bf16 ones of SURVEY 8c (loss abs <= 5e-2, forward rel-L2 <= 2e-2).  Gradients pass through thousands of
+    ReLU decisions that bf16 rounding moves, so they are held to direction (cosine) rather than to digits;
+    the bf16 kernels themselves are pinned digit-for-digit in test_gpu_ops.py."""
+    hl, lay, nets, step = pkg
+    model, dim_zl, nf, n = 'normal', 6, 16, 4
+    rng = np.random.RandomState(4242)
+    gen = _f64(onet.init_generator(rng, dim_zl=dim_zl, n_filters=nf))
+    di = _f64(onet.init_discriminator(rng, 2, 3, 1, nf))
+    dv = _f64(onet.init_discriminator(rng, 3, 3, 1, nf))
+    G = nets.GenNet(dim_zl=dim_zl, n_filters=nf)
+    DI = nets.DisNet(2, 3, 1, nf, use_noise=True)
+    DV = nets.DisNet(3, 3, 1, nf, use_noise=True)
+    ts = step.TrainStep(model, G, DI, DV, precision='bf16')
+    assert G.precision == DI.precision == DV.precision == 'bf16'
+    og, oi, ov = (oupd.new_adam_state(q) for q in (gen, di, dv))
+    for net, p, st in ((G, gen, og), (DI, di, oi), (DV, dv, ov)):
+        net.load_reference_params(p)
+        net.load_adam_state(st)
+    x_real = rng.uniform(-1, 1, (n, 3, 16, 64, 64))
+    t_real = rng.randint(0, 6, n)
+    rnd = oupd.draw_step_randomness(rng, model, n, 3, nf, dim_zl=dim_zl, dtype=F64)
+    ref = oupd.update_core(model, gen, di, dv, og, oi, ov, x_real, t_real, rnd, dim_zl=dim_zl, keep=True)
+    inject = {'t': rnd['t'], 'gen': draw_to_dev(rnd['gen'])}
+    for k in ('noise_i_real', 'noise_v_real', 'noise_i_fake', 'noise_v_fake'):
+        inject[k] = noise_to_dev(lay, rnd[k])
+    out = ts.run(dev(x_real), dev(t_real, torch.int32), inject)
+    losses = ts.losses()
+    report = {}
+    for k, r in (('image_dis/loss', 'loss_dis_i'), ('video_dis/loss', 'loss_dis_v'), ('image_gen/loss', 'loss_gen')):
+        report[k] = abs(losses[k] - ref[r])
+        assert report[k] < 5e-2, (k, losses[k], ref[r])
+    report['x_fake'] = rel_l2(lay.act_from_dev(out['x_fake'], 3), ref['x_fake'][:, :3])
+    assert report['x_fake'] < 2e-2, report
+    assert report['x_fake'] > 1e-5, "bf16 rounding left no trace: the bf16 kernels did not run"
+
+    def cosine(a, b):
+        a = a.detach().cpu().double().numpy().ravel() if isinstance(a, torch.Tensor) else np.asarray(a, np.float64).ravel()
+        b = np.asarray(b, np.float64).ravel()
+        return float(a @ b / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-300))
+
+    for name, net, kind, refg in (('D_I', DI, 'dis', ref['grads_dis_i']), ('D_V', DV, 'dis', ref['grads_dis_v']),
+                                  ('G', G, 'gen', ref['grads_gen'])):
+        got = net.export_reference_grads()
+        for k in refg:
+            if k.endswith('/W'):
+                report[name + '.' + k] = cosine(got[k], refg[k])
+    print('bf16 step report:', {k: round(v, 5) for k, v in report.items()})
+    for k, v in report.items():
+        if k.endswith('/W'):
+            assert v > 0.95, (k, v)

@@ -48,6 +48,7 @@ def main():
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--tile', type=int, default=0)
     ap.add_argument('--only', default='')
+    ap.add_argument('--precision', default='f32', choices=['f32', 'bf16'])
     ap.add_argument('--net', default='', help='restrict to layers whose name starts with this (e.g. D_V)')
     args = ap.parse_args()
     hl.load()
@@ -57,7 +58,7 @@ def main():
     for name, N, T, H, Ci, Co, kt, ci_real in layers(args.batch):
         if args.net and not name.startswith(args.net):
             continue
-        g = hl.make_geom(N, T, H, H, Ci, Co, kt)
+        g = hl.make_geom(N, T, H, H, Ci, Co, kt, precision=args.precision)
         x = torch.randn((N, T, H, H, Ci), device='cuda')
         y = torch.randn((N, g.To, g.Ho, g.Wo, Co), device='cuda')
         w = torch.randn((Co, kt, 4, 4, Ci), device='cuda') * 0.05
