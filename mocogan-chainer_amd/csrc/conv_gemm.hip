@@ -362,9 +362,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(P p) {
             bx = t % gx; by = (t / gx) % gy; bz = t / (gx * gy);
         }
     }
-    const int m0 = bx * BM, n0 = by * BN, z = bz;
-
+    const int m0 = bx * BM, n0 = by * BN;
+#ifdef MCG_PROBE_SAMETILE
+    // diagnostic build (tools/probe_variant.py): every block LOADS tile (0,0,0) -- all operand traffic hits
+    // in L1/L2 -- but keeps its own output rows; the time difference to the real build is what the memory
+    // system costs
+    const int z = 0;
+    p.init(0, 0, tid, 0);
+#else
+    const int z = bz;
     p.init(m0, n0, tid, z);
+#endif
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -386,6 +394,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(P p) {
     while (k0 < kend) {
         MCG_T(ts0);
         // registers -> LDS
+#ifndef MCG_PROBE_NOWRITE      // (MCG_PROBE_*: timing ablations of tools/probe_variant.py; results are garbage)
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             int q = tid + NTHREADS * j;
@@ -397,11 +406,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(P p) {
             *reinterpret_cast<f32x4*>(&Bs[(q / B_C4) * B_LD + (q % B_C4) * 4]) = rb[j];
         }
         __syncthreads();
+#endif
         MCG_T(ts1);
         const int kn = p.next_valid(k0 + BK);
         // prefetch the next live step; past the end the offsets are forced out of range (loads return 0,
         // nothing is consumed), which keeps the loop body free of divergent branches
+#ifndef MCG_PROBE_NOLOADS
         { const int kl = kn < kend ? kn : kend - BK; p.load_a(kl, ra); p.load_b(kl, rb); }
+#endif
         MCG_T(ts2);
 #pragma unroll
         for (int gk = 0; gk < BK / 8; ++gk) {
@@ -435,7 +447,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(P p) {
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
         }
         MCG_T(ts3);
+#ifndef MCG_PROBE_NOBAR2
         __syncthreads();
+#endif
         MCG_T(ts4);
 #ifdef MCG_STAMPS
         acc_w += ts1 - ts0; acc_l += ts2 - ts1; acc_c += ts3 - ts2; acc_b += ts4 - ts3;
@@ -516,9 +530,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(P p) {
         else if (P::ORDER == 1) { bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z; }
         else { bx = t % gx; by = (t / gx) % gy; bz = t / (gx * gy); }
     }
-    const int m0 = bx * BM, n0 = by * BN, z = bz;
-
+    const int m0 = bx * BM, n0 = by * BN;
+#ifdef MCG_PROBE_SAMETILE
+    // diagnostic build (tools/probe_variant.py): every block LOADS tile (0,0,0) -- all operand traffic hits
+    // in L1/L2 -- but keeps its own output rows; the time difference to the real build is what the memory
+    // system costs
+    const int z = 0;
+    p.init(0, 0, tid, 0);
+#else
+    const int z = bz;
     p.init(m0, n0, tid, z);
+#endif
 
     f32x16 acc[TM][TN];
 #pragma unroll

@@ -79,6 +79,29 @@ class _Net:
     # and Adam stay fp32).  BASELINE.json configs[2].
     precision = 'f32'
 
+    # Optional second HIP stream for the weight-gradient GEMMs of the backward pass.  wgrad(l) and dgrad(l)
+    # both only read the layer's output gradient, so they may run side by side: the blocks of one fill the
+    # CUs the other leaves idle in its last, partial round of tiles.  None = everything on the caller's stream.
+    wgrad_stream = None
+
+    def _wgrad(self, geom, x, y, dw):
+        """conv_wgrad on wgrad_stream (after everything queued so far on the current stream)."""
+        ws = self.wgrad_stream
+        if ws is None:
+            hl.conv_wgrad(geom, x, y, dw)
+            return
+        cur = torch.cuda.current_stream()
+        ws.wait_stream(cur)
+        with torch.cuda.stream(ws):
+            hl.conv_wgrad(geom, x, y, dw)
+        for t in (x, y):
+            t.record_stream(ws)            # the caching allocator must not hand the block out before ws is done with it
+
+    def _wgrad_join(self):
+        """the current stream waits for the weight gradients queued on wgrad_stream"""
+        if self.wgrad_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+
     def _alloc(self, specs, device):
         self.device = torch.device(device)
         self.fp = FlatParams(specs, self.device)
@@ -350,8 +373,9 @@ class DisNet(_Net):
                 if l == 1:
                     hl.colsum_acc(m * G, co, g, fp.grad('dc1/b'), self.ws)
                 # dc2..dc4 feed BatchNorm: sum_m gx == 0 exactly (see _Net.BIAS_NOTE), nothing to add
-                hl.conv_wgrad(geom, saved['a'][l], g, fp.grad('dc%d/W' % l))
+                self._wgrad(geom, saved['a'][l], g, fp.grad('dc%d/W' % l))
                 if l == 4 and on_late_bucket is not None:
+                    self._wgrad_join()
                     on_late_bucket()
             if l > 1:
                 ga = torch.empty_like(saved['a'][l])
@@ -360,6 +384,8 @@ class DisNet(_Net):
             elif gx is not None:
                 hl.conv_dgrad(gx_geom if gx_geom is not None else geom, g, fp.param('dc1/W'), None, gx,
                               accumulate=gx_accumulate)
+        if param_grads:
+            self._wgrad_join()
 
 
 # ==========================================================================================
@@ -546,7 +572,7 @@ class GenNet(_Net):
                               fp.grad(name + '/gamma'), fp.grad(name + '/beta'), self.ws)
             if l == 5:
                 hl.colsum_acc(m, ci, g, fp.grad('dc5/b'), self.ws)         # dc1..dc4 feed BatchNorm: exact zero
-            hl.conv_wgrad(geom, g, saved['a'][l], fp.grad('dc%d/W' % l))
+            self._wgrad(geom, g, saved['a'][l], fp.grad('dc%d/W' % l))
             ga = torch.empty_like(saved['a'][l])
             hl.conv_fprop(geom, g, fp.param('dc%d/W' % l), None, ga)
             g = ga
@@ -559,3 +585,4 @@ class GenNet(_Net):
         hl.fc_fprop(frames, k1, self.n_hidden, g.view(frames, k1), fp.param('dc1/W').view(self.n_hidden, k1), None, gz)
         d = saved['draw']
         hl.gru_seq_bwd(n, T, dz, dl, dc, fp.param('g0'), d['e'], d['labels'], saved['gru'], gz, fp.grad('g0'))
+        self._wgrad_join()

@@ -73,7 +73,7 @@ class GradExchange:
 class TrainStep:
     """Holds the three networks, their Adam hyper-parameters and runs update_core on device data."""
 
-    def __init__(self, model, gen, dis_i, dis_v, hyper=None, exchange=None, seed=0, rank=0, precision=None):
+    def __init__(self, model, gen, dis_i, dis_v, hyper=None, exchange=None, seed=0, rank=0, precision=None, overlap=False):
         assert model in ('normal', 'cgan', 'infogan')
         self.model, self.gen, self.dis_i, self.dis_v = model, gen, dis_i, dis_v
         if precision is not None:                                 # 'f32' | 'bf16': MFMA operand type of every conv GEMM
@@ -86,6 +86,21 @@ class TrainStep:
         self.iteration = 0
         self.device = gen.device
         self.loss = torch.zeros(3, device=self.device)            # loss_dis_i, loss_dis_v, loss_gen
+        # overlap: independent work goes to side HIP streams -- the whole ImageDiscriminator update (small
+        # kernels that cannot fill 256 CUs) beside the VideoDiscriminator's, and every weight-gradient GEMM
+        # beside the input-gradient GEMM of the same layer.  Same kernels, same results; only placement in time.
+        self.side = None
+        self._wstreams = None
+        self.set_overlap(overlap)
+
+    def set_overlap(self, on):
+        """Switch the side-stream placement on or off (between iterations)."""
+        if on and self._wstreams is None:
+            self._side = torch.cuda.Stream(device=self.device)
+            self._wstreams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
+        self.side = self._side if on else None
+        for i, net in enumerate((self.gen, self.dis_i, self.dis_v)):
+            net.wgrad_stream = self._wstreams[i] if on else None
 
     # ---- cgan label planes (model/updater.py:65-76) -------------------------------------------------
     def _concat_label_clip(self, x_dev, labels):
@@ -179,23 +194,26 @@ class TrainStep:
 
         # ------------------------------------------------ forward: both discriminators on [real | fake]
         # (model/updater.py:97-98,107-108 as one 2n batch per net; per-call BatchNorm statistics, real first)
-        y_i, s_i = di.forward_groups(n, [dict(first_input=first_real_i, noise=nz('noise_i_real'), rng=rngs(0)),
-                                         dict(first_input=first_fake_i, noise=nz('noise_i_fake'), rng=rngs(3))])
+        cd = di.out_channels
+        ex = self.exchange
+        main = torch.cuda.current_stream()
+        side = self.side if self.side is not None else main
+        side.wait_stream(main)                                        # x_fake is ready
+        # ------------------------------------------------ image_dis_optimizer.update(loss_dis, ...)   :111
+        with torch.cuda.stream(side):
+            y_i, s_i = di.forward_groups(n, [dict(first_input=first_real_i, noise=nz('noise_i_real'), rng=rngs(0)),
+                                             dict(first_input=first_fake_i, noise=nz('noise_i_fake'), rng=rngs(3))])
+            y_real_i, y_fake_i = y_i[:n], y_i[n:]
+            g_i = torch.empty((2 * n, cd), device=self.device)      # [d loss / d logits] of (real | fake)
+            di.zero_grad()
+            hl.loss_dis(n, cd, y_real_i, y_fake_i, t_real, t_fake, False, self.loss[0:1], g_i[:n], g_i[n:])
+            di.backward(s_i, g_i, True)
+            work_i = ex.start(di.fp.g) if ex else None
+        # ------------------------------------------------ video_dis_optimizer.update(loss_dis, ...)   :112
         y_v, s_v = dv.forward_groups(n, [dict(first_input=first_real_v, noise=nz('noise_v_real'), rng=rngs(1)),
                                          dict(first_input=first_fake_v, noise=nz('noise_v_fake'), rng=rngs(4))])
-        y_real_i, y_fake_i, y_real_v, y_fake_v = y_i[:n], y_i[n:], y_v[:n], y_v[n:]
-
-        cd = di.out_channels
-        g_i = torch.empty((2 * n, cd), device=self.device)          # [d loss / d logits] of (real | fake)
+        y_real_v, y_fake_v = y_v[:n], y_v[n:]
         g_v = torch.empty((2 * n, cd), device=self.device)
-        ex = self.exchange
-
-        # ------------------------------------------------ image_dis_optimizer.update(loss_dis, ...)   :111
-        di.zero_grad()
-        hl.loss_dis(n, cd, y_real_i, y_fake_i, t_real, t_fake, False, self.loss[0:1], g_i[:n], g_i[n:])
-        di.backward(s_i, g_i, True)
-        work_i = ex.start(di.fp.g) if ex else None
-        # ------------------------------------------------ video_dis_optimizer.update(loss_dis, ...)   :112
         dv.zero_grad()
         hl.loss_dis(n, cd, y_real_v, y_fake_v, t_real, t_fake, with_ce, self.loss[1:2], g_v[:n], g_v[n:])
         # D_V's gradient is exchanged in two buckets: dc4/W..dc5/b (76 % of the bytes) is final after the
@@ -203,14 +221,16 @@ class TrainStep:
         late = []
         lo, hi = dv.grad_bucket_late()
         dv.backward(s_v, g_v, True, on_late_bucket=(lambda: late.append(ex.start(dv.fp.g[lo:hi]))) if ex else None)
-        if ex:
-            ex.finish(work_i)                                        # D_I's exchange overlapped D_V's backward
-        adam_update(di, self.hyper['image_dis'])
+        with torch.cuda.stream(side):
+            if ex:
+                ex.finish(work_i)                                    # D_I's exchange overlapped D_V's backward
+            adam_update(di, self.hyper['image_dis'])
         if ex:
             rest = [ex.start(dv.fp.g[:lo]), ex.start(dv.fp.g[hi:])]
             for h in late + rest:
                 ex.finish(h)
         adam_update(dv, self.hyper['video_dis'])
+        main.wait_stream(side)                                        # D_I's logits and updated weights (Q5)
         # ------------------------------------------------ image_gen_optimizer.update(loss_gen, ...)   :113
         gen.zero_grad()
         gi, gv = g_i[:n], g_v[:n]                                    # buffers reused: D's backward has consumed them

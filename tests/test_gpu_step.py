@@ -151,7 +151,7 @@ def test_generator_forward_backward(pkg, dim_zl, nf):
 TIGHT_MARGIN = 2e-6     # see oracle.updater.update_core: min |pre-activation| over every ReLU / LeakyReLU decision
 
 
-def _run_steps(pkg, model, dim_zl, nf, n, steps, seed, min_tight_steps=1):
+def _run_steps(pkg, model, dim_zl, nf, n, steps, seed, min_tight_steps=1, overlap=False):
     """Teacher-forced multi-step parity: before every iteration the device state (parameters, Adam
     moments and step counters, BN running statistics) is loaded from the oracle, so each iteration
     is compared on identical inputs and errors cannot compound through Adam's sign-like early steps.
@@ -173,7 +173,7 @@ def _run_steps(pkg, model, dim_zl, nf, n, steps, seed, min_tight_steps=1):
     G = nets.GenNet(dim_zl=dim_zl, n_filters=nf)
     DI = nets.DisNet(2, c_d, out_c, nf, use_noise=True)
     DV = nets.DisNet(3, c_d, out_c, nf, use_noise=True)
-    ts = step.TrainStep(model, G, DI, DV)
+    ts = step.TrainStep(model, G, DI, DV, overlap=overlap)
     og, oi, ov = (oupd.new_adam_state(q) for q in (gen, di, dv))
     tight_steps = 0
     for s in range(steps):
@@ -217,6 +217,13 @@ def _run_steps(pkg, model, dim_zl, nf, n, steps, seed, min_tight_steps=1):
 @pytest.mark.parametrize("model,dim_zl,seed", [("normal", 0, 303), ("normal", 6, 311), ("infogan", 6, 313), ("cgan", 6, 320)])
 def test_update_core_three_steps(pkg, model, dim_zl, seed):
     _run_steps(pkg, model, dim_zl, nf=4, n=2, steps=3, seed=seed)
+
+
+def test_update_core_with_side_streams(pkg):
+    """overlap=True only moves launches onto side HIP streams (D_I's update beside D_V's, wgrad beside dgrad);
+    the same teacher-forced parity must hold."""
+    _run_steps(pkg, "infogan", 6, nf=4, n=2, steps=3, seed=313, overlap=True)
+    _run_steps(pkg, "normal", 6, nf=16, n=3, steps=2, seed=77, min_tight_steps=0, overlap=True)
 
 
 def test_update_core_full_width_one_step(pkg):
