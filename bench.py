@@ -102,6 +102,8 @@ def main():
                     help="MFMA operand type of the conv GEMMs: f32 = BASELINE configs[1] (the headline); "
                          "bf16 = configs[2] (use with --batch 256), fp32 accumulation / parameters / Adam")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--autotune', type=int, default=1,
+                    help='1 (default): the first launch of each conv geometry times the 7 tile candidates once (warm-up)')
     ap.add_argument('--overlap', type=int, default=int(os.environ.get('MCG_OVERLAP', '1')),
                     help='1 (default): the headline pass places the ImageDiscriminator update and the weight-gradient '
                          'GEMMs on side HIP streams; 0: one stream throughout.  The roofline pass is always one-stream.')
@@ -136,6 +138,7 @@ def main():
         dist.init_process_group(os.environ.get('MCG_DIST_BACKEND', 'nccl'), rank=rank, world_size=world)
         exchange = mstep.GradExchange()
     hl.load()
+    hl.set_autotune(bool(args.autotune))
 
     gen, di, dv = mstep.make_models(args.model, num_labels=6, seed=0)         # identical init on every rank
     ts = mstep.TrainStep(args.model, gen, di, dv, exchange=exchange, seed=1234, rank=rank, precision=args.dtype, overlap=False)
@@ -219,6 +222,8 @@ def main():
                                         "overlaps independent kernels on side streams, which stretches individual launches"
                                         if args.overlap else "is one-stream too"),
                          "dv_conv_share_of_step_time": dv_total_ms / (dt_serial_instr / args.steps * 1e3)},
+            "tile_choices": {"%s N=%d T=%d H=%d Ci=%d Co=%d" % (k[0], k[1], k[2], k[3], k[5], k[6]): v
+                             for k, v in sorted(hl.tile_choices().items(), key=str)},
             "losses": losses,
         }
         if world == 1 and not args.no_cpu_baseline:

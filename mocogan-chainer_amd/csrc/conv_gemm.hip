@@ -54,6 +54,7 @@ struct Geom {
     u32 magic_To;      // floor(2^32 / To) + 1:  q / To == umulhi(q, magic_To) for q < 2^32 / To
     u32 magic_N;       // the same for the batch size N
     int prec;          // MCG_PREC_F32 / MCG_PREC_BF16
+    int tile, bk;      // caller's choice (mcg_conv_geom.tile): tile 0 = library heuristic, 1/2/3; bk 0 = heuristic, 32/64
 };
 
 __device__ __forceinline__ long long x_batch_off(const Geom& g, int n) {
@@ -724,6 +725,8 @@ int make_geom(const mcg_conv_geom* c, Geom& g) {
     g.taps = c->kt * 16;
     g.prec = c->precision;
     if (g.prec != MCG_PREC_F32 && g.prec != MCG_PREC_BF16) return MCG_ERR_BAD_ARG;
+    if (c->tile < 0 || c->tile % 100 > 3 || c->tile / 100 > 2) return MCG_ERR_BAD_ARG;
+    g.tile = c->tile % 100; g.bk = (c->tile / 100) * 32;
     g.lgHo = ilog2_exact(g.Ho); g.lgWo = ilog2_exact(g.Wo);
     g.lgCi = ilog2_exact(g.Ci); g.lgCo = ilog2_exact(g.Co);
     if (g.N <= 0 || g.Ci <= 0 || g.Co <= 0) return MCG_ERR_BAD_ARG;
@@ -826,13 +829,14 @@ extern "C" int mcg_conv_fprop(const mcg_conv_geom* c, const float* x, const floa
     long long M = (long long)g.N * g.To * g.Ho * g.Wo;
     // Tile choice (measured on MI355X, tools/bench_layers.py): 128x128 only when there are enough tiles
     // that the last partial round of blocks does not matter, else 128x64, else 64x64 to fill 256 CUs.
-    int t = g_tile_override;
+    int t = g_tile_override ? g_tile_override : g.tile;
+    const int bk = g_tile_override || g_bk_override ? g_bk_override : g.bk;
     const long long mt = (M + 127) / 128;
     if (!t) t = g.Co <= 64 ? 2 : (mt * ((g.Co + 127) / 128) >= 1024 ? 1 : (mt * ((g.Co + 63) / 64) >= 512 ? 2 : 3));
     // 64-deep K-steps halve the per-step overhead (barriers, LDS refill, address math) and pay off when the
     // grid is small (few resident waves to hide it: measured on dc4); big grids prefer the higher occupancy of 32.
     const long long nblk = ((M + (t == 3 ? 63 : 127)) / (t == 3 ? 64 : 128)) * ((g.Co + (t == 1 ? 127 : 63)) / (t == 1 ? 128 : 64));
-    const bool bk64 = (g.taps * g.Ci) % 64 == 0 && (g_bk_override ? g_bk_override == 64 : (nblk < 1024 || g.prec == MCG_PREC_BF16));
+    const bool bk64 = (g.taps * g.Ci) % 64 == 0 && (bk ? bk == 64 : (nblk < 1024 || g.prec == MCG_PREC_BF16));
     MCG_DISPATCH(launch_fprop, t, bk64, g.prec == MCG_PREC_BF16, g, x, w, bias, y, s);
     return launch_status();
 }
@@ -846,7 +850,8 @@ extern "C" int mcg_conv_dgrad(const mcg_conv_geom* c, const float* y, const floa
     if (act != MCG_ACT_NONE && act != MCG_ACT_TANH) return MCG_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     long long M = (long long)g.N * g.Ti * g.Ho * g.Wo;
-    int t = g_tile_override;
+    int t = g_tile_override ? g_tile_override : g.tile;
+    const int bk = g_tile_override || g_bk_override ? g_bk_override : g.bk;
     if (!t && g.Ci == 4 && g.Co == 64 && (g.Wo & 15) == 0) {      // VALU kernel for the padded 3-channel clip
         const int runs = (int)(M / 16);
         const int per_block = (NTHREADS / 64) * C4_RUNS_PER_WAVE;
@@ -861,7 +866,7 @@ extern "C" int mcg_conv_dgrad(const mcg_conv_geom* c, const float* y, const floa
         else t = g.Ci <= 64 ? 2 : (4 * mt * ((g.Ci + 127) / 128) >= 1024 ? 1 : 2);
     }
     const long long nblk = 4 * ((M + (t == 3 ? 63 : 127)) / (t == 3 ? 64 : 128)) * ((g.Ci + (t == 1 ? 127 : 63)) / (t == 1 ? 128 : 64));
-    const bool bk64 = (g.kt * 4 * g.Co) % 64 == 0 && (g_bk_override ? g_bk_override == 64 : (nblk < 1024 || g.prec == MCG_PREC_BF16));
+    const bool bk64 = (g.kt * 4 * g.Co) % 64 == 0 && (bk ? bk == 64 : (nblk < 1024 || g.prec == MCG_PREC_BF16));
     MCG_DISPATCH(launch_dgrad, t, bk64, g.prec == MCG_PREC_BF16, g, y, w, bias, x, act, accumulate, s);
     return launch_status();
 }
@@ -873,9 +878,10 @@ extern "C" int mcg_conv_wgrad(const mcg_conv_geom* c, const float* x, const floa
     if (!x || !dw || !y) return MCG_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     int Kf = g.taps * g.Ci;
-    int t = g_tile_override;
+    int t = g_tile_override ? g_tile_override : g.tile;
+    const int bk = g_tile_override || g_bk_override ? g_bk_override : g.bk;
     if (!t) t = (g.Co <= 64 || Kf <= 64) ? 3 : 1;
-    const bool bk64 = g_bk_override ? g_bk_override == 64 : g.prec == MCG_PREC_BF16;
+    const bool bk64 = bk ? bk == 64 : g.prec == MCG_PREC_BF16;
     MCG_DISPATCH(launch_wgrad, t, bk64, g.prec == MCG_PREC_BF16, g, x, y, dw, s);
     return launch_status();
 }

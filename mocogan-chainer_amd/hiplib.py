@@ -26,6 +26,7 @@ class ConvGeom(C.Structure):
     _fields_ = [("N", C.c_int32), ("Ti", C.c_int32), ("Hi", C.c_int32), ("Wi", C.c_int32), ("Ci", C.c_int32),
                 ("To", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32), ("Co", C.c_int32),
                 ("kt", C.c_int32), ("x_perm_n", C.c_int32), ("precision", C.c_int32),
+                ("tile", C.c_int32), ("reserved_", C.c_int32),
                 ("x_stride0", C.c_int64), ("x_stride1", C.c_int64)]
 
 
@@ -169,21 +170,121 @@ def _launch(kind, fn, *args):
 
 
 # ------------------------------------------------------------------------------------------
-# thin typed wrappers (tensors in, nothing allocated here)
+# per-geometry choice of the GEMM block tile (mcg_conv_geom.tile).  The best of the six candidates
+# depends on how the tile count of a launch divides over the 256 CUs and, for dgrad, on how many blocks
+# skip dead temporal taps -- the library's closed-form heuristic misses by up to 20 % on some layers.
+# With autotune on, the first launch of each (pass, geometry) times every candidate once on scratch
+# tensors and the winner is used from then on.  Off by default (tests, parity runs): bench.py, train.py
+# and generate_samples.py switch it on.
 # ------------------------------------------------------------------------------------------
+TILE_CANDIDATES = (0, 101, 102, 103, 201, 202, 203)
+_autotune = False
+_tile_cache = {}
+
+
+def set_autotune(on):
+    global _autotune
+    _autotune = bool(on)
+
+
+def tile_choices():
+    """{(pass, geometry...): tile code} chosen so far (for logs / DESIGN.md tables)."""
+    return dict(_tile_cache)
+
+
+def _geom_key(kind, g, extra=()):
+    return (kind, g.N, g.Ti, g.Hi, g.Wi, g.Ci, g.Co, g.kt, g.x_perm_n, g.precision) + tuple(extra)
+
+
+def _tuned(kind, g, extra, out_side, run_on):
+    """Returns a copy of g with .tile set to the fastest candidate.  run_on(geom, scratch) launches the pass
+    with its OUTPUT directed to `scratch` (extent of the geometry's `out_side`), so tuning never touches
+    the caller's output or accumulators."""
+    if not _autotune or g.tile:
+        return g
+    key = _geom_key(kind, g, extra)
+    code = _tile_cache.get(key)
+    if code is None:
+        global _timing
+        saved, _timing = _timing, None                      # tuning launches are not part of any measurement
+        cur = torch.cuda.current_stream()
+        best, code = None, 0
+        gg = ConvGeom.from_buffer_copy(g)
+        scratch = _scratch_like(g, out_side)
+
+        def run(geom):
+            run_on(geom, scratch)
+        try:
+            for cand in TILE_CANDIDATES:
+                gg.tile = cand
+                try:
+                    run(gg)                                 # warm-up (and rejects impossible candidates)
+                except McgError:
+                    continue
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+                run(gg)
+                run(gg)
+                e1.record(cur)
+                e1.synchronize()
+                ms = e0.elapsed_time(e1)
+                if best is None or ms < best:
+                    best, code = ms, cand
+        finally:
+            _timing = saved
+        _tile_cache[key] = code
+    if not code:
+        return g
+    gg = ConvGeom.from_buffer_copy(g)
+    gg.tile = code
+    return gg
+
+
+def _scratch_like(g, which):
+    """dense scratch tensors with the extents of the geometry's x / y / w sides"""
+    if which == 'x':
+        if g.x_perm_n:
+            n = (g.x_perm_n - 1) * g.x_stride0 + (g.N // g.x_perm_n - 1) * g.x_stride1 + g.Ti * g.Hi * g.Wi * g.Ci
+        else:
+            n = (g.N - 1) * g.x_stride0 + g.Ti * g.Hi * g.Wi * g.Ci
+        return torch.zeros(n, device='cuda')
+    if which == 'y':
+        return torch.zeros(g.N * g.To * g.Ho * g.Wo * g.Co, device='cuda')
+    return torch.zeros(g.Co * g.kt * 16 * g.Ci, device='cuda')
+
+
+# ------------------------------------------------------------------------------------------
+# thin typed wrappers (tensors in; nothing allocated here except the one-off tuning scratch)
+# ------------------------------------------------------------------------------------------
+def _fprop(g, x, w, bias, y):
+    _check(load().mcg_conv_fprop(C.byref(g), _p(x), _p(_dense(w)), _p(bias), _p(_dense(y)), _stream()), "mcg_conv_fprop")
+
+
+def _dgrad(g, y, w, bias, x, act, accumulate):
+    _check(load().mcg_conv_dgrad(C.byref(g), _p(_dense(y)), _p(_dense(w)), _p(bias), _p(x), act, int(accumulate), _stream()),
+           "mcg_conv_dgrad")
+
+
+def _wgrad(g, x, y, dw):
+    _check(load().mcg_conv_wgrad(C.byref(g), _p(x), _p(_dense(y)), _p(_dense(dw)), _stream()), "mcg_conv_wgrad")
+
+
 def conv_fprop(g, x, w, bias, y):
-    _check(_launch("fprop", load().mcg_conv_fprop, C.byref(g), _p(x), _p(_dense(w)), _p(bias), _p(_dense(y)), _stream()),
-           "mcg_conv_fprop")
+    if _autotune and not g.tile:
+        g = _tuned("fprop", g, (), 'y', lambda gg, out: _fprop(gg, x, w, bias, out))   # x, w are only read
+    _launch("fprop", _fprop, g, x, w, bias, y)
 
 
 def conv_dgrad(g, y, w, bias, x, act=ACT_NONE, accumulate=False):
-    _check(_launch("dgrad", load().mcg_conv_dgrad, C.byref(g), _p(_dense(y)), _p(_dense(w)), _p(bias), _p(x), act,
-                   int(accumulate), _stream()), "mcg_conv_dgrad")
+    if _autotune and not g.tile:
+        g = _tuned("dgrad", g, (act, int(accumulate)), 'x', lambda gg, out: _dgrad(gg, y, w, bias, out, act, accumulate))
+    _launch("dgrad", _dgrad, g, y, w, bias, x, act, accumulate)
 
 
 def conv_wgrad(g, x, y, dw):
-    _check(_launch("wgrad", load().mcg_conv_wgrad, C.byref(g), _p(x), _p(_dense(y)), _p(_dense(dw)), _stream()),
-           "mcg_conv_wgrad")
+    if _autotune and not g.tile:
+        g = _tuned("wgrad", g, (), 'w', lambda gg, out: _wgrad(gg, x, y, out))
+    _launch("wgrad", _wgrad, g, x, y, dw)
 
 
 def fc_fprop(M, K, Co, x, w, bias, y):

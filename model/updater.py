@@ -26,13 +26,18 @@ class Updater:
         seed = kwargs.pop('seed', 0)
         exchange = kwargs.pop('exchange', None)
         rank = kwargs.pop('rank', 0)
+        # placement / arithmetic options of the MI355X path (no reference counterpart): side HIP streams,
+        # MFMA operand type of the conv GEMMs ('f32' | 'bf16')
+        overlap = kwargs.pop('overlap', False)
+        precision = kwargs.pop('precision', None)
         if kwargs:
             raise TypeError('unexpected arguments: %s' % sorted(kwargs))
         self.iteration = 0
         self.observation = {}
         hyper = {k: self._optimizers[k].hyper() for k in ('image_gen', 'image_dis', 'video_dis')}
         self._step = _step.TrainStep(self.model, self.image_gen.impl, self.image_dis.impl, self.video_dis.impl,
-                                     hyper=hyper, exchange=exchange, seed=seed, rank=rank)
+                                     hyper=hyper, exchange=exchange, seed=seed, rank=rank, overlap=overlap,
+                                     precision=precision)
 
     # ---- StandardUpdater surface -------------------------------------------------------------------
     def get_optimizer(self, name):

@@ -141,6 +141,50 @@ def test_conv_three_passes_bf16_mfma(hl, case, tile):
         hl.set_tile_override(0)
 
 
+def test_conv_tile_field_and_autotune(hl):
+    """mcg_conv_geom.tile selects the block tile per call (no process-global state), bad codes are rejected,
+    and the autotuner (times the candidates on scratch, keeps the winner) leaves results and accumulators
+    untouched."""
+    N, Ti, H, Ci, Co, kt = 2, 6, 16, 16, 96, 4
+    rng = np.random.RandomState(5)
+    x = rng.uniform(-1, 1, (N, Ci, Ti, H, H))
+    W = rng.randn(Co, Ci, kt, 4, 4) * 0.1
+    y_ref = F.conv3d_fwd(x, W, None, (1, 2, 2), (0, 1, 1))
+    gy = rng.randn(*y_ref.shape)
+    gx_ref, gW_ref, _ = F.conv3d_bwd(x, W, gy, (1, 2, 2), (0, 1, 1))
+    lay = L()
+    xd, wd, gyd = lay.act_to_dev(dev(x)), lay.conv_w_to_dev(dev(W)), lay.act_to_dev(dev(gy))
+    for code in (1, 2, 3, 101, 203):
+        g = hl.make_geom(N, Ti, H, H, Ci, Co, kt)
+        g.tile = code
+        yd = torch.empty((N, g.To, g.Ho, g.Wo, Co), device="cuda")
+        hl.conv_fprop(g, xd, wd, None, yd)
+        assert rel_l2(lay.act_from_dev(yd, Co), y_ref) < FWD_TOL, code
+    g = hl.make_geom(N, Ti, H, H, Ci, Co, kt)
+    g.tile = 7
+    with pytest.raises(hl.McgError):
+        hl.conv_fprop(g, xd, wd, None, yd)
+
+    hl.set_autotune(True)
+    try:
+        g = hl.make_geom(N, Ti, H, H, Ci, Co, kt)
+        before = len(hl.tile_choices())
+        for rep in range(2):                                      # second round: cache hits
+            yd = torch.empty((N, g.To, g.Ho, g.Wo, Co), device="cuda")
+            hl.conv_fprop(g, xd, wd, None, yd)
+            assert rel_l2(lay.act_from_dev(yd, Co), y_ref) < FWD_TOL
+            gxd = torch.ones_like(xd)
+            hl.conv_dgrad(g, gyd, wd, None, gxd, accumulate=True)  # tuning must not accumulate into gxd
+            assert rel_l2(lay.act_from_dev(gxd, Ci), gx_ref + 1.0) < BWD_TOL
+            dwd = torch.zeros_like(wd)
+            hl.conv_wgrad(g, xd, gyd, dwd)                        # ... nor into dwd
+            assert rel_l2(lay.conv_w_from_dev(dwd, Ci, 3), gW_ref) < BWD_TOL
+        assert len(hl.tile_choices()) == before + 3
+        assert g.tile == 0                                        # the caller's geometry is not modified
+    finally:
+        hl.set_autotune(False)
+
+
 def test_conv_frame_view_and_frame_permutation(hl):
     """x[:, :, t] as the x side (model/updater.py:97) and the (T,N)->(N,T) output permutation of the
     generator's last layer (model/updater.py:102)."""

@@ -44,6 +44,11 @@ def parse_args(argv=None):
     p.add_argument('--resume', '-r', default='', help='Resume the training from snapshot')
     p.add_argument('--synthetic_size', type=int, default=256, help='clips in the synthetic dataset')
     p.add_argument('--seed', type=int, default=0)
+    # MI355X-path options (no counterpart in the reference's train.py)
+    p.add_argument('--mfma', choices=['f32', 'bf16'], default='f32',
+                   help="operand type of the convolution GEMMs (accumulation, parameters, Adam: always fp32)")
+    p.add_argument('--overlap', type=int, default=1, help="side HIP streams for independent kernels")
+    p.add_argument('--autotune', type=int, default=1, help="time the GEMM tile candidates once per layer geometry")
     return p.parse_args(argv)
 
 
@@ -60,6 +65,8 @@ def main(argv=None):
         raise SystemExit('train.py needs an MI355X: the HIP path has no CPU fallback (the reference\'s --gpu -1 CPU mode '
                          'is what oracle/ restates for tests)')
     torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', max(args.gpu, 0))))
+    import mocogan_chainer_amd.hiplib as hl
+    hl.set_autotune(bool(args.autotune))
     exchange = None
     if world > 1:
         import torch.distributed as dist
@@ -104,7 +111,8 @@ def main(argv=None):
     writer = T.make_summary_writer(Path('runs') / args.save_name) if rank == 0 else T.NullWriter()
     updater = Updater(model=args.model, models=(image_gen, image_dis, video_dis), video_length=video_length,
                       img_size=size, channel=channel, dim_zl=num_labels, iterator=train_iter,
-                      tensorboard_writer=writer, optimizer=opts, device=args.gpu, seed=args.seed, exchange=exchange, rank=rank)
+                      tensorboard_writer=writer, optimizer=opts, device=args.gpu, seed=args.seed, exchange=exchange, rank=rank,
+                      overlap=bool(args.overlap), precision=args.mfma)
 
     save_path = Path('result') / args.save_name
     trainer = T.Trainer(updater, (args.max_epoch, 'epoch'), out=save_path)
