@@ -195,7 +195,17 @@ def main():
             n_l, ms = dv_ms[k]
             kern[k] = {"launches_per_step": n_l / args.steps, "ms_per_step": ms / args.steps,
                        "tflops": fl / (ms / args.steps * 1e-3) / 1e12 if ms > 0 else 0.0}
-        all_conv_ms = sum(v[1] for v in timing.values()) / args.steps
+        all_conv_ms = sum(v[1] for k, v in timing.items() if ' N=' not in k) / args.steps
+        by_layer = {}
+        for k, (n_l, ms) in sorted(timing.items()):
+            if ' N=' not in k:
+                continue
+            f = dict(kv.split('=') for kv in k.split()[1:])
+            N_, T_, H_, Ci_, Co_ = (int(f[x]) for x in ('N', 'T', 'H', 'Ci', 'Co'))
+            kt_ = 4 if T_ > 1 else 1
+            gflop = 2.0 * N_ * (T_ - kt_ + 1) * (H_ // 2) ** 2 * kt_ * 16 * min(Ci_, 3 if Ci_ == 4 else Ci_) * Co_ / 1e9
+            by_layer[k] = {"launches_per_step": n_l / args.steps, "ms_per_launch": ms / n_l,
+                           "tflops": gflop * n_l / ms if ms > 0 else 0.0}
         traffic, traffic_src = pmc_traffic(B) if args.dtype == 'f32' else (None, None)
         peak = PEAK_FP32_MFMA_TFLOPS if args.dtype == 'f32' else PEAK_BF16_MFMA_TFLOPS
         cfg_name = "configs[2]" if (args.dtype == 'bf16' and B == 256) else "configs[1]" if (args.dtype == 'f32' and B == 32) else \
@@ -215,7 +225,7 @@ def main():
                                    % ("gemm_kernel" if args.dtype == 'f32' else "gemm_bf16_kernel") +
                                    "dc1..dc4, all launches of one step",
                          "algorithmic_gflop_per_step": tot / 1e9, "kernel_ms_per_step": dv_total_ms, "by_pass": kern,
-                         "all_conv_kernels_ms_per_step": all_conv_ms,
+                         "all_conv_kernels_ms_per_step": all_conv_ms, "by_layer": by_layer,
                          "measured": "HIP events around every launch of the family during %d one-stream iterations "
                                      "(%.3f ms/step with the event records); the headline pass %s"
                                      % (args.steps, dt_serial_instr / args.steps * 1e3,

@@ -215,6 +215,9 @@ struct DgradP {
     // first K-step >= k0 that has a valid temporal tap for some row of this block
     __device__ int next_valid(int k0) const {
         if (g.kt == 1) return k0;
+#ifdef MCG_PROBE_NOSKIP
+        return k0;
+#endif
         while (k0 < K) {
             int q0, q1, r_;
             divmod_c(k0, g.Co, g.lgCo, q0, r_);

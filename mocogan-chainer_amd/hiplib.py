@@ -166,6 +166,8 @@ def _launch(kind, fn, *args):
     r = fn(*args)
     e1.record()
     _timing.setdefault(_tag + "." + kind, []).append((e0, e1))
+    g = args[0]                                             # per-geometry detail: "<tag>.<pass> N T H Ci Co"
+    _timing.setdefault("%s.%s N=%d T=%d H=%d Ci=%d Co=%d" % (_tag, kind, g.N, g.Ti, g.Hi, g.Ci, g.Co), []).append((e0, e1))
     return r
 
 
