@@ -623,93 +623,109 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(P p) {
 // ------------------------------------------------------------------------------------------
 // dgrad for Ci == 4, Co == 64 (the 3-channel clip padded to 4: D's first layer backward and G's
 // last layer forward).  N = 4 output columns would waste 15/16 of a 64-wide MFMA tile, so this case
-// runs on the VALU with fully coalesced loads: a wave works on a run of 16 consecutive output pixels
-// of one parity class; lane = (pixel group pg = lane>>4, channel quad c4 = lane&15) so that the 16
-// lanes of a group read one y pixel's 64 channels as one 256-byte row.  Each lane accumulates, for its
-// 4 pixels (pg*4 + p), the partial sums over its 4 input channels; a 4-step reduce-scatter over the 16
-// lanes leaves lane c4 with output (p = c4>>2, ci = c4&3).  The class's KT*4 taps x 64 x 4 weights sit
-// in LDS as [tap][j][c4] float4 (conflict-free ds_read_b128).
+// runs on the VALU with fully coalesced loads.  A wave works on a run of 16 consecutive HALF-resolution
+// positions (t, n, h2, w0..w0+15) and produces all four output-parity classes of them, i.e. a 2 x 32
+// patch of output pixels: the classes read the same 3 x 3 neighbourhood of y, so each y value is loaded
+// once per temporal tap instead of once per (class, tap) -- the first version of this kernel was bound
+// by L1 load bandwidth (3.5x more loads).  lane = (position group pg = lane>>4, channel quad c4 =
+// lane&15): the 16 lanes of a group read one y pixel's 64 channels as one 256-byte row; a lane keeps
+// the 6 pixels w2-1 .. w2+4 of its 4 positions in registers and accumulates, for 4 classes x 4
+// positions, the partial sums over its 4 y-channels; a 4-step reduce-scatter over the 16 lanes leaves
+// lane c4 with the 4 channels of output pixel (class = c4>>2, position = c4&3): one 16-byte store.
+// All KT*16 taps x 64 x 4 weights sit in LDS as [tap][j][c4] float4 (conflict-free ds_read_b128).
 // ------------------------------------------------------------------------------------------
-constexpr int C4_RUNS_PER_WAVE = 8;
+constexpr int C4_RUNS_PER_WAVE = 4;
 
 template <int KT>
 __global__ __launch_bounds__(NTHREADS) void dgrad_c4_kernel(Geom g, const float* __restrict__ y, const float* __restrict__ w,
                                                             const float* __restrict__ bias, float* __restrict__ x, int act,
-                                                            int accumulate, int runs /* 16-pixel runs per class */) {
-    __shared__ f32x4 wl[KT * 4 * 64];
-    const int z = blockIdx.y, ph = z >> 1, pw = z & 1;
+                                                            int accumulate, int runs /* 16-position runs */) {
+    extern __shared__ f32x4 wl[];                                     // KT*16*64 float4
     constexpr int Co = 64;
-    for (int i = threadIdx.x; i < KT * 4 * Co; i += NTHREADS) {
-        int ts = i >> 6, r = i & 63, jj = r >> 4, c4 = r & 15;        // LDS index (ts*4 + jj)*16 + c4 <- co = c4*4 + jj
-        int a = ts >> 2, bh = (ts >> 1) & 1, bw = ts & 1;
-        int tap = a * 16 + ((1 - ph) + 2 * bh) * 4 + (1 - pw) + 2 * bw;
+    for (int i = threadIdx.x; i < KT * 16 * Co; i += NTHREADS) {
+        int tap = i >> 6, r = i & 63, jj = r >> 4, c4 = r & 15;       // LDS index (tap*4 + jj)*16 + c4 <- co = c4*4 + jj
         wl[i] = *reinterpret_cast<const f32x4*>(w + ((long long)(c4 * 4 + jj) * g.taps + tap) * 4);
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pg = lane >> 4, c4 = lane & 15;
-    const int lgR = g.lgWo - 4;                                       // runs per output row = Wo / 16
+    const int lgR = g.lgWo - 4;                                       // runs per half-res row = Wo / 16
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    const float bv = bias ? bias[c4 & 3] : 0.f;
+    f32x4 bv = zero;
+    if (bias) bv = *reinterpret_cast<const f32x4*>(bias);
     for (int it = 0; it < C4_RUNS_PER_WAVE; ++it) {
         const int run = (blockIdx.x * (NTHREADS / 64) + wave) * C4_RUNS_PER_WAVE + it;     // wave-uniform
         if (run >= runs) break;
         const int w0 = (run & ((1 << lgR) - 1)) << 4, h2 = (run >> lgR) & (g.Ho - 1), q = run >> (lgR + g.lgHo);
         const int t = div_N(g, q), n = q - t * g.N;
         const float* yb = y + (long long)n * g.To * g.Ho * g.Wo * Co + c4 * 4;
-        f32x4 acc[4] = {zero, zero, zero, zero};
+        const int wl0 = w0 + pg * 4 - 1;                              // y column of register slot e = 0
+        f32x4 acc[4][4];                                              // [class ph*2+pw][position p] over ci
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) acc[c][pp] = zero;
 #pragma unroll
         for (int a = 0; a < KT; ++a) {
             const int to = t - a;
             if ((unsigned)to >= (unsigned)g.To) continue;             // wave-uniform
 #pragma unroll
-            for (int bh = 0; bh < 2; ++bh) {
-                const int ho = h2 + ph - bh;
+            for (int dh = -1; dh <= 1; ++dh) {
+                const int ho = h2 + dh;
                 if ((unsigned)ho >= (unsigned)g.Ho) continue;         // wave-uniform
                 const float* yr = yb + (long long)(to * g.Ho + ho) * g.Wo * Co;
+                f32x4 yv[6];
 #pragma unroll
-                for (int bw = 0; bw < 2; ++bw) {
-                    const int wob = w0 + pg * 4 + pw - bw;
-                    f32x4 yv[4];
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) {
-                        const int wo = wob + p;
-                        const bool v = (unsigned)wo < (unsigned)g.Wo;
-                        f32x4 t4 = *reinterpret_cast<const f32x4*>(yr + (long long)(v ? wo : 0) * Co);
-                        yv[p] = v ? t4 : zero;
-                    }
-                    const f32x4* wp = wl + (a * 4 + bh * 2 + bw) * 64 + c4;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const f32x4 wv = wp[j * 16];
-#pragma unroll
-                        for (int p = 0; p < 4; ++p) acc[p] += yv[p][j] * wv;
-                    }
+                for (int e = 0; e < 6; ++e) {
+                    const int wo = wl0 + e;
+                    const bool v = (unsigned)wo < (unsigned)g.Wo;     // only e = 0 / e = 5 can fail (image edge)
+                    f32x4 t4 = *reinterpret_cast<const f32x4*>(yr + (long long)(v ? wo : 0) * Co);
+                    yv[e] = v ? t4 : zero;
                 }
+#pragma unroll
+                for (int dw = -1; dw <= 1; ++dw)
+#pragma unroll
+                    for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+                        for (int pw = 0; pw < 2; ++pw) {
+                            const int bh = ph - dh, bw = pw - dw;     // compile-time after unrolling
+                            if (bh < 0 || bh > 1 || bw < 0 || bw > 1) continue;
+                            const int tap = a * 16 + ((1 - ph) + 2 * bh) * 4 + (1 - pw) + 2 * bw;
+                            const f32x4* wp = wl + tap * 64 + c4;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const f32x4 wv = wp[j * 16];
+#pragma unroll
+                                for (int pp = 0; pp < 4; ++pp) acc[ph * 2 + pw][pp] += yv[pp + dw + 1][j] * wv;
+                            }
+                        }
             }
         }
-        // reduce-scatter over the 16 lanes of the group: value index v = p*4 + ci ends on lane c4 == v
-        float v16[16];
+        // reduce-scatter over the 16 lanes of the group: value index v = (class, position, ci); lane bits
+        // 3..0 pick value bits 5..2, so lane c4 ends with v = c4*4 + ci
+        float v64[64];
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v16[p * 4 + c] = acc[p][c];
+            for (int pp = 0; pp < 4; ++pp)
 #pragma unroll
-        for (int half = 8; half >= 1; half >>= 1) {
-            const bool up = (c4 & half) != 0;
+                for (int ci = 0; ci < 4; ++ci) v64[(c * 4 + pp) * 4 + ci] = acc[c][pp][ci];
+#pragma unroll
+        for (int half = 32, lb = 8; half >= 4; half >>= 1, lb >>= 1) {
+            const bool up = (c4 & lb) != 0;
 #pragma unroll
             for (int i2 = 0; i2 < half; ++i2) {
-                const float lo = v16[i2], hi = v16[i2 + half];
+                const float lo = v64[i2], hi = v64[i2 + half];
                 const float send = up ? lo : hi, keep = up ? hi : lo;
-                v16[i2] = keep + __shfl_xor(send, half, 64);
+                v64[i2] = keep + __shfl_xor(send, lb, 64);
             }
         }
-        float r = v16[0] + bv;
-        if (act == MCG_ACT_TANH) r = tanhf(r);
-        const int p = c4 >> 2, ci = c4 & 3;
-        const long long o = x_batch_off(g, n) + ((long long)(t * g.Hi + 2 * h2 + ph) * g.Wi + 2 * (w0 + pg * 4 + p) + pw) * 4 + ci;
-        if (accumulate) r += x[o];
-        x[o] = r;
+        f32x4 r = {v64[0] + bv[0], v64[1] + bv[1], v64[2] + bv[2], v64[3] + bv[3]};
+        if (act == MCG_ACT_TANH) { r[0] = tanhf(r[0]); r[1] = tanhf(r[1]); r[2] = tanhf(r[2]); r[3] = tanhf(r[3]); }
+        const int cls = c4 >> 2, pp = c4 & 3, ph = cls >> 1, pw = cls & 1;
+        f32x4* o = reinterpret_cast<f32x4*>(x + x_batch_off(g, n) + ((long long)(t * g.Hi + 2 * h2 + ph) * g.Wi + 2 * (w0 + pg * 4 + pp) + pw) * 4);
+        if (accumulate) r += *o;
+        *o = r;
     }
 }
 
@@ -856,11 +872,17 @@ extern "C" int mcg_conv_dgrad(const mcg_conv_geom* c, const float* y, const floa
     int t = g_tile_override ? g_tile_override : g.tile;
     const int bk = g_tile_override || g_bk_override ? g_bk_override : g.bk;
     if (!t && g.Ci == 4 && g.Co == 64 && (g.Wo & 15) == 0) {      // VALU kernel for the padded 3-channel clip
-        const int runs = (int)(M / 16);
+        const int runs = (int)(M / 16);                          // M = N*Ti*Ho*Wo half-resolution positions
         const int per_block = (NTHREADS / 64) * C4_RUNS_PER_WAVE;
-        dim3 grid((runs + per_block - 1) / per_block, 4, 1);
-        if (g.kt == 4) hipLaunchKernelGGL(dgrad_c4_kernel<4>, grid, dim3(NTHREADS), 0, s, g, y, w, bias, x, act, accumulate, runs);
-        else hipLaunchKernelGGL(dgrad_c4_kernel<1>, grid, dim3(NTHREADS), 0, s, g, y, w, bias, x, act, accumulate, runs);
+        dim3 grid((runs + per_block - 1) / per_block, 1, 1);
+        const size_t lds = (size_t)g.kt * 16 * 64 * sizeof(f32x4);
+        if (g.kt == 4) {
+            static bool attr_set = false;                        // 64 KiB of dynamic LDS needs the opt-in once
+            if (!attr_set) { (void)hipFuncSetAttribute((const void*)dgrad_c4_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+            hipLaunchKernelGGL(dgrad_c4_kernel<4>, grid, dim3(NTHREADS), lds, s, g, y, w, bias, x, act, accumulate, runs);
+        } else {
+            hipLaunchKernelGGL(dgrad_c4_kernel<1>, grid, dim3(NTHREADS), lds, s, g, y, w, bias, x, act, accumulate, runs);
+        }
         return launch_status();
     }
     if (!t) {
