@@ -194,6 +194,20 @@ def tile_choices():
     return dict(_tile_cache)
 
 
+def save_tile_choices(path):
+    """Persist the tuned choices (JSON) so that a later process -- or a profiler pass that must not see the
+    tuning launches -- can start from them."""
+    import json
+    with open(path, 'w') as f:
+        json.dump([[list(k), v] for k, v in _tile_cache.items()], f)
+
+
+def load_tile_choices(path):
+    import json
+    for k, v in json.load(open(path)):
+        _tile_cache[tuple(k)] = int(v)
+
+
 def _geom_key(kind, g, extra=()):
     return (kind, g.N, g.Ti, g.Hi, g.Wi, g.Ci, g.Co, g.kt, g.x_perm_n, g.precision) + tuple(extra)
 

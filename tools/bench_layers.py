@@ -50,8 +50,14 @@ def main():
     ap.add_argument('--only', default='')
     ap.add_argument('--precision', default='f32', choices=['f32', 'bf16'])
     ap.add_argument('--net', default='', help='restrict to layers whose name starts with this (e.g. D_V)')
+    ap.add_argument('--autotune', action='store_true', help='time the tile candidates per geometry first')
+    ap.add_argument('--save-tiles', default='', help='write the tuned choices to this JSON file')
+    ap.add_argument('--tiles', default='', help='use the tile choices of this JSON file (no tuning launches)')
     args = ap.parse_args()
     hl.load()
+    if args.tiles:
+        hl.load_tile_choices(args.tiles)
+    hl.set_autotune(args.autotune or bool(args.tiles))
     hl.set_tile_override(args.tile)
     print('%-10s %-6s %10s %10s %8s' % ('layer', 'pass', 'ms', 'TFLOP/s', 'GFLOP'))
     tot = {}
@@ -73,6 +79,8 @@ def main():
             tot[p] = tot.get(p, 0) + ms
             print('%-10s %-6s %10.3f %10.1f %8.1f' % (name, p, ms, flops / ms / 1e9, flops / 1e9))
     print('totals (ms):', {k: round(v, 3) for k, v in tot.items()})
+    if args.save_tiles:
+        hl.save_tile_choices(args.save_tiles)
 
 
 if __name__ == '__main__':
