@@ -215,7 +215,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic" + (" (single-device rehearsal)" if rehearsal else ""),
             "config": {"workload": "MUG-shape synthetic (B,3,16,64,64) U(-1,1), one update_core iteration per step "
-                                   "(BASELINE.json %s)" % cfg_name, "model": "mocogan-" + args.model,
+                                   "(BASELINE.json %s)" % cfg_name, "variant": args.model,
                        "per_gpu_batch": B, "global_batch": B * world, "n_filters": 64, "dim_zl": 6,
                        "parallelism": "dp%d" % world, "side_streams": bool(args.overlap)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
