@@ -55,6 +55,7 @@ struct Geom {
     u32 magic_N;       // the same for the batch size N
     int prec;          // MCG_PREC_F32 / MCG_PREC_BF16
     int tile, bk;      // caller's choice (mcg_conv_geom.tile): tile 0 = library heuristic, 1/2/3; bk 0 = heuristic, 32/64
+    int ksplit;        // fprop / dgrad: number of K splits (1, 2 or 4) from mcg_conv_geom.tile / 1000
 };
 
 __device__ __forceinline__ long long x_batch_off(const Geom& g, int n) {
@@ -97,6 +98,9 @@ struct FpropP {
     Geom g;
     const float* x; const float* w; const float* bias; float* y;
     int M, K;
+    int kchunk;         // K range of one blockIdx.z (multiple of BK; == K without split-K)
+    int zz;             // this block's K split; with more than one split the partial tiles are added atomically
+                        // onto a zeroed y (mcg_conv_fprop clears it) and split 0 contributes the bias
     // per-thread state
     __amdgpu_buffer_rsrc_t xr, wr;
     int abase[NA];      // BYTE offset of the window origin (may be negative: padding)
@@ -104,9 +108,10 @@ struct FpropP {
     int ak;             // this thread's k offset inside a K-step (c4*4)
     u32 bbase[NB];      // byte offset of the filter row, OOB for rows beyond Co
 
-    __device__ void init(int m0, int n0, int tid, int /*z*/) {
+    __device__ void init(int m0, int n0, int tid, int z) {
         constexpr int KC4 = BK / 4, RSTEP = NTHREADS / KC4;        // float4 slots per tile row, rows per pass
         xr = make_srd(x, g.x_bytes); wr = make_srd(w, g.w_bytes);
+        zz = z;
         ak = (tid % KC4) * 4;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
@@ -131,8 +136,8 @@ struct FpropP {
             bbase[j] = co < g.Co ? (u32)(co * K + ak) * 4u : OOB;
         }
     }
-    __device__ int k_begin(int) const { return 0; }
-    __device__ int k_end(int) const { return K; }
+    __device__ int k_begin(int z) const { return z * kchunk; }
+    __device__ int k_end(int z) const { int e = (z + 1) * kchunk; return e < K ? e : K; }
     __device__ int next_valid(int k0) const { return k0; }
     __device__ void load_a(int k0, f32x4 (&r)[NA]) const {
         int k = k0 + ak;
@@ -148,7 +153,9 @@ struct FpropP {
         for (int j = 0; j < NB; ++j) r[j] = bload(wr, bbase[j] + (u32)k0 * 4u);
     }
     __device__ void store(int m, int n, float v) const {
-        if (m < M && n < g.Co) y[(long long)m * g.Co + n] = v + (bias ? bias[n] : 0.f);
+        if (m >= M || n >= g.Co) return;
+        if (kchunk >= K) y[(long long)m * g.Co + n] = v + (bias ? bias[n] : 0.f);
+        else atomicAdd(y + (long long)m * g.Co + n, v + (bias && zz == 0 ? bias[n] : 0.f));
     }
 };
 
@@ -162,6 +169,7 @@ struct DgradP {
     const float* y; const float* w; const float* bias; float* x;
     int M, K, act, accumulate;   // M = N*Ti*Ho*Wo pixels of ONE parity class; K = kt*4*Co
     int ph, pw;
+    int kchunk, zsplit;          // split-K as in FpropP: blockIdx.z = split * 4 + parity class
     __amdgpu_buffer_rsrc_t yr, wr;
     int abase[NA];      // BYTE offset of y[n][t][h2+ph][w2+pw][0]  (tap offsets are subtracted)
     u32 amask[NA];      // bit a*4+bh*2+bw set <=> that sub-filter tap of the row reads inside y
@@ -176,7 +184,7 @@ struct DgradP {
     __device__ void init(int m0, int n0, int tid, int z) {
         constexpr int KC4 = BK / 4, RSTEP = NTHREADS / KC4;
         yr = make_srd(y, g.y_bytes); wr = make_srd(w, g.w_bytes);
-        ph = z >> 1; pw = z & 1;
+        ph = (z >> 1) & 1; pw = z & 1; zsplit = z >> 2;
         ak = (tid % KC4) * 4;
         {
             int mlast = m0 + BM - 1 < M ? m0 + BM - 1 : M - 1;
@@ -210,8 +218,8 @@ struct DgradP {
             bfast[j] = bok ? (u32)(bkrow[j] * g.taps * g.Ci + bci) * 4u : OOB;
         }
     }
-    __device__ int k_begin(int) const { return 0; }
-    __device__ int k_end(int) const { return K; }
+    __device__ int k_begin(int z) const { return (z >> 2) * kchunk; }
+    __device__ int k_end(int z) const { int e = ((z >> 2) + 1) * kchunk; return e < K ? e : K; }
     // first K-step >= k0 that has a valid temporal tap for some row of this block
     __device__ int next_valid(int k0) const {
         if (g.kt == 1) return k0;
@@ -262,6 +270,10 @@ struct DgradP {
         int w2 = m & (g.Wo - 1), h2 = (m >> g.lgWo) & (g.Ho - 1), q = m >> (g.lgWo + g.lgHo);
         int t = div_N(g, q), nb = q - t * g.N;
         long long o = x_batch_off(g, nb) + ((long long)(t * g.Hi + 2 * h2 + ph) * g.Wi + 2 * w2 + pw) * g.Ci + n;
+        if (kchunk < K) {                          // split-K (act == NONE; x cleared by the host unless accumulating)
+            atomicAdd(x + o, v + (bias && zsplit == 0 ? bias[n] : 0.f));
+            return;
+        }
         if (bias) v += bias[n];
         if (act == MCG_ACT_TANH) v = tanhf(v);
         if (accumulate) v += x[o];
@@ -356,8 +368,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(P p) {
         const int L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
         const int xcd = L & 7, q = nwg >> 3, r = nwg & 7;
         const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
-        if (P::ORDER == 0) {            // fprop: N tile fastest, then M tile (same activations, next filters)
-            by = t % gy; bx = t / gy; bz = 0;
+        if (P::ORDER == 0) {            // fprop: N tile fastest, then M tile (same activations, next filters), then K split
+            by = t % gy; bx = (t / gy) % gx; bz = t / (gy * gx);
         } else if (P::ORDER == 1) {     // dgrad: dispatch order.  Its rows are time-major and blocks near the temporal
             // boundary skip most K-steps, so a contiguous range per XCD would give the XCDs unequal work
             // (measured: dc2 0.81 -> 0.97 ms with a contiguous mapping); round-robin interleaves light and heavy.
@@ -530,7 +542,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(P p) {
         const int L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
         const int xcd = L & 7, q = nwg >> 3, r = nwg & 7;
         const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
-        if (P::ORDER == 0) { by = t % gy; bx = t / gy; bz = 0; }
+        if (P::ORDER == 0) { by = t % gy; bx = (t / gy) % gx; bz = t / (gy * gx); }
         else if (P::ORDER == 1) { bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z; }
         else { bx = t % gx; by = (t / gx) % gy; bz = t / (gx * gy); }
     }
@@ -744,8 +756,8 @@ int make_geom(const mcg_conv_geom* c, Geom& g) {
     g.taps = c->kt * 16;
     g.prec = c->precision;
     if (g.prec != MCG_PREC_F32 && g.prec != MCG_PREC_BF16) return MCG_ERR_BAD_ARG;
-    if (c->tile < 0 || c->tile % 100 > 3 || c->tile / 100 > 2) return MCG_ERR_BAD_ARG;
-    g.tile = c->tile % 100; g.bk = (c->tile / 100) * 32;
+    if (c->tile < 0 || c->tile % 100 > 3 || (c->tile / 100) % 10 > 2 || c->tile / 1000 > 2) return MCG_ERR_BAD_ARG;
+    g.tile = c->tile % 100; g.bk = ((c->tile / 100) % 10) * 32; g.ksplit = 1 << (c->tile / 1000);
     g.lgHo = ilog2_exact(g.Ho); g.lgWo = ilog2_exact(g.Wo);
     g.lgCi = ilog2_exact(g.Ci); g.lgCo = ilog2_exact(g.Co);
     if (g.N <= 0 || g.Ci <= 0 || g.Co <= 0) return MCG_ERR_BAD_ARG;
@@ -775,7 +787,15 @@ void launch_fprop(const Geom& g, const float* x, const float* w, const float* bi
     FpropP<BM, BN, BK> p;
     p.g = g; p.x = x; p.w = w; p.bias = bias; p.y = y;
     p.M = g.N * g.To * g.Ho * g.Wo; p.K = g.taps * g.Ci;
-    dim3 grid((p.M + BM - 1) / BM, (g.Co + BN - 1) / BN, 1);
+    int splits = g.ksplit;
+    const int ksteps = (p.K + BK - 1) / BK;
+    if (splits > ksteps / 8) splits = ksteps / 8;               // keep >= 8 K-steps per block
+    if (splits < 1) splits = 1;
+    p.kchunk = ((ksteps + splits - 1) / splits) * BK;
+    splits = (p.K + p.kchunk - 1) / p.kchunk;
+    if (splits == 1) p.kchunk = p.K > 0 ? ((p.K + BK - 1) / BK) * BK : BK;
+    else (void)hipMemsetAsync(y, 0, (size_t)p.M * g.Co * sizeof(float), s);
+    dim3 grid((p.M + BM - 1) / BM, (g.Co + BN - 1) / BN, splits);
     if (BF) hipLaunchKernelGGL((gemm_bf16_kernel<FpropP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
     else hipLaunchKernelGGL((gemm_kernel<FpropP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
 }
@@ -785,7 +805,16 @@ void launch_dgrad(const Geom& g, const float* y, const float* w, const float* bi
     DgradP<BM, BN, BK> p;
     p.g = g; p.y = y; p.w = w; p.bias = bias; p.x = x; p.act = act; p.accumulate = acc;
     p.M = g.N * g.Ti * g.Ho * g.Wo; p.K = g.kt * 4 * g.Co;
-    dim3 grid((p.M + BM - 1) / BM, (g.Ci + BN - 1) / BN, 4);
+    const long long frame = (long long)g.Ti * g.Hi * g.Wi * g.Ci;
+    const bool dense_x = !g.perm_n && g.xs0 == frame;
+    int splits = (act == MCG_ACT_NONE && (acc || dense_x)) ? g.ksplit : 1;
+    const int ksteps = (p.K + BK - 1) / BK;
+    if (splits > ksteps / 8) splits = ksteps / 8;
+    if (splits < 1) splits = 1;
+    p.kchunk = ((ksteps + splits - 1) / splits) * BK;
+    splits = (p.K + p.kchunk - 1) / p.kchunk;
+    if (splits > 1 && !acc) (void)hipMemsetAsync(x, 0, (size_t)g.N * frame * sizeof(float), s);
+    dim3 grid((p.M + BM - 1) / BM, (g.Ci + BN - 1) / BN, 4 * splits);
     if (BF) hipLaunchKernelGGL((gemm_bf16_kernel<DgradP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
     else hipLaunchKernelGGL((gemm_kernel<DgradP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
 }

@@ -180,6 +180,7 @@ def _launch(kind, fn, *args):
 # and generate_samples.py switch it on.
 # ------------------------------------------------------------------------------------------
 TILE_CANDIDATES = (0, 101, 102, 103, 201, 202, 203)
+FPROP_SPLIT_CANDIDATES = (1103, 1203, 1202, 2103, 2203, 2202)     # 2- / 4-way split-K: only when few tiles (see _tuned)
 _autotune = False
 _tile_cache = {}
 
@@ -231,7 +232,11 @@ def _tuned(kind, g, extra, out_side, run_on):
         def run(geom):
             run_on(geom, scratch)
         try:
-            for cand in TILE_CANDIDATES:
+            cands = TILE_CANDIDATES
+            out_elems = g.N * g.To * g.Ho * g.Wo * g.Co if kind == "fprop" else g.N * g.Ti * g.Hi * g.Wi * g.Ci
+            if kind in ("fprop", "dgrad") and g.Ci > 4 and out_elems <= (1 << 23):
+                cands = cands + FPROP_SPLIT_CANDIDATES          # <= 1024 tiles of 64x64: K splits can fill the CUs
+            for cand in cands:
                 gg.tile = cand
                 try:
                     run(gg)                                 # warm-up (and rejects impossible candidates)

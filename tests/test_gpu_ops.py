@@ -154,12 +154,21 @@ def test_conv_tile_field_and_autotune(hl):
     gx_ref, gW_ref, _ = F.conv3d_bwd(x, W, gy, (1, 2, 2), (0, 1, 1))
     lay = L()
     xd, wd, gyd = lay.act_to_dev(dev(x)), lay.conv_w_to_dev(dev(W)), lay.act_to_dev(dev(gy))
-    for code in (1, 2, 3, 101, 203):
+    for code in (1, 2, 3, 101, 203, 1103, 2203, 1202, 2001):       # 1xxx / 2xxx: 2- / 4-way split-K in fprop
         g = hl.make_geom(N, Ti, H, H, Ci, Co, kt)
         g.tile = code
-        yd = torch.empty((N, g.To, g.Ho, g.Wo, Co), device="cuda")
-        hl.conv_fprop(g, xd, wd, None, yd)
-        assert rel_l2(lay.act_from_dev(yd, Co), y_ref) < FWD_TOL, code
+        yd = torch.full((N, g.To, g.Ho, g.Wo, Co), 3.0, device="cuda")          # split-K must clear y itself
+        bd = dev(rng.randn(Co))
+        hl.conv_fprop(g, xd, wd, bd, yd)
+        assert rel_l2(lay.act_from_dev(yd, Co), y_ref + bd.cpu().double().numpy().reshape(1, Co, 1, 1, 1)) < FWD_TOL, code
+    for code in (1203, 2103, 2202):                                  # split-K in dgrad: plain and accumulating
+        g = hl.make_geom(N, Ti, H, H, Ci, Co, kt)
+        g.tile = code
+        gxd = torch.full_like(xd, 5.0)
+        hl.conv_dgrad(g, gyd, wd, None, gxd)                         # must clear x itself
+        assert rel_l2(lay.act_from_dev(gxd, Ci), gx_ref) < BWD_TOL, code
+        hl.conv_dgrad(g, gyd, wd, None, gxd, accumulate=True)
+        assert rel_l2(lay.act_from_dev(gxd, Ci), 2 * gx_ref) < BWD_TOL, code
     g = hl.make_geom(N, Ti, H, H, Ci, Co, kt)
     g.tile = 7
     with pytest.raises(hl.McgError):
