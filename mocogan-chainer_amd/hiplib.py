@@ -234,7 +234,7 @@ def _tuned(kind, g, extra, out_side, run_on):
         try:
             cands = TILE_CANDIDATES
             out_elems = g.N * g.To * g.Ho * g.Wo * g.Co if kind == "fprop" else g.N * g.Ti * g.Hi * g.Wi * g.Ci
-            if kind in ("fprop", "dgrad") and g.Ci > 4 and out_elems <= (1 << 23):
+            if kind in ("fprop", "dgrad") and g.Ci > 4 and out_elems <= (1 << (23 if kind == "fprop" else 25)):
                 cands = cands + FPROP_SPLIT_CANDIDATES          # <= 1024 tiles of 64x64: K splits can fill the CUs
             for cand in cands:
                 gg.tile = cand
