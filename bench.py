@@ -104,6 +104,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--autotune', type=int, default=1,
                     help='1 (default): the first launch of each conv geometry times the 7 tile candidates once (warm-up)')
+    ap.add_argument('--tiles', default='', help='JSON of tile choices to start from (e.g. for a profiler pass without tuning launches)')
+    ap.add_argument('--save-tiles', default='', help='write the tile choices of this run to this JSON file')
     ap.add_argument('--overlap', type=int, default=int(os.environ.get('MCG_OVERLAP', '1')),
                     help='1 (default): the headline pass places the ImageDiscriminator update and the weight-gradient '
                          'GEMMs on side HIP streams; 0: one stream throughout.  The roofline pass is always one-stream.')
@@ -139,6 +141,8 @@ def main():
         exchange = mstep.GradExchange()
     hl.load()
     hl.set_autotune(bool(args.autotune))
+    if args.tiles:
+        hl.load_tile_choices(args.tiles)
 
     gen, di, dv = mstep.make_models(args.model, num_labels=6, seed=0)         # identical init on every rank
     ts = mstep.TrainStep(args.model, gen, di, dv, exchange=exchange, seed=1234, rank=rank, precision=args.dtype, overlap=False)
@@ -183,6 +187,8 @@ def main():
     dt_best = float(tmax)
     losses = ts.losses()
 
+    if rank == 0 and args.save_tiles:
+        hl.save_tile_choices(args.save_tiles)
     if rank == 0:
         ms_per_step = dt_best / args.steps * 1e3
         value = B * world * args.steps / dt_best
