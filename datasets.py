@@ -17,13 +17,37 @@ def _frame_number(name):
     return int(_FRAME.search(str(name)).group(1))
 
 
-def read_video(paths):
+def read_video(paths, dtype=np.float32):
     from PIL import Image
     frames = []
     for p in paths:
         with Image.open(p) as f:
-            frames.append(np.asarray(f, dtype=np.float32))
-    return np.asarray(frames, dtype=np.float32)
+            frames.append(np.asarray(f, dtype=dtype))
+    return np.asarray(frames, dtype=dtype)
+
+
+def load_examples(dataset, indices, raw):
+    """Worker entry point of trainer.PrefetchIterator (this module imports neither torch nor the HIP library,
+    so spawned worker processes stay light).  raw=True returns the decoded uint8 frames (T,H,W,C) -- a quarter
+    of the bytes; normalisation and the (C,T,H,W) transpose then happen on the GPU."""
+    if raw:
+        out = [dataset.get_example_raw(int(i)) for i in indices]
+    else:
+        out = [dataset.get_example(int(i)) for i in indices]
+    return np.stack([o[0] for o in out]), [o[1] for o in out]
+
+
+_WORKER = {'seed': 0, 'dataset': None}
+
+
+def worker_init(seed, dataset):
+    """initializer of the PrefetchIterator's worker processes: the dataset travels once, not per task"""
+    _WORKER['seed'], _WORKER['dataset'] = seed, dataset
+
+
+def worker_load(indices, raw, batch_no, chunk_no):
+    np.random.seed((int(_WORKER['seed']) * 1000003 + batch_no * 131 + chunk_no) % (2 ** 32))
+    return load_examples(_WORKER['dataset'], indices, raw)
 
 
 class _FrameDirDataset:
@@ -35,7 +59,7 @@ class _FrameDirDataset:
     def __getitem__(self, i):
         return self.get_example(i)
 
-    def _load(self, frame_paths, extract_speed=None):
+    def _load(self, frame_paths, extract_speed=None, raw=False):
         n, T = len(frame_paths), self.video_length
         if n < T:
             raise ValueError('invalid video length: {} < {}'.format(n, T))
@@ -48,9 +72,11 @@ class _FrameDirDataset:
             gap = n - T
             start = 0 if gap == 0 else np.random.randint(0, gap, 1)[0]
             idx = np.arange(start, start + T)
-        video = read_video(frame_paths[idx])
+        video = read_video(frame_paths[idx], np.uint8 if raw else np.float32)
         if video.ndim != 4:
             raise ValueError('invalid video shape: {}'.format(video.shape))
+        if raw:
+            return video                                              # (T,H,W,C) uint8
         video = (video - 128.) / 128.
         return video.astype(np.float32).transpose(3, 0, 1, 2)         # (C,T,H,W)
 
@@ -68,10 +94,13 @@ class MugDataset(_FrameDirDataset):
                 if vp.is_dir() and len(list(vp.glob("*.jpg"))) >= video_length:
                     self.videos.append((vp, MUG_CATEGORIES[cat.name]))
 
-    def get_example(self, i):
+    def get_example(self, i, raw=False):
         vp, categ = self.videos[i]
         paths = np.array(sorted(glob.glob(os.path.join(vp, '*.jpg')), key=_frame_number))
-        return self._load(paths, self.extract_speed), categ
+        return self._load(paths, self.extract_speed, raw), categ
+
+    def get_example_raw(self, i):
+        return self.get_example(i, raw=True)
 
 
 class MovingMnistDataset(_FrameDirDataset):
@@ -92,9 +121,12 @@ class MovingMnistDataset(_FrameDirDataset):
             for j, img in enumerate(video):
                 Image.fromarray(img).save(path / "{:02d}.jpg".format(j))
 
-    def get_example(self, i):
+    def get_example(self, i, raw=False):
         paths = np.array(sorted(self.videos[i].glob("*.jpg"), key=_frame_number))
-        return self._load(paths), None
+        return self._load(paths, raw=raw), None
+
+    def get_example_raw(self, i):
+        return self.get_example(i, raw=True)
 
 
 class SyntheticDataset:

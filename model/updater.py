@@ -120,10 +120,14 @@ class Updater:
 
     # ---- one iteration ---------------------------------------------------------------------------
     def update_core(self):
-        batch = self.get_iterator('main').next()
-        videos = np.stack([b[0] for b in batch]).astype(np.float32)                  # concat_examples
-        labels = [b[1] for b in batch]
-        x_real = torch.as_tensor(videos).to(self._step.device, non_blocking=True)
+        it = self.get_iterator('main')
+        if hasattr(it, 'next_device_batch'):                                         # prefetching loader: uint8 from
+            x_real, labels = it.next_device_batch(self._step.device)                 # pinned memory, normalised on the GPU
+        else:
+            batch = it.next()
+            videos = np.stack([b[0] for b in batch]).astype(np.float32)              # concat_examples
+            labels = [b[1] for b in batch]
+            x_real = torch.as_tensor(videos).to(self._step.device, non_blocking=True)
         t_real = None if labels[0] is None else torch.as_tensor(np.asarray(labels, dtype=np.int32)).to(self._step.device)
         self._step.run(x_real, t_real)
         if self.is_new_epoch:

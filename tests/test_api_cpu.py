@@ -67,6 +67,58 @@ def test_serial_iterator_epochs_and_batches():
     assert flags == [(0, False), (0, False), (1, True), (1, False), (2, True)]
 
 
+def _fake_frame_tree(root, videos=5, frames=20):
+    from PIL import Image
+    rng = np.random.RandomState(1)
+    for v in range(videos):
+        d = root / ("anger", "happiness")[v % 2] / ("%03d" % v)
+        d.mkdir(parents=True)
+        for f in range(frames):
+            Image.fromarray(rng.randint(0, 255, (64, 64, 3)).astype(np.uint8)).save(d / ("%03d.jpg" % f))
+
+
+def test_prefetch_iterator_keeps_serial_order_and_epoch_bookkeeping(tmp_path):
+    """PrefetchIterator (worker processes decode ahead) must show exactly SerialIterator's sample order, wrap-around
+    batches and epoch / is_new_epoch / epoch_detail for the same NumPy seed; the uint8 'raw' transport must
+    reproduce the float path bit for bit."""
+    from mocogan_chainer_amd.trainer import SerialIterator, PrefetchIterator
+    from datasets import SyntheticDataset, MugDataset
+    ds = SyntheticDataset(10, num_labels=6)
+    np.random.seed(7)
+    a = SerialIterator(ds, 4)
+    ref = []
+    for _ in range(7):
+        b = a.next()
+        ref.append(([x[1] for x in b], float(np.sum([x[0][0, 0, 0, 0] for x in b])), a.epoch, a.is_new_epoch, a.epoch_detail))
+    np.random.seed(7)
+    p = PrefetchIterator(ds, 4, n_workers=2, prefetch=3, chunk=2)
+    try:
+        for r in ref:
+            b = p.next()
+            assert ([x[1] for x in b], float(np.sum([x[0][0, 0, 0, 0] for x in b])), p.epoch, p.is_new_epoch, p.epoch_detail) == r
+    finally:
+        p.close()
+    # frame directories: raw (uint8 through the pipes) == float path, shapes and range as the reference's
+    _fake_frame_tree(tmp_path / "mug")
+    mug = MugDataset(tmp_path / "mug")
+    assert len(mug) == 5 and mug.num_labels == 2
+    np.random.seed(3)
+    v_f, l_f = mug.get_example(2)
+    np.random.seed(3)
+    v_r, l_r = mug.get_example_raw(2)
+    assert v_r.dtype == np.uint8 and v_r.shape == (16, 64, 64, 3) and l_f == l_r
+    assert np.array_equal(((v_r.astype(np.float32) - 128.) / 128.).transpose(3, 0, 1, 2), v_f)
+    p = PrefetchIterator(mug, 3, n_workers=2, prefetch=2, chunk=2, shuffle=False)
+    try:
+        for _ in range(3):
+            b = p.next()
+            assert len(b) == 3 and b[0][0].shape == (3, 16, 64, 64) and b[0][0].dtype == np.float32
+            assert -1 <= b[0][0].min() and b[0][0].max() < 1
+        assert (p.epoch, p.is_new_epoch) == (1, False)          # 5 videos, batches of 3: the 2nd batch wrapped
+    finally:
+        p.close()
+
+
 def test_grid_and_sequence_helpers():
     from util import to_grid, to_sequence
     v = np.arange(2 * 3 * 1 * 2 * 2, dtype=np.uint8).reshape(2, 3, 1, 2, 2)

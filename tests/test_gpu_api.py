@@ -155,3 +155,39 @@ def test_train_and_generate_entry_points(tmp_path, monkeypatch):
     assert len(frames) == 16
     from PIL import Image
     assert Image.open(frames[0]).size == (128, 128)
+
+
+def test_prefetching_loader_feeds_the_updater(tmp_path, monkeypatch):
+    """--loader_workers: worker processes decode uint8 frames, the batch is copied from pinned memory on a side
+    stream and normalised / transposed on the GPU; the device batch equals the reference-style float batch, and
+    train.py runs with it end to end on a MUG-shaped JPEG tree."""
+    from PIL import Image
+    from datasets import MugDataset
+    from mocogan_chainer_amd import trainer as T
+    import train
+    rng = np.random.RandomState(2)
+    for v in range(6):
+        d = tmp_path / 'mug' / ('anger', 'disgust', 'happiness', 'fear', 'sadness', 'surprise')[v] / ('%03d' % v)
+        d.mkdir(parents=True)
+        for f in range(16):                                          # exactly 16 frames: no random crop offset
+            Image.fromarray(rng.randint(0, 255, (64, 64, 3)).astype(np.uint8)).save(d / ('%03d.jpg' % f))
+    ds = MugDataset(tmp_path / 'mug')
+    assert len(ds) == 6 and ds.num_labels == 6
+    ser = T.SerialIterator(ds, 4, shuffle=False)
+    pre = T.PrefetchIterator(ds, 4, shuffle=False, n_workers=2, prefetch=2, chunk=2)
+    try:
+        for _ in range(3):
+            b = ser.next()
+            x_ref = np.stack([e[0] for e in b])
+            x_dev, labels = pre.next_device_batch(torch.device('cuda'))
+            torch.cuda.synchronize()
+            assert x_dev.shape == (4, 3, 16, 64, 64) and x_dev.dtype == torch.float32 and x_dev.is_contiguous()
+            assert np.array_equal(x_dev.cpu().numpy(), x_ref) and labels == [e[1] for e in b]
+            assert (pre.epoch, pre.is_new_epoch) == (ser.epoch, ser.is_new_epoch)
+    finally:
+        pre.close()
+    monkeypatch.chdir(tmp_path)
+    tr = train.main(['--dataset_type', 'mug', '--dataset', str(tmp_path / 'mug'), '--batchsize', '3', '--max_epoch', '2',
+                     '--n_filters_gen', '8', '--save_name', 'pf', '--loader_workers', '2', '--snapshot_interval', '5'])
+    assert tr.updater.iteration == 4 and tr.updater.epoch == 2
+    tr.updater.get_iterator('main').close()

@@ -49,6 +49,9 @@ def parse_args(argv=None):
                    help="operand type of the convolution GEMMs (accumulation, parameters, Adam: always fp32)")
     p.add_argument('--overlap', type=int, default=1, help="side HIP streams for independent kernels")
     p.add_argument('--autotune', type=int, default=1, help="time the GEMM tile candidates once per layer geometry")
+    p.add_argument('--loader_workers', type=int, default=0,
+                   help="0: the reference's serial in-process loading (SerialIterator); N > 0: N worker processes decode the "
+                        "next batches while the GPU trains (PrefetchIterator)")
     return p.parse_args(argv)
 
 
@@ -97,7 +100,10 @@ def main(argv=None):
     image_dis = ImageDiscriminator(c_d, out_d, nf, use_noise, noise_sigma)
     video_dis = VideoDiscriminator(c_d, out_d, nf, use_noise, noise_sigma)
     np.random.seed(args.seed + 1 + rank)                         # data order / sub-sequence offsets differ per rank
-    train_iter = T.SerialIterator(train_dataset, args.batchsize)
+    if args.loader_workers > 0:
+        train_iter = T.PrefetchIterator(train_dataset, args.batchsize, n_workers=args.loader_workers, seed=args.seed + rank)
+    else:
+        train_iter = T.SerialIterator(train_dataset, args.batchsize)
 
     def make_optimizer(model, alpha=1e-3, beta1=0.9, beta2=0.999):
         optimizer = T.Adam(alpha=alpha, beta1=beta1)              # beta2 is not forwarded (train.py:94)
