@@ -15,20 +15,10 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _setup(nf=4, n=2, seed=5):
-    from oracle import net as onet, updater as oupd
-    rng = np.random.RandomState(seed)
-    f64 = lambda p: {k: (v.astype(np.float64) if v.dtype.kind == 'f' else v) for k, v in p.items()}
-    nets = [f64(onet.init_generator(rng, n_filters=nf)), f64(onet.init_discriminator(rng, 2, 3, 1, nf)),
-            f64(onet.init_discriminator(rng, 3, 3, 1, nf))]
-    shards = []
-    t = int(rng.randint(0, 16))
-    for r in range(2):
-        x = rng.uniform(-1, 1, (n, 3, 16, 64, 64))
-        rnd = oupd.draw_step_randomness(rng, 'normal', n, 3, nf, dtype=np.float64)
-        rnd['t'] = t                                        # one frame index for all ranks (Q7)
-        shards.append((x, rnd))
-    return nets, shards
+def _setup():
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import dp_common
+    return dp_common.setup()
 
 
 def _flatten(d):
@@ -85,41 +75,10 @@ def test_two_rank_gradient_averaging_matches_the_sharded_oracle():
     assert np.array_equal(res[0][5], res[1][5])
     assert res[0][4] != res[1][4]                                # different shards -> different losses
 
-    # single-process emulation: per-shard gradients averaged by hand
-    (gen, di, dv), shards = _setup()
-    import copy
-    reps = [copy.deepcopy((gen, di, dv)) for _ in range(2)]
-    opts = [[oupd.new_adam_state(p) for p in rep] for rep in reps]
-    store = {}
-
-    class Rendezvous(Exception):
-        pass
-    # run both shards phase by phase: collect each shard's gradient for a phase, average, continue.
-    # (update_core is re-run per phase with the averaged gradients of the earlier phases injected)
-    avg = {}
-
-    def make_reduce(r):
-        def reduce(name, grads):
-            if name in avg:
-                for k in grads:
-                    grads[k][...] = avg[name][k]
-            else:
-                store.setdefault(name, {})[r] = {k: v.copy() for k, v in grads.items()}
-                raise Rendezvous()
-        return reduce
-    for phase in ('image_dis', 'video_dis', 'image_gen', None):
-        finals = []
-        for r in range(2):
-            g_, i_, v_ = copy.deepcopy((gen, di, dv))
-            st = [oupd.new_adam_state(p) for p in (g_, i_, v_)]
-            try:
-                oupd.update_core('normal', g_, i_, v_, st[0], st[1], st[2], shards[r][0], None, shards[r][1], reduce=make_reduce(r))
-                finals.append((g_, i_, v_))
-            except Rendezvous:
-                pass
-        if phase is not None:
-            avg[phase] = {k: 0.5 * (store[phase][0][k] + store[phase][1][k]) for k in store[phase][0]}
-    ref_gen, ref_di, ref_dv = finals[0]
+    # single-process emulation: per-shard gradients averaged by hand (tests/dp_common.py)
+    import dp_common
+    nets, shards = _setup()
+    ref_gen, ref_di, ref_dv = dp_common.emulate(nets, shards)
     for k in res[0][1]:
         assert np.allclose(res[0][1][k], ref_gen[k], rtol=1e-12, atol=1e-15), k
     assert np.allclose(res[0][2], ref_di['dc2/W'], rtol=1e-12, atol=1e-15)
