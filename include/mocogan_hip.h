@@ -112,7 +112,9 @@ int mcg_fc_wgrad(int M, int K, int Co, const float* x, const float* y, float* dw
 /* L.BatchNormalization (model/net.py:50-53,139-141,180-182; Chainer decay 0.9, eps 2e-5).
  * y is [M][C].  stats is a caller buffer of 4*C floats: mean, inv_std, scale = gamma*inv_std,
  * shift = beta - mean*scale (kept for the backward pass).  avg_mean/avg_var (may be NULL) get
- * Chainer's running update.  workspace: mcg_bn_workspace_bytes(M, C). */
+ * Chainer's running update.  workspace: mcg_bn_workspace_bytes(M, C).
+ * The column reductions (here, in mcg_bn_act_bwd and mcg_colsum_acc) support C = 4 * 2^k, k <= 8 -- every width
+ * a power-of-two n_filters produces; other multiples of 4 return MCG_ERR_UNSUPPORTED. */
 int64_t mcg_bn_workspace_bytes(int64_t M, int C);
 int mcg_bn_stats(int64_t M, int C, const float* y, const float* gamma, const float* beta,
                  float* stats, float* avg_mean, float* avg_var, float eps, float decay,

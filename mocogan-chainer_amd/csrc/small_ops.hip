@@ -627,7 +627,10 @@ __global__ __launch_bounds__(NT) void randn_kernel(long long n, float sigma, uin
     }
 }
 
-bool bad_c(int C) { return C <= 0 || (C & 3) || (C >> 2) > NT || (NT % (C >> 2)) != 0; }
+bool bad_c(int C) { return C <= 0 || (C & 3); }
+// the column-reduction kernels give each thread one channel quad and stride the rows by NT / (C/4):
+// C must be 4 * 2^k, k <= 8 (every width the reference can produce from a power-of-two n_filters)
+bool unsupported_c(int C) { return (C >> 2) > NT || (NT % (C >> 2)) != 0; }
 
 }  // namespace
 
@@ -641,6 +644,7 @@ extern "C" int mcg_bn_stats(int64_t M, int C, const float* y, const float* gamma
                             float* avg_mean, float* avg_var, float eps, float decay, void* workspace, void* stream) {
     if (!y || !gamma || !beta || !stats || !workspace || M <= 0 || bad_c(C)) return MCG_ERR_BAD_ARG;
     if ((avg_mean == nullptr) != (avg_var == nullptr)) return MCG_ERR_BAD_ARG;
+    if (unsupported_c(C)) return MCG_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     PartPlan pl = plan_partial(M, C);
     float* part = (float*)workspace;
@@ -671,6 +675,7 @@ extern "C" int mcg_bn_act_bwd(int64_t M, int C, const float* g_out, const float*
     float* coef = nullptr;
     if (stats) {
         if (!gamma || !workspace || bad_c(C)) return MCG_ERR_BAD_ARG;
+        if (unsupported_c(C)) return MCG_ERR_UNSUPPORTED;
         PartPlan pl = plan_partial(M, C);
         float* part = (float*)workspace;
         coef = part + (long long)MAX_PART * 2 * C;
@@ -684,6 +689,7 @@ extern "C" int mcg_bn_act_bwd(int64_t M, int C, const float* g_out, const float*
 
 extern "C" int mcg_colsum_acc(int64_t M, int C, const float* g, float* db, void* workspace, void* stream) {
     if (!g || !db || !workspace || M <= 0 || bad_c(C)) return MCG_ERR_BAD_ARG;
+    if (unsupported_c(C)) return MCG_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     PartPlan pl = plan_partial(M, C);
     float* part = (float*)workspace;
