@@ -1,0 +1,79 @@
+"""Size-independent properties at the FULL sizes of BASELINE configs[1] (batch 32, n_filters 64), where the
+float64 oracle is too slow to run: the three conv passes of every layer must be mutually adjoint,
+    <fprop(x, W), gy>  ==  <x, dgrad(gy, W)>  ==  <W, wgrad(x, gy)>,
+and linear; with the tuned tiles (incl. split-K) and with the bf16 MFMA mode.  A Philox noise tensor of the
+largest activation must have the moments of sigma * N(0,1)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _layers(batch):
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import bench_layers
+    return bench_layers.layers(batch)
+
+
+def _dot(a, b):
+    return float(torch.dot(a.reshape(-1).double(), b.reshape(-1).double()))
+
+
+@pytest.mark.parametrize("precision,tol", [("f32", 2e-5), ("bf16", 2e-2)])
+def test_conv_passes_are_adjoint_and_linear_at_full_size(precision, tol):
+    import mocogan_chainer_amd.hiplib as hl
+    hl.load()
+    hl.set_autotune(True)
+    gen = torch.Generator(device='cuda')
+    gen.manual_seed(5)
+    try:
+        for name, N, T, H, Ci, Co, kt, ci_real in _layers(32):
+            g = hl.make_geom(N, T, H, H, Ci, Co, kt, precision=precision)
+            x = torch.randn((N, T, H, H, Ci), device='cuda', generator=gen)
+            if Ci == 4:
+                x[..., 3] = 0                                       # padded channel
+            w = torch.randn((Co, kt, 4, 4, Ci), device='cuda', generator=gen) * 0.05
+            if Ci == 4:
+                w[..., 3] = 0
+            gy = torch.randn((N, g.To, g.Ho, g.Wo, Co), device='cuda', generator=gen)
+            y = torch.empty_like(gy)
+            hl.conv_fprop(g, x, w, None, y)
+            gx = torch.empty_like(x)
+            hl.conv_dgrad(g, gy, w, None, gx)
+            gw = torch.zeros_like(w)
+            hl.conv_wgrad(g, x, gy, gw)
+            a, b, c = _dot(y, gy), _dot(x, gx), _dot(w, gw)
+            scale = float(torch.linalg.vector_norm(y.double()) * torch.linalg.vector_norm(gy.double()))
+            assert abs(a - b) < tol * scale and abs(a - c) < tol * scale, (name, precision, a, b, c, scale)
+            # linearity of fprop in x (same W): fprop(2 x1 - 3 x2) == 2 fprop(x1) - 3 fprop(x2)
+            x2 = torch.randn_like(x)
+            if Ci == 4:
+                x2[..., 3] = 0
+            y2, y3 = torch.empty_like(y), torch.empty_like(y)
+            hl.conv_fprop(g, x2, w, None, y2)
+            hl.conv_fprop(g, 2 * x - 3 * x2, w, None, y3)
+            err = float(torch.linalg.vector_norm((y3 - (2 * y - 3 * y2)).double()) / torch.linalg.vector_norm(y3.double()))
+            assert err < (5e-6 if precision == "f32" else 2e-2), (name, err)
+    finally:
+        hl.set_autotune(False)
+
+
+def test_philox_noise_moments_at_full_size():
+    import mocogan_chainer_amd.hiplib as hl
+    hl.load()
+    n = 32 * 13 * 32 * 32 * 64                                      # D_V's largest noisy activation at batch 32
+    out = torch.empty(n, device='cuda')
+    hl.randn(out, 0.2, 1234, 77)
+    d = out.double()
+    m, v = float(d.mean()), float(d.var())
+    k = float(((d - m) ** 4).mean() / v ** 2)
+    assert abs(m) < 5e-5 and abs(v - 0.04) < 1e-4 and abs(k - 3.0) < 0.01, (m, v, k)
+    out2 = torch.empty(n, device='cuda')
+    hl.randn(out2, 0.2, 1234, 78)                                   # another stream: uncorrelated
+    c = float((d * out2.double()).mean() / 0.04)
+    assert abs(c) < 1e-3, c
