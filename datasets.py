@@ -17,6 +17,9 @@ def _frame_number(name):
     return int(_FRAME.search(str(name)).group(1))
 
 
+frame_number = _frame_number          # the reference's public name (datasets.py:12)
+
+
 def read_video(paths, dtype=np.float32):
     from PIL import Image
     frames = []
