@@ -104,6 +104,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--autotune', type=int, default=1,
                     help='1 (default): the first launch of each conv geometry times the 7 tile candidates once (warm-up)')
+    ap.add_argument('--sync-bn', type=int, default=0, help='N > 1 only: 1 = synchronised BatchNorm (not the headline semantics)')
     ap.add_argument('--tiles', default='', help='JSON of tile choices to start from (e.g. for a profiler pass without tuning launches)')
     ap.add_argument('--save-tiles', default='', help='write the tile choices of this run to this JSON file')
     ap.add_argument('--overlap', type=int, default=int(os.environ.get('MCG_OVERLAP', '1')),
@@ -145,7 +146,8 @@ def main():
         hl.load_tile_choices(args.tiles)
 
     gen, di, dv = mstep.make_models(args.model, num_labels=6, seed=0)         # identical init on every rank
-    ts = mstep.TrainStep(args.model, gen, di, dv, exchange=exchange, seed=1234, rank=rank, precision=args.dtype, overlap=False)
+    ts = mstep.TrainStep(args.model, gen, di, dv, exchange=exchange, seed=1234, rank=rank, precision=args.dtype, overlap=False,
+                          sync_bn=bool(args.sync_bn))
     B = args.batch
     g = torch.Generator(device='cuda')
     g.manual_seed(rank)
@@ -223,7 +225,8 @@ def main():
             "config": {"workload": "MUG-shape synthetic (B,3,16,64,64) U(-1,1), one update_core iteration per step "
                                    "(BASELINE.json %s)" % cfg_name, "variant": args.model,
                        "per_gpu_batch": B, "global_batch": B * world, "n_filters": 64, "dim_zl": 6,
-                       "parallelism": "dp%d" % world, "side_streams": bool(args.overlap)},
+                       "parallelism": "dp%d" % world, "side_streams": bool(args.overlap),
+                       "sync_bn": bool(args.sync_bn)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "traffic_unit": "bytes per step (memory side of L2, incl. Infinity-Cache hits)",
                          "traffic_source": traffic_src,

@@ -144,6 +144,25 @@ int mcg_bn_act_bwd(int64_t M, int C, const float* g_out, const float* y, const f
                    const float* gamma, int act, float* gx, float* dgamma, float* dbeta,
                    void* workspace, void* stream);
 
+/* ---- synchronised BatchNorm (opt-in under data parallelism; the reference is single-device) ---------------
+ * Both passes of BatchNorm split at their per-channel reduction: the local sums leave the library as
+ * doubles, the caller adds them over the ranks (RCCL all-reduce) and the second half starts from the global
+ * sums, so the statistics are those of the global batch.
+ *   forward : mcg_bn_sums (sums = [sum x | sum x^2], 2*C doubles)  -> all-reduce ->  mcg_bn_stats_from_sums
+ *   backward: mcg_bn_bwd_sums (sums = [sum g' | sum g' x_hat], g' = g_out * act')  -> all-reduce ->
+ *             mcg_bn_act_bwd_from_sums: gx from the GLOBAL sums and M_total; dgamma / dbeta += the LOCAL sums
+ *             (the gradient exchange averages parameter gradients over the ranks afterwards). */
+int mcg_bn_sums(int64_t M, int C, const float* y, double* sums, void* workspace, void* stream);
+int mcg_bn_stats_from_sums(int64_t M_total, int C, const double* sums, const float* gamma,
+                           const float* beta, float* stats, float* avg_mean, float* avg_var, float eps,
+                           float decay, void* stream);
+int mcg_bn_bwd_sums(int64_t M, int C, const float* g_out, const float* y, const float* stats, int act,
+                    double* sums, void* workspace, void* stream);
+int mcg_bn_act_bwd_from_sums(int64_t M, int64_t M_total, int C, const float* g_out, const float* y,
+                             const float* stats, const float* gamma, int act, const double* local_sums,
+                             const double* global_sums, float* gx, float* dgamma, float* dbeta,
+                             void* workspace, void* stream);
+
 /* db += column sums of g [M][C] (bias gradient of every conv/deconv). */
 int mcg_colsum_acc(int64_t M, int C, const float* g, float* db, void* workspace, void* stream);
 

@@ -180,6 +180,49 @@ __global__ __launch_bounds__(FIN_CH * FIN_SL) void bn_bwd_finalize_kernel(int nb
     if (dbeta) dbeta[c] += (float)gb;
 }
 
+// ---- synchronised BatchNorm (opt-in, data parallel): the per-channel sums leave the library as doubles, the caller
+// all-reduces them over the ranks, and the second half of each pass starts from the global sums ----
+__global__ __launch_bounds__(FIN_CH * FIN_SL) void sums_finalize_kernel(int nblocks, int C, const float* __restrict__ part, double* __restrict__ sums) {
+    int c; double s, ss;
+    if (!reduce_partials(nblocks, C, part, c, s, ss)) return;
+    sums[c] = s; sums[C + c] = ss;
+}
+
+__global__ void bn_stats_from_sums_kernel(int C, double inv_m, double adjust, const double* __restrict__ sums,
+                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                          float* __restrict__ stats, float* avg_mean, float* avg_var, float eps, float decay) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double mean = sums[c] * inv_m;
+    double var = sums[C + c] * inv_m - mean * mean;
+    if (var < 0) var = 0;
+    var += eps;
+    float istd = (float)(1.0 / sqrt(var));
+    float scale = gamma[c] * istd;
+    stats[c] = (float)mean;
+    stats[C + c] = istd;
+    stats[2 * C + c] = scale;
+    stats[3 * C + c] = fmaf(-(float)mean, scale, beta[c]);
+    if (avg_mean) {
+        avg_mean[c] = avg_mean[c] * decay + (1.f - decay) * (float)mean;
+        avg_var[c] = avg_var[c] * decay + (1.f - decay) * (float)(adjust * var);
+    }
+}
+
+// coef as in bn_bwd_finalize_kernel from the GLOBAL sums; dgamma / dbeta take the LOCAL sums (the gradient
+// exchange averages them over the ranks afterwards)
+__global__ void bn_bwd_from_sums_kernel(int C, double inv_m_total, const double* __restrict__ local_sums, const double* __restrict__ global_sums,
+                                        const float* __restrict__ stats, const float* __restrict__ gamma, float* __restrict__ coef,
+                                        float* dgamma, float* dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    coef[c] = gamma[c] * stats[C + c];
+    coef[C + c] = (float)(global_sums[C + c] * inv_m_total);
+    coef[2 * C + c] = (float)(global_sums[c] * inv_m_total);
+    if (dgamma) dgamma[c] += (float)local_sums[C + c];
+    if (dbeta) dbeta[c] += (float)local_sums[c];
+}
+
 __global__ __launch_bounds__(FIN_CH * FIN_SL) void colsum_finalize_kernel(int nblocks, int C, const float* __restrict__ part, float* db) {
     int c; double s, unused;
     if (!reduce_partials(nblocks, C, part, c, s, unused)) return;
@@ -683,6 +726,52 @@ extern "C" int mcg_bn_act_bwd(int64_t M, int C, const float* g_out, const float*
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, pl.blocks, C, 1.0 / (double)M, part, stats, gamma,
                            coef, dgamma, dbeta);
     }
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(NT), 0, s, n4, C, g_out, y, stats, coef, act, gx);
+    return launch_status();
+}
+
+extern "C" int mcg_bn_sums(int64_t M, int C, const float* y, double* sums, void* workspace, void* stream) {
+    if (!y || !sums || !workspace || M <= 0 || bad_c(C)) return MCG_ERR_BAD_ARG;
+    if (unsupported_c(C)) return MCG_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    PartPlan pl = plan_partial(M, C);
+    float* part = (float*)workspace;
+    hipLaunchKernelGGL(col_partial_kernel<0>, dim3(pl.blocks), dim3(NT), 0, s, (long long)M, C, pl.rows_per_block, y, nullptr, nullptr, 0, part);
+    hipLaunchKernelGGL(sums_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, pl.blocks, C, part, sums);
+    return launch_status();
+}
+
+extern "C" int mcg_bn_stats_from_sums(int64_t M_total, int C, const double* sums, const float* gamma, const float* beta, float* stats,
+                                      float* avg_mean, float* avg_var, float eps, float decay, void* stream) {
+    if (!sums || !gamma || !beta || !stats || M_total <= 0 || C <= 0) return MCG_ERR_BAD_ARG;
+    if ((avg_mean == nullptr) != (avg_var == nullptr)) return MCG_ERR_BAD_ARG;
+    double adjust = (double)M_total / (M_total - 1.0 > 1.0 ? M_total - 1.0 : 1.0);
+    hipLaunchKernelGGL(bn_stats_from_sums_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, C, 1.0 / (double)M_total, adjust, sums,
+                       gamma, beta, stats, avg_mean, avg_var, eps, decay);
+    return launch_status();
+}
+
+extern "C" int mcg_bn_bwd_sums(int64_t M, int C, const float* g_out, const float* y, const float* stats, int act, double* sums,
+                               void* workspace, void* stream) {
+    if (!g_out || !y || !stats || !sums || !workspace || M <= 0 || bad_c(C)) return MCG_ERR_BAD_ARG;
+    if (unsupported_c(C)) return MCG_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    PartPlan pl = plan_partial(M, C);
+    float* part = (float*)workspace;
+    hipLaunchKernelGGL(col_partial_kernel<1>, dim3(pl.blocks), dim3(NT), 0, s, (long long)M, C, pl.rows_per_block, g_out, y, stats, act, part);
+    hipLaunchKernelGGL(sums_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, pl.blocks, C, part, sums);
+    return launch_status();
+}
+
+extern "C" int mcg_bn_act_bwd_from_sums(int64_t M, int64_t M_total, int C, const float* g_out, const float* y, const float* stats,
+                                        const float* gamma, int act, const double* local_sums, const double* global_sums, float* gx,
+                                        float* dgamma, float* dbeta, void* workspace, void* stream) {
+    if (!g_out || !y || !gx || !stats || !gamma || !local_sums || !global_sums || !workspace || M <= 0 || M_total < M || bad_c(C)) return MCG_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    float* coef = (float*)workspace + (long long)MAX_PART * 2 * C;
+    hipLaunchKernelGGL(bn_bwd_from_sums_kernel, dim3((C + 63) / 64), dim3(64), 0, s, C, 1.0 / (double)M_total, local_sums, global_sums, stats, gamma,
+                       coef, dgamma, dbeta);
+    long long n4 = (long long)M * (C >> 2);
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(NT), 0, s, n4, C, g_out, y, stats, coef, act, gx);
     return launch_status();
 }

@@ -47,6 +47,10 @@ SIGNATURES = {
     "mcg_bn_stats": (_I, [_I64, _I, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P]),
     "mcg_bn_act_fwd": (_I, [_I64, _I, _I, _P, _I64, _I64, _P, _I, _P, _F, _U64, _U64, _P, _P]),
     "mcg_bn_act_bwd": (_I, [_I64, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
+    "mcg_bn_sums": (_I, [_I64, _I, _P, _P, _P, _P]),
+    "mcg_bn_stats_from_sums": (_I, [_I64, _I, _P, _P, _P, _P, _P, _P, _F, _F, _P]),
+    "mcg_bn_bwd_sums": (_I, [_I64, _I, _P, _P, _P, _I, _P, _P, _P]),
+    "mcg_bn_act_bwd_from_sums": (_I, [_I64, _I64, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
     "mcg_colsum_acc": (_I, [_I64, _I, _P, _P, _P, _P]),
     "mcg_pack_clip": (_I, [_I, _I, _I, _I, _I, _P, _I64, _I64, _P, _F, _U64, _U64, _P, _P]),
     "mcg_unpack_clip": (_I, [_I, _I, _I, _I, _I, _P, _P, _P]),
@@ -327,9 +331,18 @@ def bn_workspace_floats(C_max):
     return int(load().mcg_bn_workspace_bytes(0, C_max)) // 4
 
 
-def bn_stats(M, Cn, y, gamma, beta, stats, avg_mean, avg_var, ws, eps=2e-5, decay=0.9):
-    _check(load().mcg_bn_stats(M, Cn, _p(_dense(y)), _p(gamma), _p(beta), _p(stats), _p(avg_mean), _p(avg_var),
-                               eps, decay, _p(ws), _stream()), "mcg_bn_stats")
+def bn_stats(M, Cn, y, gamma, beta, stats, avg_mean, avg_var, ws, eps=2e-5, decay=0.9, sync=None):
+    """sync: None, or an object with .world and .all_reduce_sum(tensor) (step.GradExchange): the statistics are then
+    those of the global batch (every rank holds M rows)."""
+    if sync is None or sync.world == 1:
+        _check(load().mcg_bn_stats(M, Cn, _p(_dense(y)), _p(gamma), _p(beta), _p(stats), _p(avg_mean), _p(avg_var),
+                                   eps, decay, _p(ws), _stream()), "mcg_bn_stats")
+        return
+    sums = torch.empty(2 * Cn, dtype=torch.float64, device=y.device)
+    _check(load().mcg_bn_sums(M, Cn, _p(_dense(y)), _p(sums, torch.float64), _p(ws), _stream()), "mcg_bn_sums")
+    sync.all_reduce_sum(sums)
+    _check(load().mcg_bn_stats_from_sums(M * sync.world, Cn, _p(sums, torch.float64), _p(gamma), _p(beta), _p(stats), _p(avg_mean),
+                                         _p(avg_var), eps, decay, _stream()), "mcg_bn_stats_from_sums")
 
 
 def bn_act_fwd(M, Cn, y, scale_shift, act, out, addend=None, sigma=0.0, seed=0, stream_id=0, c_valid=None,
@@ -341,9 +354,19 @@ def bn_act_fwd(M, Cn, y, scale_shift, act, out, addend=None, sigma=0.0, seed=0, 
                                  _p(_dense(addend)), sigma, seed, stream_id, _p(_dense(out)), _stream()), "mcg_bn_act_fwd")
 
 
-def bn_act_bwd(M, Cn, g_out, y, stats, gamma, act, gx, dgamma, dbeta, ws):
-    _check(load().mcg_bn_act_bwd(M, Cn, _p(_dense(g_out)), _p(_dense(y)), _p(stats), _p(gamma), act, _p(_dense(gx)),
-                                 _p(dgamma), _p(dbeta), _p(ws), _stream()), "mcg_bn_act_bwd")
+def bn_act_bwd(M, Cn, g_out, y, stats, gamma, act, gx, dgamma, dbeta, ws, sync=None):
+    if sync is None or sync.world == 1 or stats is None:
+        _check(load().mcg_bn_act_bwd(M, Cn, _p(_dense(g_out)), _p(_dense(y)), _p(stats), _p(gamma), act, _p(_dense(gx)),
+                                     _p(dgamma), _p(dbeta), _p(ws), _stream()), "mcg_bn_act_bwd")
+        return
+    local = torch.empty(2 * Cn, dtype=torch.float64, device=y.device)
+    _check(load().mcg_bn_bwd_sums(M, Cn, _p(_dense(g_out)), _p(_dense(y)), _p(stats), act, _p(local, torch.float64), _p(ws), _stream()),
+           "mcg_bn_bwd_sums")
+    glob = local.clone()
+    sync.all_reduce_sum(glob)
+    _check(load().mcg_bn_act_bwd_from_sums(M, M * sync.world, Cn, _p(g_out), _p(y), _p(stats), _p(gamma), act, _p(local, torch.float64),
+                                           _p(glob, torch.float64), _p(_dense(gx)), _p(dgamma), _p(dbeta), _p(ws), _stream()),
+           "mcg_bn_act_bwd_from_sums")
 
 
 def colsum_acc(M, Cn, g, db, ws):

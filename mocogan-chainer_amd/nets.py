@@ -83,6 +83,7 @@ class _Net:
     # both only read the layer's output gradient, so they may run side by side: the blocks of one fill the
     # CUs the other leaves idle in its last, partial round of tiles.  None = everything on the caller's stream.
     wgrad_stream = None
+    sync_bn = None                 # step.GradExchange when BatchNorm is synchronised over the data-parallel ranks
 
     def _wgrad(self, geom, x, y, dw):
         """conv_wgrad on wgrad_stream (after everything queued so far on the current stream)."""
@@ -301,7 +302,7 @@ class DisNet(_Net):
                         stats = torch.empty(4 * co, device=dev)
                         hl.bn_stats(m, co, yg, self.fp.param(name + '/gamma'), self.fp.param(name + '/beta'), stats,
                                     self.running[name + '/avg_mean'] if update_stats else None,
-                                    self.running[name + '/avg_var'] if update_stats else None, self.ws)
+                                    self.running[name + '/avg_var'] if update_stats else None, self.ws, sync=self.sync_bn)
                         if update_stats:
                             self.bn_count[name] += 1
                         saved['stats'][l].append(stats)
@@ -366,7 +367,7 @@ class DisNet(_Net):
                     name = 'bn%d' % l
                     hl.bn_act_bwd(m, co, gg, yg, saved['stats'][l][gi], fp.param(name + '/gamma'), hl.ACT_LRELU, gg,
                                   fp.grad(name + '/gamma') if param_grads else None,
-                                  fp.grad(name + '/beta') if param_grads else None, self.ws)
+                                  fp.grad(name + '/beta') if param_grads else None, self.ws, sync=self.sync_bn)
                 else:
                     hl.bn_act_bwd(m, co, gg, yg, None, None, hl.ACT_LRELU, gg, None, None, self.ws)
             if param_grads:
@@ -528,7 +529,7 @@ class GenNet(_Net):
                 stats = torch.empty(4 * co, device=dev)
                 hl.bn_stats(m, co, y, fp.param(name + '/gamma'), fp.param(name + '/beta'), stats,
                             self.running[name + '/avg_mean'] if update_stats else None,
-                            self.running[name + '/avg_var'] if update_stats else None, self.ws)
+                            self.running[name + '/avg_var'] if update_stats else None, self.ws, sync=self.sync_bn)
                 if update_stats:
                     self.bn_count[name] += 1
                 saved['stats'][l] = stats
@@ -569,7 +570,7 @@ class GenNet(_Net):
             if l < 5:
                 name = 'bn%d' % l
                 hl.bn_act_bwd(m, ci, g, saved['y'][l], saved['stats'][l], fp.param(name + '/gamma'), hl.ACT_RELU, g,
-                              fp.grad(name + '/gamma'), fp.grad(name + '/beta'), self.ws)
+                              fp.grad(name + '/gamma'), fp.grad(name + '/beta'), self.ws, sync=self.sync_bn)
             if l == 5:
                 hl.colsum_acc(m, ci, g, fp.grad('dc5/b'), self.ws)         # dc1..dc4 feed BatchNorm: exact zero
             self._wgrad(geom, g, saved['a'][l], fp.grad('dc%d/W' % l))
@@ -579,7 +580,7 @@ class GenNet(_Net):
         c1 = self.chans[1]
         k1 = 16 * c1
         hl.bn_act_bwd(frames * 16, c1, g, saved['y'][1], saved['stats'][1], fp.param('bn1/gamma'), hl.ACT_RELU, g,
-                      fp.grad('bn1/gamma'), fp.grad('bn1/beta'), self.ws)
+                      fp.grad('bn1/gamma'), fp.grad('bn1/beta'), self.ws, sync=self.sync_bn)
         hl.fc_wgrad(frames, k1, self.n_hidden, g.view(frames, k1), saved['z'], fp.grad('dc1/W').view(self.n_hidden, k1))
         gz = torch.empty_like(saved['z'])
         hl.fc_fprop(frames, k1, self.n_hidden, g.view(frames, k1), fp.param('dc1/W').view(self.n_hidden, k1), None, gz)

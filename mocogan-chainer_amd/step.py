@@ -63,6 +63,11 @@ class GradExchange:
         work.wait()
         buf.mul_(1.0 / self.world)
 
+    def all_reduce_sum(self, t):
+        """In-place SUM over the ranks, ordered on the current stream (synchronised BatchNorm's per-channel sums)."""
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+
     def broadcast_params(self, tensors, src=0):
         if self.world == 1:
             return
@@ -73,7 +78,7 @@ class GradExchange:
 class TrainStep:
     """Holds the three networks, their Adam hyper-parameters and runs update_core on device data."""
 
-    def __init__(self, model, gen, dis_i, dis_v, hyper=None, exchange=None, seed=0, rank=0, precision=None, overlap=False):
+    def __init__(self, model, gen, dis_i, dis_v, hyper=None, exchange=None, seed=0, rank=0, precision=None, overlap=False, sync_bn=False):
         assert model in ('normal', 'cgan', 'infogan')
         self.model, self.gen, self.dis_i, self.dis_v = model, gen, dis_i, dis_v
         if precision is not None:                                 # 'f32' | 'bf16': MFMA operand type of every conv GEMM
@@ -82,6 +87,10 @@ class TrainStep:
                 net.precision = precision
         self.hyper = hyper or {'image_gen': AdamHyper(), 'image_dis': AdamHyper(), 'video_dis': AdamHyper()}
         self.exchange = exchange
+        # sync_bn (opt-in): BatchNorm statistics and their backward sums are all-reduced over the ranks, i.e.
+        # taken over the GLOBAL batch; without it every rank normalises with the statistics of its own shard.
+        for net in (gen, dis_i, dis_v):
+            net.sync_bn = exchange if (sync_bn and exchange is not None) else None
         self.seed, self.rank = seed, rank
         self.iteration = 0
         self.device = gen.device

@@ -30,6 +30,7 @@ class Updater:
         # MFMA operand type of the conv GEMMs ('f32' | 'bf16')
         overlap = kwargs.pop('overlap', False)
         precision = kwargs.pop('precision', None)
+        sync_bn = kwargs.pop('sync_bn', False)
         if kwargs:
             raise TypeError('unexpected arguments: %s' % sorted(kwargs))
         self.iteration = 0
@@ -37,7 +38,7 @@ class Updater:
         hyper = {k: self._optimizers[k].hyper() for k in ('image_gen', 'image_dis', 'video_dis')}
         self._step = _step.TrainStep(self.model, self.image_gen.impl, self.image_dis.impl, self.video_dis.impl,
                                      hyper=hyper, exchange=exchange, seed=seed, rank=rank, overlap=overlap,
-                                     precision=precision)
+                                     precision=precision, sync_bn=sync_bn)
 
     # ---- StandardUpdater surface -------------------------------------------------------------------
     def get_optimizer(self, name):

@@ -15,15 +15,19 @@ from . import net
 # ----------------------------------------------------------------------------------------
 # losses (value + gradient w.r.t. the logits)
 # ----------------------------------------------------------------------------------------
-def loss_dis(model, is_video, y_real, y_fake, t_real, t_fake):
+def loss_dis(model, is_video, y_real, y_fake, t_real, t_fake, q1_rows=None):
     """model/updater.py:21-44.  The GAN term uses batch sample 0 only ([:1] slices the batch
-    axis) yet divides by the full batch size (quirk Q1).  Returns (loss, gy_real, gy_fake)."""
+    axis) yet divides by the full batch size (quirk Q1).  Returns (loss, gy_real, gy_fake).
+    q1_rows (data-parallel emulation with synchronised BatchNorm only): the rows playing "sample 0", i.e. the
+    first sample of every rank's shard -- the mean over ranks of the per-shard Q1 terms is their sum over the
+    global batch size."""
     n = len(y_fake)
-    loss = F.softplus(-y_real[:1]).sum() / n + F.softplus(y_fake)[:1].sum() / n
+    rows = [0] if q1_rows is None else list(q1_rows)
+    loss = F.softplus(-y_real[rows]).sum() / n + F.softplus(y_fake)[rows].sum() / n
     gr = np.zeros_like(y_real)
     gf = np.zeros_like(y_fake)
-    gr[:1] = -F.sigmoid(-y_real[:1]) / n
-    gf[:1] = F.sigmoid(y_fake[:1]) / n
+    gr[rows] = -F.sigmoid(-y_real[rows]) / n
+    gf[rows] = F.sigmoid(y_fake[rows]) / n
     if model == 'infogan' and is_video:
         c = y_real.shape[1]
         lr, g1 = F.softmax_cross_entropy(y_real.reshape(n, c)[:, 1:], t_real)
@@ -100,7 +104,7 @@ def zero_grads(p):
 # one iteration
 # ----------------------------------------------------------------------------------------
 def update_core(model, gen, dis_i, dis_v, opt_g, opt_i, opt_v, x_real, t_real, rnd,
-                dim_zl=0, video_len=16, keep=False, reduce=None):
+                dim_zl=0, video_len=16, keep=False, reduce=None, q1_rows=None):
     """model/updater.py:78-113 with injected randomness.
 
     gen/dis_i/dis_v: parameter dicts (updated IN PLACE, as Chainer does).
@@ -135,7 +139,7 @@ def update_core(model, gen, dis_i, dis_v, opt_g, opt_i, opt_v, x_real, t_real, r
 
     out = {}
     # image_dis_optimizer.update(self.loss_dis, image_dis, ...)   :111
-    l_i, gr, gf = loss_dis(model, False, y_real_i, y_fake_i, t_real, t_fake)
+    l_i, gr, gf = loss_dis(model, False, y_real_i, y_fake_i, t_real, t_fake, q1_rows)
     g_i = zero_grads(dis_i)
     net.dis_backward(dis_i, c_real_i, gr, g_i)
     net.dis_backward(dis_i, c_fake_i, gf, g_i)
@@ -145,7 +149,7 @@ def update_core(model, gen, dis_i, dis_v, opt_g, opt_i, opt_v, x_real, t_real, r
         reduce('image_dis', g_i)
     adam_wd_update(dis_i, g_i, opt_i)
     # video_dis_optimizer.update(self.loss_dis, video_dis, ...)   :112
-    l_v, gr, gf = loss_dis(model, True, y_real_v, y_fake_v, t_real, t_fake)
+    l_v, gr, gf = loss_dis(model, True, y_real_v, y_fake_v, t_real, t_fake, q1_rows)
     g_v = zero_grads(dis_v)
     net.dis_backward(dis_v, c_real_v, gr, g_v)
     net.dis_backward(dis_v, c_fake_v, gf, g_v)

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NF, N, MODEL, DIM_ZL = 4, 2, 'infogan', 6
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, sync_bn=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
@@ -34,7 +34,7 @@ def _worker(rank, world, port, q):
         G = nets.GenNet(dim_zl=DIM_ZL, n_filters=NF)
         DI = nets.DisNet(2, 3, 7, NF, use_noise=True)
         DV = nets.DisNet(3, 3, 7, NF, use_noise=True)
-        ts = step.TrainStep(MODEL, G, DI, DV, exchange=step.GradExchange(), rank=rank, overlap=True)
+        ts = step.TrainStep(MODEL, G, DI, DV, exchange=step.GradExchange(), rank=rank, overlap=True, sync_bn=sync_bn)
         for net, p in ((G, gen), (DI, di), (DV, dv)):
             net.load_reference_params(p)
             net.load_adam_state(oupd.new_adam_state(p))
@@ -55,17 +55,15 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_rank_hip_step_matches_the_sharded_oracle():
-    import torch.multiprocessing as mp
-    sys.path.insert(0, os.path.join(ROOT, 'tests'))
-    import dp_common
-    ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    port = 29600 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    [p.start() for p in procs]
+def _run_ranks(sync_bn, port_base):
     import queue
     import time
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = port_base + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, sync_bn)) for r in range(2)]
+    [p.start() for p in procs]
     res, t0 = [], time.time()
     while len(res) < 2:
         try:
@@ -78,6 +76,65 @@ def test_two_rank_hip_step_matches_the_sharded_oracle():
         assert r[1] != 'error', r[2]
     res.sort(key=lambda r: r[0])
     assert all(p.exitcode == 0 for p in procs)
+    return res
+
+
+def _update_errors(res, nets, ref):
+    worst = 0.0
+    for name, refp in zip(('gen', 'di', 'dv'), ref):
+        for k, v in refp.items():
+            if 'avg_' in k or k.endswith('/N') or v.dtype.kind != 'f':
+                continue
+            got = res[0][1][name][k].astype(np.float64)
+            base = nets[('gen', 'di', 'dv').index(name)][k]     # parameters move by ~alpha per step: compare the UPDATE
+            du, dr = got - base, v - base
+            if np.abs(dr).max() < 1e-12:
+                continue
+            err = np.linalg.norm(du - dr) / max(np.linalg.norm(dr), 1e-30)
+            worst = max(worst, err)
+            assert err < 1e-2, (name, k, err)             # measured ~2e-4; Adam's first step is sign-like, so a gradient
+                                                          # element within rounding of 0 may move by 2*alpha
+    return worst
+
+
+def test_two_rank_synchronised_batchnorm_matches_the_global_batch_oracle():
+    """sync_bn=True: BatchNorm statistics (and the sums of its backward pass) are all-reduced, so two ranks with n
+    clips each must reproduce ONE oracle iteration on the concatenated batch of 2n clips -- with the per-shard
+    "sample 0" terms of quirk Q1 (rows 0 and n), the only place where the ranks still differ from a single device."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import dp_common
+    from oracle import updater as oupd
+    res = _run_ranks(True, 31600)
+    for name in ('gen', 'di', 'dv'):
+        for k, v in res[0][1][name].items():
+            if k.endswith('/N'):
+                continue
+            assert np.array_equal(v, res[1][1][name][k]), (name, k)      # incl. the running statistics: global now
+    nets, shards = dp_common.setup(nf=NF, n=N, seed=11, model=MODEL, dim_zl=DIM_ZL, world=2)
+    gen, di, dv = nets
+    import copy
+    base = copy.deepcopy(nets)
+    x = np.concatenate([s[0] for s in shards])
+    r0, r1 = shards[0][1], shards[1][1]
+    rnd = {'t': r0['t'],
+           'gen': {'h0': np.concatenate((r0['gen']['h0'], r1['gen']['h0'])), 'zc': np.concatenate((r0['gen']['zc'], r1['gen']['zc'])),
+                   'e': np.concatenate((r0['gen']['e'], r1['gen']['e']), axis=1),
+                   'labels': None if r0['gen']['labels'] is None else np.concatenate((r0['gen']['labels'], r1['gen']['labels']))}}
+    for k in ('noise_i_real', 'noise_v_real', 'noise_i_fake', 'noise_v_fake'):
+        rnd[k] = [np.concatenate((a, b)) for a, b in zip(r0[k], r1[k])]
+    og, oi, ov = (oupd.new_adam_state(p) for p in (gen, di, dv))
+    oupd.update_core(MODEL, gen, di, dv, og, oi, ov, x, np.zeros(2 * N, dtype=np.int64), rnd, dim_zl=DIM_ZL, q1_rows=[0, N])
+    print('sync-BN worst relative update error', _update_errors(res, base, (gen, di, dv)))
+    for name, p in (('gen', gen), ('di', di), ('dv', dv)):
+        for k, v in p.items():
+            if 'avg_' in k:
+                assert np.allclose(res[0][1][name][k], v, rtol=1e-4, atol=1e-6), (name, k)
+
+
+def test_two_rank_hip_step_matches_the_sharded_oracle():
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import dp_common
+    res = _run_ranks(False, 29600)
     # replicas bit-identical: same averaged gradients, same Adam
     for name in ('gen', 'di', 'dv'):
         for k, v in res[0][1][name].items():
@@ -100,19 +157,5 @@ def test_two_rank_hip_step_matches_the_sharded_oracle():
         ref = dp_common.emulate(nets, shards, model=MODEL, dim_zl=DIM_ZL)
     finally:
         oupd.update_core = orig
-    worst = 0.0
-    for name, refp in zip(('gen', 'di', 'dv'), ref):
-        for k, v in refp.items():
-            if 'avg_' in k or k.endswith('/N') or v.dtype.kind != 'f':
-                continue
-            got = res[0][1][name][k].astype(np.float64)
-            # parameters move by ~alpha = 2e-4 per Adam step: compare the UPDATE, not the parameter
-            base = nets[('gen', 'di', 'dv').index(name)][k]
-            du, dr = got - base, v - base
-            if np.abs(dr).max() < 1e-12:
-                continue
-            err = np.linalg.norm(du - dr) / max(np.linalg.norm(dr), 1e-30)
-            worst = max(worst, err)
-            assert err < 1e-2, (name, k, err)             # measured 1.7e-4; Adam's first step is sign-like, so a gradient
-                                                          # element within rounding of 0 may move by 2*alpha
+    worst = _update_errors(res, nets, ref)
     print('worst relative update error', worst)

@@ -49,6 +49,8 @@ def parse_args(argv=None):
                    help="operand type of the convolution GEMMs (accumulation, parameters, Adam: always fp32)")
     p.add_argument('--overlap', type=int, default=1, help="side HIP streams for independent kernels")
     p.add_argument('--autotune', type=int, default=1, help="time the GEMM tile candidates once per layer geometry")
+    p.add_argument('--sync_bn', type=int, default=0,
+                   help="data parallel only: 1 = BatchNorm statistics over the global batch (all-reduced sums) instead of per rank")
     p.add_argument('--loader_workers', type=int, default=0,
                    help="0: the reference's serial in-process loading (SerialIterator); N > 0: N worker processes decode the "
                         "next batches while the GPU trains (PrefetchIterator)")
@@ -118,7 +120,7 @@ def main(argv=None):
     updater = Updater(model=args.model, models=(image_gen, image_dis, video_dis), video_length=video_length,
                       img_size=size, channel=channel, dim_zl=num_labels, iterator=train_iter,
                       tensorboard_writer=writer, optimizer=opts, device=args.gpu, seed=args.seed, exchange=exchange, rank=rank,
-                      overlap=bool(args.overlap), precision=args.mfma)
+                      overlap=bool(args.overlap), precision=args.mfma, sync_bn=bool(args.sync_bn))
 
     save_path = Path('result') / args.save_name
     trainer = T.Trainer(updater, (args.max_epoch, 'epoch'), out=save_path)
