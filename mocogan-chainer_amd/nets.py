@@ -98,6 +98,17 @@ class _Net:
         for t in (x, y):
             t.record_stream(ws)            # the caching allocator must not hand the block out before ws is done with it
 
+    def _after_wgrads(self, fn):
+        """Runs fn (the start of a gradient bucket's all-reduce) once everything queued so far -- on the current stream
+        and on wgrad_stream -- is done, without making the current stream wait: fn is issued on wgrad_stream."""
+        ws = self.wgrad_stream
+        if ws is None:
+            fn()
+            return
+        ws.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(ws):
+            fn()
+
     def _wgrad_join(self):
         """the current stream waits for the weight gradients queued on wgrad_stream"""
         if self.wgrad_stream is not None:
@@ -376,8 +387,7 @@ class DisNet(_Net):
                 # dc2..dc4 feed BatchNorm: sum_m gx == 0 exactly (see _Net.BIAS_NOTE), nothing to add
                 self._wgrad(geom, saved['a'][l], g, fp.grad('dc%d/W' % l))
                 if l == 4 and on_late_bucket is not None:
-                    self._wgrad_join()
-                    on_late_bucket()
+                    self._after_wgrads(on_late_bucket)
             if l > 1:
                 ga = torch.empty_like(saved['a'][l])
                 hl.conv_dgrad(geom, g, fp.param('dc%d/W' % l), None, ga)
@@ -553,7 +563,13 @@ class GenNet(_Net):
         return x, saved
 
     # ---- backward --------------------------------------------------------------------------
-    def backward(self, saved, gx_clip):
+    def grad_bucket_late(self):
+        """(start, end) of the flat-gradient range dc2/W .. dc5/b: 85 % of the bytes, final once layer 2's weight
+        gradient is queued -- its exchange then overlaps the rest of the backward pass (dc2's input gradient, dc1, GRU)."""
+        o = self.fp.offsets
+        return o['dc2/W'], o['bn1/gamma']
+
+    def backward(self, saved, gx_clip, on_late_bucket=None):
         """gx_clip: gradient w.r.t. the clip tensor [n][T][64][64][cp_out].  Accumulates into the flat gradient."""
         n = saved['n']
         T, dz, dl, dc = self.video_len, self.dim_zm, self.dim_zl, self.dim_zc
@@ -574,6 +590,8 @@ class GenNet(_Net):
             if l == 5:
                 hl.colsum_acc(m, ci, g, fp.grad('dc5/b'), self.ws)         # dc1..dc4 feed BatchNorm: exact zero
             self._wgrad(geom, g, saved['a'][l], fp.grad('dc%d/W' % l))
+            if l == 2 and on_late_bucket is not None:
+                self._after_wgrads(on_late_bucket)
             ga = torch.empty_like(saved['a'][l])
             hl.conv_fprop(geom, g, fp.param('dc%d/W' % l), None, ga)
             g = ga

@@ -253,9 +253,13 @@ class TrainStep:
             gxg = torch.zeros_like(x_fake)
             gxg[..., :c_img] = gx[..., :c_img]                       # label planes carry no gradient to G
             gx = gxg
-        gen.backward(s_gen, gx)
+        late_g = []
+        lo_g, hi_g = gen.grad_bucket_late()
+        gen.backward(s_gen, gx, on_late_bucket=(lambda: late_g.append(ex.start(gen.fp.g[lo_g:hi_g]))) if ex else None)
         if ex:
-            ex.finish(ex.start(gen.fp.g))
+            rest_g = [ex.start(gen.fp.g[:lo_g]), ex.start(gen.fp.g[hi_g:])]
+            for h in late_g + rest_g:
+                ex.finish(h)
         adam_update(gen, self.hyper['image_gen'])
         self.iteration += 1
         return {'x_fake': x_fake, 't_fake': t_fake, 't': t, 'gx_fake': gx, 'saved_gen': s_gen, 'saved_fake_i': s_fake_i, 'saved_fake_v': s_fake_v,
