@@ -247,7 +247,7 @@ def _tuned(kind, g, extra, out_side, run_on):
                 except McgError:
                     continue
                 ms = None
-                for _ in range(2):                          # best of two timings of two launches each
+                for _ in range(3):                          # best of three timings of two launches each
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(cur)
                     run(gg)
