@@ -343,7 +343,9 @@ struct WgradP {
 // ------------------------------------------------------------------------------------------
 template <class P, int BM, int BN, int BK>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(P p) {
-    constexpr int TM = BM / 64, TN = BN / 64;
+    // wave grid: 2 x 2, except for the long tiles 256x64 (4 x 1) and 64x256 (1 x 4) whose waves keep 64x64 outputs
+    constexpr int WM = (BM >= 4 * BN) ? 4 : (BN >= 4 * BM) ? 1 : 2, WN = 4 / WM;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_R = P::A_KC ? BM : BK, A_C = P::A_KC ? BK : BM;
     constexpr int B_R = P::B_KC ? BN : BK, B_C = P::B_KC ? BK : BN;
     constexpr int A_LD = A_C + PAD, B_LD = B_C + PAD;
@@ -355,7 +357,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(P p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
+    const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
     // XCD-aware tile mapping.  Workgroups are dealt round-robin over the 8 XCDs (each with its own 4 MiB
     // L2), so workgroup ids L and L+8 share an L2.  Re-label them so that every XCD works on one
     // contiguous range of logical tiles, ordered such that consecutive logical tiles share operand rows
@@ -518,7 +520,9 @@ __device__ __forceinline__ s16x4 lds_tr16(const u16* p) {
 
 template <class P, int BM, int BN, int BK>
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(P p) {
-    constexpr int TM = BM / 64, TN = BN / 64;
+    // wave grid: 2 x 2, except for the long tiles 256x64 (4 x 1) and 64x256 (1 x 4) whose waves keep 64x64 outputs
+    constexpr int WM = (BM >= 4 * BN) ? 4 : (BN >= 4 * BM) ? 1 : 2, WN = 4 / WM;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int KPAD = 8, CPAD = 32;
     constexpr int A_R = P::A_KC ? BM : BK, A_C = P::A_KC ? BK : BM;
     constexpr int B_R = P::B_KC ? BN : BK, B_C = P::B_KC ? BK : BN;
@@ -534,7 +538,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(P p) {
     // transposed-read coordinates: 16-lane group `lane>>4` = (k half lh, column half), lane 4q+p of the
     // group addresses row q, columns 4p..4p+3 of the 4x16 block
     const int tr_row = 8 * lh + ((lane & 15) >> 2), tr_col = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
-    const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
+    const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
     int bx, by, bz;
     {   // XCD-aware tile mapping, as in gemm_kernel
         const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
@@ -756,7 +760,7 @@ int make_geom(const mcg_conv_geom* c, Geom& g) {
     g.taps = c->kt * 16;
     g.prec = c->precision;
     if (g.prec != MCG_PREC_F32 && g.prec != MCG_PREC_BF16) return MCG_ERR_BAD_ARG;
-    if (c->tile < 0 || c->tile % 100 > 3 || (c->tile / 100) % 10 > 2 || c->tile / 1000 > 2) return MCG_ERR_BAD_ARG;
+    if (c->tile < 0 || c->tile % 100 > 5 || (c->tile / 100) % 10 > 2 || c->tile / 1000 > 2) return MCG_ERR_BAD_ARG;
     g.tile = c->tile % 100; g.bk = ((c->tile / 100) % 10) * 32; g.ksplit = 1 << (c->tile / 1000);
     g.lgHo = ilog2_exact(g.Ho); g.lgWo = ilog2_exact(g.Wo);
     g.lgCi = ilog2_exact(g.Ci); g.lgCo = ilog2_exact(g.Co);
@@ -842,6 +846,8 @@ void launch_wgrad(const Geom& g, const float* x, const float* y, float* dw, hipS
     do {                                                                \
         if ((t) == 1) fn<128, 128, BK, BF>(__VA_ARGS__);                \
         else if ((t) == 2) fn<128, 64, BK, BF>(__VA_ARGS__);            \
+        else if ((t) == 4) fn<256, 64, 32, BF>(__VA_ARGS__);            \
+        else if ((t) == 5) fn<64, 256, 32, BF>(__VA_ARGS__);            \
         else fn<64, 64, BK, BF>(__VA_ARGS__);                           \
     } while (0)
 #define MCG_DISPATCH(fn, t, bk64, bf, ...)                              \

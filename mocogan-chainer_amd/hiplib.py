@@ -183,7 +183,8 @@ def _launch(kind, fn, *args):
 # tensors and the winner is used from then on.  Off by default (tests, parity runs): bench.py, train.py
 # and generate_samples.py switch it on.
 # ------------------------------------------------------------------------------------------
-TILE_CANDIDATES = (0, 101, 102, 103, 201, 202, 203)
+TILE_CANDIDATES = (0, 101, 102, 103, 201, 202, 203)     # (the long tiles 4 = 256x64 and 5 = 64x256 exist, but when they
+                                                        # win the isolated timing they lose inside the iteration: measured)
 FPROP_SPLIT_CANDIDATES = (1103, 1203, 1202, 2103, 2203, 2202)     # 2- / 4-way split-K: only when few tiles (see _tuned)
 _autotune = False
 _tile_cache = {}

@@ -52,7 +52,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 101, 103, 201, 202, 203])     # 1xx / 2xx force BK = 32 / 64
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 101, 103, 201, 202, 203])     # 1xx / 2xx force BK = 32 / 64
 def test_conv_three_passes(hl, case, tile):
     N, Ti, H, Ci, Co, kt = case
     rng = np.random.RandomState(hash(case) % 2**31)
@@ -101,7 +101,7 @@ BF16_TOL = 2e-2      # bf16 configuration, forward rel-L2 <= 2e-2
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 101, 102, 103, 201, 202, 203])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 101, 102, 103, 201, 202, 203])
 def test_conv_three_passes_bf16_mfma(hl, case, tile):
     """precision = bf16: operands are rounded to bf16 in the kernel, products accumulate in fp32.
     (1) On inputs that are already bf16-representable the rounding is the identity, so the result must
