@@ -24,24 +24,30 @@ def parse_args(argv=None):
         default_name = datetime.now(timezone('Asia/Tokyo')).strftime("%Y_%m%d_%H%M")
     except Exception:
         default_name = datetime.now().strftime("%Y_%m%d_%H%M")
-    p = argparse.ArgumentParser(description='Train script')
-    p.add_argument('--gpu', '-g', type=int, default=-1, help='GPU ID (negative value indicates CPU)')
-    p.add_argument('--dataset_type', choices=['mug', 'mnist', 'synthetic'], default='mug', help="dataset type")
-    p.add_argument('--dataset', default='data/dataset/train', help="dataset root path")
-    p.add_argument('--batchsize', type=int, default=100, help="batchsize")
-    p.add_argument('--max_epoch', type=int, default=1000, help="num learning epochs")
-    p.add_argument('--model', type=str, choices=['normal', 'cgan', 'infogan'], default="normal", help="MoCoGAN model")
-    p.add_argument('--save_name', default=default_name, help="save path for log, snapshot etc")
-    p.add_argument('--display_interval', type=int, default=1, help='interval of displaying log to console')
-    p.add_argument('--snapshot_interval', type=int, default=10, help='interval of snapshot')
-    p.add_argument('--log_tensorboard_interval', type=int, default=10, help='interval of log to tensorboard (genenrate samples too)')
-    p.add_argument('--num_gen_samples', type=int, default=36, help='num generate samples')
-    p.add_argument('--dim_zc', type=int, default=50, help='number of dimensions of z content')
-    p.add_argument('--dim_zm', type=int, default=10, help='number of dimensions of z motion')
-    p.add_argument('--n_filters_gen', type=int, default=64, help='number of channelsof image generator')
-    p.add_argument('--n_filters_idis', type=int, default=64, help='number of channel of image discriminator')
-    p.add_argument('--n_filters_vdis', type=int, default=64, help='number of channel of video discriminator')
-    p.add_argument('--resume', '-r', default='', help='Resume the training from snapshot')
+    p = argparse.ArgumentParser(description='MoCoGAN training on MI355X; flags and defaults of the reference train.py:21-47')
+    # (flags, type, default, help): names, short forms and defaults are the reference's interface, the texts are ours
+    reference_flags = [
+        (('--gpu', '-g'), int, -1, 'device index; this build always runs on an MI355X (the flag keeps old command lines valid)'),
+        (('--dataset',), str, 'data/dataset/train', 'root directory of the frame-directory dataset'),
+        (('--batchsize',), int, 100, 'clips per iteration (per GPU under torch.distributed.run)'),
+        (('--max_epoch',), int, 1000, 'stop after this many passes over the dataset'),
+        (('--save_name',), str, default_name, 'sub-directory of result/ and runs/ for log, snapshots and TensorBoard files'),
+        (('--display_interval',), int, 1, 'epochs between console reports'),
+        (('--snapshot_interval',), int, 10, 'epochs between .npz snapshots'),
+        (('--log_tensorboard_interval',), int, 10, 'epochs between TensorBoard sample videos'),
+        (('--num_gen_samples',), int, 36, 'videos per TensorBoard sample grid (a square number)'),
+        (('--dim_zc',), int, 50, 'size of the content code z_c'),
+        (('--dim_zm',), int, 10, 'size of the motion code z_m (GRU state)'),
+        (('--n_filters_gen',), int, 64, 'base width; as in the reference it is used for all three networks'),
+        (('--n_filters_idis',), int, 64, 'accepted and reported, not used (reference quirk)'),
+        (('--n_filters_vdis',), int, 64, 'accepted and reported, not used (reference quirk)'),
+        (('--resume', '-r'), str, '', 'trainer snapshot (.npz) to continue from'),
+    ]
+    for flags, typ, default, text in reference_flags:
+        p.add_argument(*flags, type=typ, default=default, help=text)
+    p.add_argument('--dataset_type', default='mug', choices=['mug', 'mnist', 'synthetic'],
+                   help="'synthetic' (this build only) needs no files")
+    p.add_argument('--model', default='normal', choices=['normal', 'cgan', 'infogan'], help='model variant')
     p.add_argument('--synthetic_size', type=int, default=256, help='clips in the synthetic dataset')
     p.add_argument('--seed', type=int, default=0)
     # MI355X-path options (no counterpart in the reference's train.py)
@@ -142,22 +148,15 @@ def main(argv=None):
         T.load_npz(args.resume, trainer)
 
     if rank == 0:
-        print('[ Training configuration ]')
-        print('# gpu: {}  (world size {})'.format(args.gpu, world))
-        print('# minibatch size: {}'.format(args.batchsize))
-        print('# max epoch: {}'.format(args.max_epoch))
-        print('# num batches: {}'.format(len(train_dataset) // args.batchsize))
-        print('# data size: {}'.format(len(train_dataset)))
-        print('# data shape: {}'.format(train_dataset[0][0].shape))
-        print('# num filters igen: {}'.format(nf))
-        print('# num filters idis: {}'.format(args.n_filters_idis))
-        print('# num filters vdis: {}'.format(args.n_filters_vdis))
-        print('# use noise: {}(sigma={})'.format(use_noise, noise_sigma))
-        print('# use label: {}'.format(use_label))
-        print('# snapshot interval: {}'.format(args.snapshot_interval))
-        print('# log tensorboard interval: {}'.format(args.log_tensorboard_interval))
-        print('# num generate samples: {}'.format(args.num_gen_samples))
-        print('')
+        # the reference's start-up banner (train.py:165-187), same lines and order
+        banner = (('gpu', '{}  (world size {})'.format(args.gpu, world)), ('minibatch size', args.batchsize),
+                  ('max epoch', args.max_epoch), ('num batches', len(train_dataset) // args.batchsize),
+                  ('data size', len(train_dataset)), ('data shape', train_dataset[0][0].shape),
+                  ('num filters igen', nf), ('num filters idis', args.n_filters_idis), ('num filters vdis', args.n_filters_vdis),
+                  ('use noise', '{}(sigma={})'.format(use_noise, noise_sigma)), ('use label', use_label),
+                  ('snapshot interval', args.snapshot_interval), ('log tensorboard interval', args.log_tensorboard_interval),
+                  ('num generate samples', args.num_gen_samples))
+        print('\n'.join(['[ Training configuration ]'] + ['# %s: %s' % kv for kv in banner]) + '\n')
     trainer.run()
     if rank == 0:
         T.save_npz(save_path / 'image_gen_epoch_fianl.npz', image_gen)     # (sic) train.py:190-192
