@@ -107,12 +107,16 @@ def main():
     ap.add_argument('--sync-bn', type=int, default=0, help='N > 1 only: 1 = synchronised BatchNorm (not the headline semantics)')
     ap.add_argument('--tiles', default='', help='JSON of tile choices to start from (e.g. for a profiler pass without tuning launches)')
     ap.add_argument('--save-tiles', default='', help='write the tile choices of this run to this JSON file')
-    ap.add_argument('--overlap', type=int, default=int(os.environ.get('MCG_OVERLAP', '1')),
-                    help='1 (default): the headline pass places the ImageDiscriminator update and the weight-gradient '
-                         'GEMMs on side HIP streams; 0: one stream throughout.  The roofline pass is always one-stream.')
+    ap.add_argument('--overlap', type=int, default=None,
+                    help='1: the headline pass places the ImageDiscriminator update and the weight-gradient GEMMs on side '
+                         'HIP streams; 0: one stream throughout.  Default: 1, except 0 for the bf16 mode at batch >= 128, where '
+                         'the step is dominated by bandwidth-bound passes that only contend (measured: 5178 vs 4768 clips/s '
+                         'at batch 256).  The roofline pass is always one-stream.')
     ap.add_argument('--cpu-sample-batch', type=int, default=4)
     ap.add_argument('--cpu-sample-steps', type=int, default=2)
     args = ap.parse_args()
+    if args.overlap is None:
+        args.overlap = int(os.environ.get('MCG_OVERLAP', '0' if (args.dtype == 'bf16' and args.batch >= 128) else '1'))
 
     if os.environ.get('MCG_DEBUG_HANG'):
         import faulthandler
