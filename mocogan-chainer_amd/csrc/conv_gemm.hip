@@ -338,6 +338,89 @@ struct WgradP {
     }
 };
 
+// ---------------- fully-connected layers with a real output width (G's dc1: 60 x 8192) ----------------
+// The same GEMM core with trivial addressing.  y[M][N] = x[M][K] w[N][K]^T (+ bias): both operands K-contiguous;
+// split over K (blockIdx.z) because M x N is only a handful of tiles.
+template <int BM, int BN, int BK>
+struct FcFpropP {
+    static constexpr bool A_KC = true, B_KC = true;
+    static constexpr int ORDER = 0;
+    static constexpr int NA = BM * BK / 4 / NTHREADS, NB = BN * BK / 4 / NTHREADS;
+    const float* x; const float* w; const float* bias; float* y;
+    int M, N, K, kchunk, zz;
+    u32 x_bytes, w_bytes;
+    __amdgpu_buffer_rsrc_t xr, wr;
+    u32 abase[NA], bbase[NB];
+
+    __device__ void init(int m0, int n0, int tid, int z) {
+        constexpr int KC4 = BK / 4, RSTEP = NTHREADS / KC4;
+        xr = make_srd(x, x_bytes); wr = make_srd(w, w_bytes);
+        zz = z;
+        const int ak = (tid % KC4) * 4;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) { int m = m0 + tid / KC4 + RSTEP * j; abase[j] = m < M ? (u32)(m * K + ak) * 4u : OOB; }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { int n = n0 + tid / KC4 + RSTEP * j; bbase[j] = n < N ? (u32)(n * K + ak) * 4u : OOB; }
+    }
+    __device__ int k_begin(int z) const { return z * kchunk; }
+    __device__ int k_end(int z) const { int e = (z + 1) * kchunk; return e < K ? e : K; }
+    __device__ int next_valid(int k0) const { return k0; }
+    __device__ void load_a(int k0, f32x4 (&r)[NA]) const {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) r[j] = bload(xr, abase[j] + (u32)k0 * 4u);
+    }
+    __device__ void load_b(int k0, f32x4 (&r)[NB]) const {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) r[j] = bload(wr, bbase[j] + (u32)k0 * 4u);
+    }
+    __device__ void store(int m, int n, float v) const {
+        if (m >= M || n >= N) return;
+        if (kchunk >= K) y[(long long)m * N + n] = v + (bias ? bias[n] : 0.f);
+        else atomicAdd(y + (long long)m * N + n, v + (bias && zz == 0 ? bias[n] : 0.f));
+    }
+};
+
+// dw[N][K] += sum_m y[m][n] x[m][k]: both operands have the reduction index m as their ROW (neither is K-contiguous),
+// split over m (blockIdx.z), fp32 atomics -- the structure of WgradP without the pixel gather.
+template <int BM, int BN, int BK>
+struct FcWgradP {
+    static constexpr bool A_KC = false, B_KC = false;
+    static constexpr int ORDER = 2;
+    static constexpr int NA = BM * BK / 4 / NTHREADS, NB = BN * BK / 4 / NTHREADS;
+    const float* x; const float* y; float* dw;
+    int M, N, K, chunk;                       // M rows to reduce; dw is [N][K]
+    u32 x_bytes, y_bytes;
+    __amdgpu_buffer_rsrc_t xr, yr;
+    u32 aoff, boff; int akrow[NA], bkrow[NB];
+
+    __device__ void init(int m0, int n0, int tid, int /*z*/) {
+        constexpr int AC4 = BM / 4, BC4 = BN / 4;
+        xr = make_srd(x, x_bytes); yr = make_srd(y, y_bytes);
+        const int an = m0 + (tid % AC4) * 4, bk = n0 + (tid % BC4) * 4;
+        aoff = an < N ? (u32)an * 4u : OOB;
+        boff = bk < K ? (u32)bk * 4u : OOB;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) akrow[j] = tid / AC4 + (NTHREADS / AC4) * j;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) bkrow[j] = tid / BC4 + (NTHREADS / BC4) * j;
+    }
+    __device__ int k_begin(int z) const { return z * chunk; }
+    __device__ int k_end(int z) const { int e = (z + 1) * chunk; return e < M ? e : M; }
+    __device__ int next_valid(int k0) const { return k0; }
+    // rows beyond M fall outside the buffers: the range check returns zeros
+    __device__ void load_a(int k0, f32x4 (&r)[NA]) const {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) r[j] = bload(yr, aoff + (u32)((k0 + akrow[j]) * N) * 4u);
+    }
+    __device__ void load_b(int k0, f32x4 (&r)[NB]) const {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) r[j] = bload(xr, boff + (u32)((k0 + bkrow[j]) * K) * 4u);
+    }
+    __device__ void store(int m, int n, float v) const {
+        if (m < N && n < K) atomicAdd(dw + (long long)m * K + n, v);
+    }
+};
+
 // ------------------------------------------------------------------------------------------
 // The GEMM core
 // ------------------------------------------------------------------------------------------
@@ -943,5 +1026,43 @@ extern "C" int mcg_conv_wgrad(const mcg_conv_geom* c, const float* x, const floa
     if (!t) t = (g.Co <= 64 || Kf <= 64) ? 3 : 1;
     const bool bk64 = bk ? bk == 64 : g.prec == MCG_PREC_BF16;
     MCG_DISPATCH(launch_wgrad, t, bk64, g.prec == MCG_PREC_BF16, g, x, y, dw, s);
+    return launch_status();
+}
+
+// ---- fully-connected layers on the GEMM core (called by mcg_fc_fprop / mcg_fc_wgrad in small_ops.hip when the
+// output width is large enough to fill MFMA tiles; not part of the public header) ----
+extern "C" int mcg_detail_fc_fprop_gemm(int M, int K, int N, const float* x, const float* w, const float* bias, float* y, void* stream) {
+    if ((K & 63) || (long long)M * K * 4 >= (1ll << 31) || (long long)N * K * 4 >= (1ll << 31)) return MCG_ERR_UNSUPPORTED;
+    constexpr int BM = 64, BN = 64, BK = 64;
+    FcFpropP<BM, BN, BK> p;
+    p.x = x; p.w = w; p.bias = bias; p.y = y; p.M = M; p.N = N; p.K = K;
+    p.x_bytes = (u32)((long long)M * K * 4); p.w_bytes = (u32)((long long)N * K * 4);
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN), ksteps = K / BK;
+    int splits = (512 + tiles - 1) / tiles;
+    if (splits > ksteps / 4) splits = ksteps / 4;
+    if (splits < 1) splits = 1;
+    p.kchunk = ((ksteps + splits - 1) / splits) * BK;
+    splits = (K + p.kchunk - 1) / p.kchunk;
+    hipStream_t s = (hipStream_t)stream;
+    if (splits > 1) (void)hipMemsetAsync(y, 0, (size_t)M * N * sizeof(float), s);
+    dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN, splits);
+    hipLaunchKernelGGL((gemm_kernel<FcFpropP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
+    return launch_status();
+}
+
+extern "C" int mcg_detail_fc_wgrad_gemm(int M, int K, int N, const float* x, const float* y, float* dw, void* stream) {
+    if ((K & 3) || (N & 3) || (long long)M * K * 4 >= (1ll << 31) || (long long)M * N * 4 >= (1ll << 31)) return MCG_ERR_UNSUPPORTED;
+    constexpr int BM = 64, BN = 64, BK = 32;
+    FcWgradP<BM, BN, BK> p;
+    p.x = x; p.y = y; p.dw = dw; p.M = M; p.N = N; p.K = K;
+    p.x_bytes = (u32)((long long)M * K * 4); p.y_bytes = (u32)((long long)M * N * 4);
+    const int tiles = ((N + BM - 1) / BM) * ((K + BN - 1) / BN), ksteps = (M + BK - 1) / BK;
+    int splits = (1024 + tiles - 1) / tiles;
+    if (splits > ksteps / 4) splits = ksteps / 4;
+    if (splits < 1) splits = 1;
+    p.chunk = ((ksteps + splits - 1) / splits) * BK;
+    splits = (M + p.chunk - 1) / p.chunk;
+    dim3 grid((N + BM - 1) / BM, (K + BN - 1) / BN, splits);
+    hipLaunchKernelGGL((gemm_kernel<FcWgradP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, (hipStream_t)stream, p);
     return launch_status();
 }

@@ -810,8 +810,16 @@ extern "C" int mcg_tanh_bwd_to_frames(int N, int T, int64_t frame_elems, const f
     return launch_status();
 }
 
+// conv_gemm.hip: the fully-connected layers with a real output width run on the MFMA GEMM core
+extern "C" int mcg_detail_fc_fprop_gemm(int M, int K, int N, const float* x, const float* w, const float* bias, float* y, void* stream);
+extern "C" int mcg_detail_fc_wgrad_gemm(int M, int K, int N, const float* x, const float* y, float* dw, void* stream);
+
 extern "C" int mcg_fc_fprop(int M, int K, int Co, const float* x, const float* w, const float* bias, float* y, void* stream) {
     if (!x || !w || !y || M <= 0 || K <= 0 || (K & 3) || Co <= 0) return MCG_ERR_BAD_ARG;
+    if (Co >= 16 && M >= 64) {                       // G's dc1 (60 x 8192): a GEMM, not 60 dot products per row
+        int st = mcg_detail_fc_fprop_gemm(M, K, Co, x, w, bias, y, stream);
+        if (st != MCG_ERR_UNSUPPORTED) return st;
+    }
     hipLaunchKernelGGL(fc_fprop_kernel, dim3(M, Co), dim3(NT), 0, (hipStream_t)stream, K, Co, x, w, bias, y);
     return launch_status();
 }
@@ -825,6 +833,10 @@ extern "C" int mcg_fc_dgrad(int M, int K, int Co, const float* y, const float* w
 
 extern "C" int mcg_fc_wgrad(int M, int K, int Co, const float* x, const float* y, float* dw, float* db, void* stream) {
     if (!x || !dw || !y || M <= 0 || K <= 0 || (K & 3) || Co <= 0) return MCG_ERR_BAD_ARG;
+    if (Co >= 16 && !(Co & 3) && M >= 64 && !db) {
+        int st = mcg_detail_fc_wgrad_gemm(M, K, Co, x, y, dw, stream);
+        if (st != MCG_ERR_UNSUPPORTED) return st;
+    }
     hipLaunchKernelGGL(fc_wgrad_kernel, dim3((K / 4 + NT - 1) / NT, Co), dim3(NT), 0, (hipStream_t)stream, M, K, Co, x, y, dw, db);
     return launch_status();
 }

@@ -237,7 +237,8 @@ def test_conv_rejects_bad_geometry(hl):
         hl.conv_fprop(hl.make_geom(1, 4, 16, 16, 4, 64, 4), torch.zeros(1), x, None, x)   # host tensor
 
 
-@pytest.mark.parametrize("M,K,Co", [(4, 512, 1), (3, 2048, 7), (32, 1024, 60)])
+@pytest.mark.parametrize("M,K,Co", [(4, 512, 1), (3, 2048, 7), (32, 1024, 60),
+                                    (512, 8192, 60), (100, 1024, 60), (77, 2048, 20)])    # M >= 64, Co >= 16: the MFMA GEMM path
 def test_fc_ops(hl, M, K, Co):
     rng = np.random.RandomState(M * 7 + Co)
     x, w, b, gy = rng.randn(M, K), rng.randn(Co, K) * 0.05, rng.randn(Co), rng.randn(M, Co)
