@@ -49,6 +49,24 @@ def dv_conv_flops_per_step(batch):
     return batch * (fwd + wgrad + dgrad), batch * fwd, batch * wgrad, batch * dgrad
 
 
+def dv_conv_algorithmic_bytes_per_step(batch):
+    """Bytes the D_V conv family has to move if every tensor crossed HBM exactly once per launch (fp32):
+    fprop reads x_l and writes y_l; wgrad reads x_l and g_l and writes dW; dgrad reads g_l and writes gx_l."""
+    chans = [4, 64, 128, 256, 512]
+    t, h = 16, 64
+    x_b, y_b, w_b = [], [], []
+    for l in range(4):
+        to, ho = t - 3, h // 2
+        x_b.append(4.0 * t * h * h * chans[l])
+        y_b.append(4.0 * to * ho * ho * chans[l + 1])
+        w_b.append(4.0 * 64 * chans[l] * chans[l + 1])
+        t, h = to, ho
+    fprop = 2 * batch * (sum(x_b) + sum(y_b)) + sum(w_b)
+    wgrad = 2 * batch * (sum(x_b) + sum(y_b)) + sum(w_b)
+    dgrad = 2 * batch * (sum(y_b[1:]) + sum(x_b[1:])) + batch * (sum(y_b) + sum(x_b)) + 2 * sum(w_b)
+    return fprop + wgrad + dgrad
+
+
 def pmc_traffic(batch):
     """HBM-side traffic of the D_V conv launches of one step, from the committed rocprofv3 --pmc summary
     (FETCH_SIZE / WRITE_SIZE cannot be read from inside the process; tools/pmc_traffic.py documents the
@@ -232,7 +250,7 @@ def main():
                        "parallelism": "dp%d" % world, "side_streams": bool(args.overlap),
                        "sync_bn": bool(args.sync_bn)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic, "traffic_unit": "bytes per step (memory side of L2, incl. Infinity-Cache hits)",
+                         "frac": achieved / peak, "traffic": traffic, "algorithmic_bytes": dv_conv_algorithmic_bytes_per_step(B), "traffic_unit": "bytes per step (memory side of L2, incl. Infinity-Cache hits)",
                          "traffic_source": traffic_src,
                          "kernel": "VideoDiscriminator Conv3d implicit-GEMM family (%s<FpropP|DgradP|WgradP>), "
                                    % ("gemm_kernel" if args.dtype == 'f32' else "gemm_bf16_kernel") +

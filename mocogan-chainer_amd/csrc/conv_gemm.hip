@@ -733,7 +733,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(P p) {
 // lane c4 with the 4 channels of output pixel (class = c4>>2, position = c4&3): one 16-byte store.
 // All KT*16 taps x 64 x 4 weights sit in LDS as [tap][j][c4] float4 (conflict-free ds_read_b128).
 // ------------------------------------------------------------------------------------------
-constexpr int C4_RUNS_PER_WAVE = 4;
+#ifndef MCG_C4_RUNS
+#define MCG_C4_RUNS 4
+#endif
+constexpr int C4_RUNS_PER_WAVE = MCG_C4_RUNS;
 
 template <int KT>
 __global__ __launch_bounds__(NTHREADS) void dgrad_c4_kernel(Geom g, const float* __restrict__ y, const float* __restrict__ w,
