@@ -5,6 +5,7 @@ device pointers to a hand-written gfx950 kernel.  There is no fallback: if the l
 missing or a status is non-zero this module raises.
 """
 import ctypes as C
+import json
 import os
 
 import torch
@@ -190,9 +191,18 @@ _autotune = False
 _tile_cache = {}
 
 
-def set_autotune(on):
+_PRETUNED = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tuned_tiles_mi355x.json')
+
+
+def set_autotune(on, use_pretuned=True):
+    """on: time the tile candidates at the first launch of every (pass, geometry) not known yet.  use_pretuned: start
+    from the table shipped with the package -- the choices this tuner made on an MI355X for the reference's layer
+    geometries at batch 32 per GPU (tuned_tiles_mi355x.json); anything else is still tuned on first use."""
     global _autotune
     _autotune = bool(on)
+    if on and use_pretuned and os.path.exists(_PRETUNED) and os.environ.get('MCG_NO_PRETUNED') != '1':
+        for k, v in json.load(open(_PRETUNED)):
+            _tile_cache.setdefault(tuple(k), int(v))
 
 
 def tile_choices():

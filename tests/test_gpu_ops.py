@@ -174,7 +174,7 @@ def test_conv_tile_field_and_autotune(hl):
     with pytest.raises(hl.McgError):
         hl.conv_fprop(g, xd, wd, None, yd)
 
-    hl.set_autotune(True)
+    hl.set_autotune(True, use_pretuned=False)
     try:
         g = hl.make_geom(N, Ti, H, H, Ci, Co, kt)
         before = len(hl.tile_choices())
