@@ -64,7 +64,8 @@ typedef struct mcg_conv_geom {
                                 * +100 / +200 also fixes the K-step depth to 32 / 64; +1000 / +2000
                                 * makes mcg_conv_fprop / mcg_conv_dgrad split the K range over 2 / 4 blocks per tile
                                 * (partial tiles are added atomically onto a cleared output; for long-K layers with
-                                * few tiles; ignored by dgrad with tanh or a strided, non-accumulating x).  A pure
+                                * few tiles; ignored by dgrad with tanh or a strided, non-accumulating x); for mcg_conv_wgrad, which always
+                                * splits over pixels, +1000 / +2000 doubles / halves the number of splits.  A pure
                                 * performance knob (the caller may time the candidates once per geometry and
                                 * keep the winner, as mocogan-chainer_amd/hiplib.py does); results are the same
                                 * up to fp32 summation order. */

@@ -916,7 +916,9 @@ void launch_wgrad(const Geom& g, const float* x, const float* y, float* dw, hipS
     p.Mpix = g.N * g.To * g.Ho * g.Wo; p.Kf = g.taps * g.Ci;
     int tiles = ((g.Co + BM - 1) / BM) * ((p.Kf + BN - 1) / BN);
     int ksteps = (p.Mpix + BK - 1) / BK;
-    int splits = (1024 + tiles - 1) / tiles;            // aim at ~4 blocks per CU
+    // aim at ~4 blocks per CU; mcg_conv_geom.tile + 1000 / + 2000 doubles / halves that target
+    const int target = g.ksplit == 2 ? 2048 : (g.ksplit == 4 ? 512 : 1024);
+    int splits = (target + tiles - 1) / tiles;
     if (splits > ksteps / 4) splits = ksteps / 4;        // keep >= 4 K-steps per block
     if (splits < 1) splits = 1;
     int steps_per = (ksteps + splits - 1) / splits;

@@ -169,6 +169,9 @@ def test_conv_tile_field_and_autotune(hl):
         assert rel_l2(lay.act_from_dev(gxd, Ci), gx_ref) < BWD_TOL, code
         hl.conv_dgrad(g, gyd, wd, None, gxd, accumulate=True)
         assert rel_l2(lay.act_from_dev(gxd, Ci), 2 * gx_ref) < BWD_TOL, code
+        dwd = torch.zeros_like(wd)
+        hl.conv_wgrad(g, xd, gyd, dwd)                               # wgrad: 1xxx / 2xxx = more / fewer pixel splits
+        assert rel_l2(lay.conv_w_from_dev(dwd, Ci, 3), gW_ref) < BWD_TOL, code
     g = hl.make_geom(N, Ti, H, H, Ci, Co, kt)
     g.tile = 7
     with pytest.raises(hl.McgError):

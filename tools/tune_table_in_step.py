@@ -73,6 +73,8 @@ def main():
             cands = list(hl.TILE_CANDIDATES)
             if k[0] in ('fprop', 'dgrad') and k[5] > 4:
                 cands += list(hl.FPROP_SPLIT_CANDIDATES)
+            if k[0] == 'wgrad':                             # more / fewer pixel splits around the current tile
+                cands += [1000 + c for c in hl.TILE_CANDIDATES if c] + [2000 + c for c in hl.TILE_CANDIDATES if c]
             cur = cache[k]
             best_c, best_t = cur, base
             for c in cands:
