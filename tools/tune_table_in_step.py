@@ -25,12 +25,14 @@ def main():
     ap.add_argument('--reps', type=int, default=3)
     ap.add_argument('--sweeps', type=int, default=1)
     ap.add_argument('--min-gain', type=float, default=0.002, help='relative iteration-time gain needed to switch')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'])
+    ap.add_argument('--overlap', type=int, default=1)
     ap.add_argument('--out', required=True)
     args = ap.parse_args()
     hl.load()
     hl.set_autotune(True)
     gen, di, dv = mstep.make_models('normal', num_labels=6, seed=0)
-    ts = mstep.TrainStep('normal', gen, di, dv, seed=1234, overlap=True)
+    ts = mstep.TrainStep('normal', gen, di, dv, seed=1234, overlap=bool(args.overlap), precision=args.dtype)
     g = torch.Generator(device='cuda'); g.manual_seed(0)
     x = torch.rand((args.batch, 3, 16, 64, 64), device='cuda', generator=g) * 2 - 1
     t = torch.randint(0, 6, (args.batch,), device='cuda', dtype=torch.int32, generator=g)
@@ -54,7 +56,7 @@ def main():
     for _ in range(4):
         ts.run(x, t)
     timing = hl.timing_end()
-    ts.set_overlap(True)
+    ts.set_overlap(bool(args.overlap))
     for _ in range(3):
         ts.run(x, t)
 
@@ -63,7 +65,8 @@ def main():
             if ' N=' in name and name.split('.')[1].split()[0] == k[0] and ('N=%d T=%d H=%d Ci=%d Co=%d' % (k[1], k[2], k[3], k[5], k[6])) in name:
                 return ms
         return 0.0
-    keys = sorted(cache, key=key_cost, reverse=True)
+    prec = hl.PRECISIONS[args.dtype]
+    keys = sorted([k for k in cache if k[9] == prec and k[1] in (args.batch, 2 * args.batch, 16 * args.batch)], key=key_cost, reverse=True)
     base = measure()
     print('baseline %.3f ms/iteration, %d geometries' % (base, len(keys)), flush=True)
     for sweep in range(args.sweeps):
