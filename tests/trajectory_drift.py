@@ -3,7 +3,7 @@
 and see the same randomness every iteration, but (unlike the teacher-forced parity tests) the device keeps its own
 parameters and Adam state from iteration to iteration.  Prints one line per iteration: |loss differences|, rel-L2 of the
 generated clip, rel-L2 of each network's parameters, and the relative size of the parameter UPDATE error.
-    python tools/trajectory_drift.py [--iters 20] [--nf 8] [--n 4] [--model infogan]"""
+    python tests/trajectory_drift.py [--iters 20] [--nf 8] [--n 4] [--model infogan]"""
 import argparse
 import os
 import sys
@@ -11,7 +11,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # repo root (this file lives in tests/)
 sys.path.insert(0, ROOT)
 from oracle import net as onet, updater as oupd                  # noqa: E402
 import mocogan_chainer_amd.hiplib as hl                           # noqa: E402
