@@ -150,3 +150,22 @@ def test_optimizer_objects_carry_the_reference_hyperparameters():
     h = opt.hyper()
     assert (h.alpha, h.beta1, h.beta2, h.eps, h.weight_decay) == (2e-4, 5e-5, 0.999, 1e-8, 1e-5)
     assert opt.t == 0
+
+
+def test_shipped_tile_table_is_well_formed():
+    """mocogan-chainer_amd/tuned_tiles_mi355x.json: [[key, code], ...] with keys as hiplib._geom_key builds them and
+    codes the C ABI accepts (mcg_conv_geom.tile)."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'mocogan-chainer_amd', 'tuned_tiles_mi355x.json')
+    table = json.load(open(path))
+    assert len(table) >= 40
+    seen = set()
+    for key, code in table:
+        assert key[0] in ('fprop', 'dgrad', 'wgrad') and all(isinstance(v, int) for v in key[1:]), key
+        assert len(key) == (12 if key[0] == 'dgrad' else 10), key          # dgrad keys carry (act, accumulate)
+        kind, N, Ti, Hi, Wi, Ci, Co, kt, perm, prec = key[:10]
+        assert Hi == Wi and Hi in (8, 16, 32, 64) and kt in (1, 4) and prec in (0, 1) and Ci % 4 == 0 and N > 0
+        assert isinstance(code, int) and 0 <= code % 100 <= 5 and (code // 100) % 10 <= 2 and code // 1000 <= 2, code
+        assert tuple(key) not in seen
+        seen.add(tuple(key))
