@@ -8,7 +8,8 @@ SOURCES = ["csrc/conv_gemm.hip", "csrc/small_ops.hip"]
 
 
 def lib_path():
-    return os.path.join(HERE, "lib", "libmocogan_hip.so")
+    """In-tree library; MCG_LIB_PATH points the binding at another build of the same sources (A/B timing)."""
+    return os.environ.get("MCG_LIB_PATH") or os.path.join(HERE, "lib", "libmocogan_hip.so")
 
 
 def _stale():

@@ -107,12 +107,25 @@ struct FpropP {
     u32 amask[NA];      // bit kh*4+kw set <=> that tap of the row reads inside the image
     int ak;             // this thread's k offset inside a K-step (c4*4)
     u32 bbase[NB];      // byte offset of the filter row, OOB for rows beyond Co
+    int krot;           // 3-D layers: the K axis is visited rotated by ((-to) & 3) temporal taps, to = the tile's first
+                        // output frame.  The four tiles that need input frame F (to = F-3..F, neighbours on one XCD,
+                        // running in lockstep) then all read it in the same quarter of their K loops, so the frame
+                        // is fetched into that XCD's L2 once instead of once per tile (it does not survive there
+                        // for the quarter of a tile's run time that otherwise separates the four uses).
 
     __device__ void init(int m0, int n0, int tid, int z) {
         constexpr int KC4 = BK / 4, RSTEP = NTHREADS / KC4;        // float4 slots per tile row, rows per pass
         xr = make_srd(x, g.x_bytes); wr = make_srd(w, g.w_bytes);
         zz = z;
         ak = (tid % KC4) * 4;
+        krot = 0;
+#ifndef MCG_NO_KROT          // (timing A/B only)
+        if (g.kt == 4) {
+            const int q0 = m0 >> (g.lgWo + g.lgHo);
+            const int to0 = q0 - div_To(g, q0) * g.To;
+            krot = ((4 - (to0 & 3)) & 3) * 16 * g.Ci;
+        }
+#endif
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             int m = m0 + tid / KC4 + RSTEP * j;
@@ -139,8 +152,9 @@ struct FpropP {
     __device__ int k_begin(int z) const { return z * kchunk; }
     __device__ int k_end(int z) const { int e = (z + 1) * kchunk; return e < K ? e : K; }
     __device__ int next_valid(int k0) const { return k0; }
+    __device__ int rotated(int k0) const { int k = k0 + krot; return k >= K ? k - K : k; }     // whole K-steps stay inside one tap
     __device__ void load_a(int k0, f32x4 (&r)[NA]) const {
-        int k = k0 + ak;
+        int k = rotated(k0) + ak;
         int tap, ci;
         divmod_c(k, g.Ci, g.lgCi, tap, ci);
         int sp = tap & 15;
@@ -149,8 +163,9 @@ struct FpropP {
         for (int j = 0; j < NA; ++j) r[j] = bload(xr, (amask[j] >> sp) & 1u ? (u32)(abase[j] + off) : OOB);
     }
     __device__ void load_b(int k0, f32x4 (&r)[NB]) const {
+        const u32 kb = (u32)rotated(k0) * 4u;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) r[j] = bload(wr, bbase[j] + (u32)k0 * 4u);
+        for (int j = 0; j < NB; ++j) r[j] = bload(wr, bbase[j] + kb);
     }
     __device__ void store(int m, int n, float v) const {
         if (m >= M || n >= g.Co) return;
@@ -170,6 +185,8 @@ struct DgradP {
     int M, K, act, accumulate;   // M = N*Ti*Ho*Wo pixels of ONE parity class; K = kt*4*Co
     int ph, pw;
     int kchunk, zsplit;          // split-K as in FpropP: blockIdx.z = split * 4 + parity class
+    int krot;                    // as in FpropP: the K axis is visited rotated by (t & 3) temporal taps, so the tiles
+                                 // t = F..F+3 that need y frame F read it in the same quarter of their K loops
     __amdgpu_buffer_rsrc_t yr, wr;
     int abase[NA];      // BYTE offset of y[n][t][h2+ph][w2+pw][0]  (tap offsets are subtracted)
     u32 amask[NA];      // bit a*4+bh*2+bw set <=> that sub-filter tap of the row reads inside y
@@ -191,6 +208,10 @@ struct DgradP {
             tmin = div_N(g, m0 >> (g.lgWo + g.lgHo));
             tmax = div_N(g, mlast >> (g.lgWo + g.lgHo));
         }
+        krot = 0;
+#ifndef MCG_NO_KROT
+        if (g.kt == 4 && (4 * g.Co) % BK == 0) krot = (tmin & 3) * 4 * g.Co;      // whole K-steps must stay inside one temporal tap
+#endif
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             int m = m0 + tid / KC4 + RSTEP * j;
@@ -228,8 +249,9 @@ struct DgradP {
 #endif
         while (k0 < K) {
             int q0, q1, r_;
-            divmod_c(k0, g.Co, g.lgCo, q0, r_);
-            divmod_c(k0 + BK - 1, g.Co, g.lgCo, q1, r_);
+            const int kr = rotated(k0);
+            divmod_c(kr, g.Co, g.lgCo, q0, r_);
+            divmod_c(kr + BK - 1, g.Co, g.lgCo, q1, r_);
             int a_lo = q0 >> 2, a_hi = q1 >> 2;
             bool dead = a_lo > tmax || a_hi <= tmin - g.To;       // every t - a < 0, or every t - a >= To
             if (!dead) break;
@@ -237,15 +259,17 @@ struct DgradP {
         }
         return k0;
     }
+    __device__ int rotated(int k0) const { int k = k0 + krot; return k >= K ? k - K : k; }     // K-steps never straddle the wrap
     __device__ void load_a(int k0, f32x4 (&r)[NA]) const {
-        int k = k0 + ak;
+        int k = rotated(k0) + ak;
         int ts, co;
         divmod_c(k, g.Co, g.lgCo, ts, co);
         int off = (co - (((ts >> 2) * g.Ho + ((ts >> 1) & 1)) * g.Wo + (ts & 1)) * g.Co) * 4;
 #pragma unroll
         for (int j = 0; j < NA; ++j) r[j] = bload(yr, (amask[j] >> ts) & 1u ? (u32)(abase[j] + off) : OOB);
     }
-    __device__ void load_b(int k0, f32x4 (&r)[NB]) const {
+    __device__ void load_b(int k0r, f32x4 (&r)[NB]) const {
+        const int k0 = rotated(k0r);
         if (g.lgCo >= 0 && (g.Co & (BK - 1)) == 0) {
             // every k of this K-step shares one sub-filter tap: the tap part of the address is wave-uniform
             int ts = k0 >> g.lgCo, co0 = k0 & (g.Co - 1);

@@ -48,6 +48,8 @@ CONV_CASES = [
     (5, 1, 4, 32, 256, 1),     # tiny spatial extent, M not a multiple of the tile
     (2, 5, 32, 3, 64, 4),      # Ci = 4, Co = 64, Wo % 16 == 0: the VALU dgrad kernel (tile 0), 3-D
     (3, 1, 32, 3, 64, 1),      # the same, 2-D
+    (2, 6, 16, 8, 8, 4),       # narrow 3-D layer (n_filters = 4 nets of the step tests): K-steps straddle temporal taps
+    (2, 9, 8, 16, 20, 4),      # Co not a power of two, 3-D, every temporal phase t & 3
 ]
 
 
