@@ -185,6 +185,7 @@ struct DgradP {
     int M, K, act, accumulate;   // M = N*Ti*Ho*Wo pixels of ONE parity class; K = kt*4*Co
     int ph, pw;
     int kchunk, zsplit;          // split-K as in FpropP: blockIdx.z = split * 4 + parity class
+    int gxm, gyn, tiles8;        // M tiles, N tiles, ceil(gxm * gyn / 8): the 1-D grid is decoded in gemm_kernel
     int krot;                    // as in FpropP: the K axis is visited rotated by (t & 3) temporal taps, so the tiles
                                  // t = F..F+3 that need y frame F read it in the same quarter of their K loops
     __amdgpu_buffer_rsrc_t yr, wr;
@@ -479,10 +480,20 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(P p) {
         const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
         if (P::ORDER == 0) {            // fprop: N tile fastest, then M tile (same activations, next filters), then K split
             by = t % gy; bx = (t / gy) % gx; bz = t / (gy * gx);
-        } else if (P::ORDER == 1) {     // dgrad: dispatch order.  Its rows are time-major and blocks near the temporal
-            // boundary skip most K-steps, so a contiguous range per XCD would give the XCDs unequal work
-            // (measured: dc2 0.81 -> 0.97 ms with a contiguous mapping); round-robin interleaves light and heavy.
+        } else if constexpr (P::ORDER == 1) {
+            // dgrad: (M tile, N tile) pairs are dealt round-robin over the XCDs in dispatch order -- rows are time-major
+            // and blocks near the temporal boundary skip most K-steps, so a contiguous range per XCD would give the
+            // XCDs unequal work (measured: dc2 0.81 -> 0.97 ms) -- and the FOUR PARITY CLASSES of a pair, which read
+            // the same y rows at the same K phase, are consecutive workgroups of one XCD (1-D grid, launch_dgrad).
+#ifndef MCG_NO_CLASS_ADJ
+            const int Lb = blockIdx.x, xq = Lb & 7, qq = Lb >> 3;
+            const int cls = qq & 3, rr = qq >> 2;
+            const int split = rr / p.tiles8, tl = (rr - split * p.tiles8) * 8 + xq;
+            if (tl >= p.gxm * p.gyn) return;                       // padding of the tile count to a multiple of 8
+            by = tl % p.gyn; bx = tl / p.gyn; bz = split * 4 + cls;
+#else
             bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+#endif
         } else {                        // wgrad: all (Co, tap*Ci) tiles of one pixel chunk together
             bx = t % gx; by = (t / gx) % gy; bz = t / (gx * gy);
         }
@@ -654,7 +665,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(P p) {
         const int xcd = L & 7, q = nwg >> 3, r = nwg & 7;
         const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
         if (P::ORDER == 0) { by = t % gy; bx = (t / gy) % gx; bz = t / (gy * gx); }
-        else if (P::ORDER == 1) { bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z; }
+        else if constexpr (P::ORDER == 1) {
+#ifndef MCG_NO_CLASS_ADJ
+            const int Lb = blockIdx.x, xq = Lb & 7, qq = Lb >> 3;
+            const int cls = qq & 3, rr = qq >> 2;
+            const int split = rr / p.tiles8, tl = (rr - split * p.tiles8) * 8 + xq;
+            if (tl >= p.gxm * p.gyn) return;
+            by = tl % p.gyn; bx = tl / p.gyn; bz = split * 4 + cls;
+#else
+            bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+#endif
+        }
         else { bx = t % gx; by = (t / gx) % gy; bz = t / (gx * gy); }
     }
     const int m0 = bx * BM, n0 = by * BN;
@@ -928,7 +949,12 @@ void launch_dgrad(const Geom& g, const float* y, const float* w, const float* bi
     p.kchunk = ((ksteps + splits - 1) / splits) * BK;
     splits = (p.K + p.kchunk - 1) / p.kchunk;
     if (splits > 1 && !acc) (void)hipMemsetAsync(x, 0, (size_t)g.N * frame * sizeof(float), s);
-    dim3 grid((p.M + BM - 1) / BM, (g.Ci + BN - 1) / BN, 4 * splits);
+    p.gxm = (p.M + BM - 1) / BM; p.gyn = (g.Ci + BN - 1) / BN; p.tiles8 = (p.gxm * p.gyn + 7) / 8;
+#ifndef MCG_NO_CLASS_ADJ
+    dim3 grid(8 * p.tiles8 * 4 * splits, 1, 1);
+#else
+    dim3 grid(p.gxm, p.gyn, 4 * splits);
+#endif
     if (BF) hipLaunchKernelGGL((gemm_bf16_kernel<DgradP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
     else hipLaunchKernelGGL((gemm_kernel<DgradP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
 }
