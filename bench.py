@@ -241,7 +241,7 @@ def main():
         cfg_name = "configs[2]" if (args.dtype == 'bf16' and B == 256) else "configs[1]" if (args.dtype == 'f32' and B == 32) else \
             "off-list variant of configs[1]"
         out = {
-            "metric": "training clips/sec (16x3x64x64)", "value": value, "unit": "clips/s", "n_gpus": world,
+            "metric": "training clips/sec (16\u00d73\u00d764\u00d764)", "value": value, "unit": "clips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic" + (" (single-device rehearsal)" if rehearsal else ""),
             "config": {"workload": "MUG-shape synthetic (B,3,16,64,64) U(-1,1), one update_core iteration per step "
@@ -250,7 +250,7 @@ def main():
                        "parallelism": "dp%d" % world, "side_streams": bool(args.overlap),
                        "sync_bn": bool(args.sync_bn)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic, "algorithmic_bytes": dv_conv_algorithmic_bytes_per_step(B), "traffic_unit": "bytes per step (memory side of L2, incl. Infinity-Cache hits)",
+                         "frac": achieved / peak, "dv_conv3d_mfma_util_pct": 100.0 * achieved / peak, "traffic": traffic, "algorithmic_bytes": dv_conv_algorithmic_bytes_per_step(B), "traffic_unit": "bytes per step (memory side of L2, incl. Infinity-Cache hits)",
                          "traffic_source": traffic_src,
                          "kernel": "VideoDiscriminator Conv3d implicit-GEMM family (%s<FpropP|DgradP|WgradP>), "
                                    % ("gemm_kernel" if args.dtype == 'f32' else "gemm_bf16_kernel") +
