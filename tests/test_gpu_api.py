@@ -191,3 +191,19 @@ def test_prefetching_loader_feeds_the_updater(tmp_path, monkeypatch):
                      '--n_filters_gen', '8', '--save_name', 'pf', '--loader_workers', '2', '--snapshot_interval', '5'])
     assert tr.updater.iteration == 4 and tr.updater.epoch == 2
     tr.updater.get_iterator('main').close()
+
+
+def test_train_on_a_moving_mnist_file(tmp_path, monkeypatch):
+    """BASELINE configs[0] plumbing: --dataset_type mnist reads the (T, N, 64, 64) uint8 .npy of Moving MNIST, writes the
+    frame directories the reference writes (datasets.py:124-139), and trains label-free (dim_zl = 0) on 16-frame crops."""
+    import train
+    rng = np.random.RandomState(0)
+    np.save(tmp_path / 'mnist_test_seq.npy', rng.randint(0, 255, (20, 6, 64, 64)).astype(np.uint8))
+    monkeypatch.chdir(tmp_path)
+    tr = train.main(['--dataset_type', 'mnist', '--dataset', str(tmp_path / 'mnist_test_seq.npy'), '--batchsize', '3', '--max_epoch', '2',
+                     '--n_filters_gen', '8', '--save_name', 'mm', '--snapshot_interval', '5'])
+    assert tr.updater.iteration == 4 and tr.updater.epoch == 2
+    assert tr.updater.image_gen.dim_zl == 0
+    frames = sorted((tmp_path / 'data' / 'dataset' / 'moving_mnist' / 'preprocessed' / '00000').glob('*.jpg'))
+    assert len(frames) == 20
+    assert all(np.isfinite(v) for v in tr.updater.observation.values())
