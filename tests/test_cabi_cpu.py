@@ -107,3 +107,15 @@ def test_adam_hyper_matches_reference_settings():
         assert np.isclose(h.lr(t), oupd.ADAM_ALPHA * np.sqrt(1 - oupd.ADAM_BETA2 ** t) / (1 - oupd.ADAM_BETA1 ** t), rtol=1e-15)
     with pytest.raises(ValueError):
         step.make_models('cgan', num_labels=0, device='cpu')
+
+
+def test_missing_library_fails_loudly():
+    """No CPU fallback: with the shared library absent the binding raises instead of computing something else."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import mocogan_chainer_amd.hiplib as hl\n"
+            "try:\n    hl.load()\nexcept hl.McgError as e:\n    print('RAISED', 'no CPU fallback' in str(e))\n" % ROOT)
+    env = dict(os.environ, MCG_LIB_PATH='/nonexistent/libmocogan_hip.so')
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, timeout=300)
+    assert 'RAISED True' in r.stdout, r.stdout + r.stderr
