@@ -71,42 +71,118 @@ def pmc_traffic(batch):
     """HBM-side traffic of the D_V conv launches of one step, from the committed rocprofv3 --pmc summary
     (FETCH_SIZE / WRITE_SIZE cannot be read from inside the process; tools/pmc_traffic.py documents the
     collection).  Scaled linearly from the profiled batch.  Returns (bytes_per_step | None, source)."""
-    path = os.path.join(ROOT, 'profiles', 'r01_dv_conv_traffic.json')
-    try:
-        d = json.load(open(path))
-        return d['dv_conv_hbm_bytes_per_step'] * batch / d['batch'], 'profiles/r01_dv_conv_traffic.json (PMC, batch %d)' % d['batch']
-    except Exception:
-        return None, None
+    for name in ('r02_dv_conv_traffic.json', 'r01_dv_conv_traffic.json'):          # newest collection first
+        try:
+            d = json.load(open(os.path.join(ROOT, 'profiles', name)))
+            return d['dv_conv_hbm_bytes_per_step'] * batch / d['batch'], 'profiles/%s (PMC, batch %d)' % (name, d['batch'])
+        except Exception:
+            continue
+    return None, None
 
 
-def cpu_baseline(sample_batch, steps):
-    """Times the fp32 NumPy port (oracle/) on a bounded sample: `steps` iterations at batch
-    `sample_batch`, full width.  Returns the JSON object."""
+def _cpu_time_shape(channels, dim_zl, batch, warmup, steps):
+    """median seconds per update_core iteration of the fp32 NumPy port at one input shape"""
     import numpy as np
     from oracle import net as onet, updater as oupd
+    rng = np.random.RandomState(0)
+    gen = onet.init_generator(rng, dim_zl=dim_zl, out_channels=channels)
+    di = onet.init_discriminator(rng, 2, channels, 1)
+    dv = onet.init_discriminator(rng, 3, channels, 1)
+    og, oi, ov = (oupd.new_adam_state(q) for q in (gen, di, dv))
+    x = rng.uniform(-1, 1, (batch, channels, 16, 64, 64)).astype(np.float32)
+    t_real = rng.randint(0, dim_zl, batch) if dim_zl else None
+    times = []
+    for s in range(warmup + steps):
+        rnd = oupd.draw_step_randomness(rng, 'normal', batch, channels, dim_zl=dim_zl)
+        t0 = time.time()
+        oupd.update_core('normal', gen, di, dv, og, oi, ov, x, t_real, rnd, dim_zl=dim_zl)
+        if s >= warmup:
+            times.append(time.time() - t0)
+    times.sort()
+    return times[len(times) // 2], times
+
+
+def cpu_baseline(batch, warmup, steps):
+    """the fp32 NumPy port (oracle/: im2col + BLAS sgemm, the algorithm class of the
+    Chainer CPU path) timed on this host's cores at batch `batch`, `warmup` untimed + `steps` timed iterations,
+    median -- at the MUG shape 16x3x64x64 (C2; `value`) and at the Moving-MNIST shape 16x1x64x64 (C1)."""
     try:
         from threadpoolctl import threadpool_info
         threads = max([i.get('num_threads', 1) for i in threadpool_info()] or [1])
     except Exception:
         threads = os.cpu_count()
-    rng = np.random.RandomState(0)
-    gen = onet.init_generator(rng, dim_zl=6)
-    di = onet.init_discriminator(rng, 2, 3, 1)
-    dv = onet.init_discriminator(rng, 3, 3, 1)
-    og, oi, ov = (oupd.new_adam_state(q) for q in (gen, di, dv))
-    x = rng.uniform(-1, 1, (sample_batch, 3, 16, 64, 64)).astype(np.float32)
-    t_real = rng.randint(0, 6, sample_batch)
-    times = []
-    for s in range(steps):
-        rnd = oupd.draw_step_randomness(rng, 'normal', sample_batch, dim_zl=6)
-        t0 = time.time()
-        oupd.update_core('normal', gen, di, dv, og, oi, ov, x, t_real, rnd, dim_zl=6)
-        times.append(time.time() - t0)
-    best = min(times)
-    return {"value": sample_batch / best, "unit": "clips/s", "cores": int(threads), "kind": "port",
-            "sample": "%d iteration(s) of update_core at batch %d, full width (n_filters=64), fp32 NumPy "
-                      "im2col+BLAS restatement of the Chainer CPU path; best iteration %.2f s; host has %d cpus"
-                      % (steps, sample_batch, best, os.cpu_count())}
+    med3, t3 = _cpu_time_shape(3, 6, batch, warmup, steps)
+    med1, t1 = _cpu_time_shape(1, 0, batch, warmup, steps)
+    return {"value": batch / med3, "unit": "clips/s", "cores": int(threads), "kind": "port",
+            "blas_threads": int(threads), "host_cpus": os.cpu_count(),
+            "c1_moving_mnist_shape": {"value": batch / med1, "unit": "clips/s", "shape": "16x1x64x64", "batch": batch,
+                                      "median_s_per_iteration": med1},
+            "sample": "CPU restatement of the Chainer-CPU algorithm (not Chainer itself): update_core at batch %d, full "
+                      "width (n_filters=64), fp32 NumPy im2col+BLAS; %d warm-up + %d timed iterations, median "
+                      "%.2f s (16x3x64x64, min %.2f max %.2f); the 16x1x64x64 shape under c1_moving_mnist_shape; "
+                      "%d BLAS threads on a %d-cpu host"
+                      % (batch, warmup, steps, med3, t3[0], t3[-1], int(threads), os.cpu_count())}
+
+
+def self_launch(n, argv):
+    """Parent of `bench.py --gpus N` (N > 1, no WORLD_SIZE): starts N ranks with torch.distributed.run as a CHILD
+    process (never exec: nothing here has initialised the GPU, and nothing will), relays the one JSON line of rank 0
+    and returns the child's exit code.  Fewer visible GPUs than ranks is an error, not a hang."""
+    import socket
+    import subprocess
+    rehearsal = os.environ.get('MCG_SINGLE_DEVICE') == '1' or os.environ.get('MCG_BENCH_DRYRUN') == '1'
+    if not rehearsal:
+        import torch
+        ndev = torch.cuda.device_count()               # counts devices without initialising HIP
+        if ndev < n:
+            sys.stderr.write('bench.py --gpus %d: only %d GPU(s) visible on this node\n' % (n, ndev))
+            return 2
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # RCCL needs dmabuf IPC on this driver
+    env.setdefault('OMP_NUM_THREADS', '8')
+    limit = float(os.environ.get('MCG_BENCH_LAUNCH_TIMEOUT', '1500'))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, start_new_session=True, text=True)
+    try:
+        out, _ = proc.communicate(timeout=limit)
+    except subprocess.TimeoutExpired:
+        import signal
+        os.killpg(proc.pid, signal.SIGKILL)            # exactly the process group started above
+        proc.wait()
+        sys.stderr.write('bench.py --gpus %d: the ranks did not finish within %.0f s\n' % (n, limit))
+        return 3
+    lines = [l for l in out.splitlines() if l.startswith('{"metric"')]
+    if lines:
+        print(lines[-1], flush=True)
+    else:
+        sys.stdout.write(out)
+    if proc.returncode == 0 and not lines:
+        sys.stderr.write('bench.py --gpus %d: rank 0 printed no result line\n' % n)
+        return 4
+    return proc.returncode
+
+
+def dry_run(args, world, rank):
+    """MCG_BENCH_DRYRUN=1 (CPU-container test of the launcher only): rendezvous over gloo, one MAX all-reduce as in
+    the timed region's epilogue, rank 0 prints a line marked dry_run -- no kernels run, nothing is measured."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "training clips/sec (16\u00d73\u00d764\u00d764)", "value": None, "unit": "clips/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True,
+                          "max_over_ranks_check": float(t)}))
+    return 0
 
 
 def main():
@@ -130,8 +206,9 @@ def main():
                          'HIP streams; 0: one stream throughout.  Default: 1, except 0 for the bf16 mode at batch >= 128, where '
                          'the step is dominated by bandwidth-bound passes that only contend (measured: 5178 vs 4768 clips/s '
                          'at batch 256).  The roofline pass is always one-stream.')
-    ap.add_argument('--cpu-sample-batch', type=int, default=4)
-    ap.add_argument('--cpu-sample-steps', type=int, default=2)
+    ap.add_argument('--cpu-sample-batch', type=int, default=8, help='BASELINE.md section 3: batch 8')
+    ap.add_argument('--cpu-sample-steps', type=int, default=5, help='timed iterations (median reported)')
+    ap.add_argument('--cpu-sample-warmup', type=int, default=3)
     args = ap.parse_args()
     if args.overlap is None:
         args.overlap = int(os.environ.get('MCG_OVERLAP', '0' if (args.dtype == 'bf16' and args.batch >= 128) else '1'))
@@ -139,18 +216,22 @@ def main():
     if os.environ.get('MCG_DEBUG_HANG'):
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ['MCG_DEBUG_HANG']), exit=True)
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world == 1 and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: this process (which must not touch the GPU) becomes the
+        # launcher -- one rank per GPU under torch.distributed.run -- and relays rank 0's line and the exit code.
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+    if world != args.gpus:
+        raise SystemExit('bench.py --gpus %d was started with WORLD_SIZE=%d' % (args.gpus, world))
+    if os.environ.get('MCG_BENCH_DRYRUN') == '1':
+        raise SystemExit(dry_run(args, world, rank))
     import torch
     import torch.distributed as dist
     import mocogan_chainer_amd.hiplib as hl
     import mocogan_chainer_amd.step as mstep
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d ...'
-                             % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
     # MCG_SINGLE_DEVICE=1 + MCG_DIST_BACKEND=gloo: rehearse the N > 1 code path on a one-GPU box
@@ -168,6 +249,9 @@ def main():
         hl.load_tile_choices(args.tiles)
 
     gen, di, dv = mstep.make_models(args.model, num_labels=6, seed=0)         # identical init on every rank
+    if exchange is not None:                                                    # ... and made identical by construction
+        for net in (gen, di, dv):
+            exchange.broadcast_params([net.fp.p, net.fp.m, net.fp.v] + list(net.running.values()))
     ts = mstep.TrainStep(args.model, gen, di, dv, exchange=exchange, seed=1234, rank=rank, precision=args.dtype, overlap=False,
                           sync_bn=bool(args.sync_bn))
     B = args.batch
@@ -252,6 +336,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "dv_conv3d_mfma_util_pct": 100.0 * achieved / peak, "traffic": traffic, "algorithmic_bytes": dv_conv_algorithmic_bytes_per_step(B), "traffic_unit": "bytes per step (memory side of L2, incl. Infinity-Cache hits)",
                          "traffic_source": traffic_src,
+                         "traffic_measured_in_run": False,      # PMC counters need rocprofv3 around the process: see traffic_source
                          "kernel": "VideoDiscriminator Conv3d implicit-GEMM family (%s<FpropP|DgradP|WgradP>), "
                                    % ("gemm_kernel" if args.dtype == 'f32' else "gemm_bf16_kernel") +
                                    "dc1..dc4, all launches of one step",
@@ -268,7 +353,7 @@ def main():
             "losses": losses,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_batch, args.cpu_sample_steps)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_batch, args.cpu_sample_warmup, args.cpu_sample_steps)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -14,6 +14,10 @@ MUG_CATEGORIES = {"anger": 0, "disgust": 1, "happiness": 2, "fear": 3, "sadness"
 
 
 def _frame_number(name):
+    """Sort key of a frame file.  Deliberately NUMERIC: the reference's frame_number (datasets.py:12-13) returns the
+    matched digit string and so sorts frames lexicographically, which equals the numeric order for its zero-padded
+    '{:02d}.jpg' names below 100 frames and scrambles longer clips ('100.jpg' < '11.jpg'); numeric order is the
+    temporal order the reference intends."""
     return int(_FRAME.search(str(name)).group(1))
 
 
@@ -55,6 +59,7 @@ def worker_load(indices, raw, batch_no, chunk_no):
 
 class _FrameDirDataset:
     video_length = 16
+    channels = 3            # 1: keep only the first colour plane (the grey-scale Moving-MNIST shape 16x1x64x64)
 
     def __len__(self):
         return len(self.videos)
@@ -78,6 +83,8 @@ class _FrameDirDataset:
         video = read_video(frame_paths[idx], np.uint8 if raw else np.float32)
         if video.ndim != 4:
             raise ValueError('invalid video shape: {}'.format(video.shape))
+        if self.channels != video.shape[3]:
+            video = np.ascontiguousarray(video[..., :self.channels])
         if raw:
             return video                                              # (T,H,W,C) uint8
         video = (video - 128.) / 128.
@@ -107,8 +114,10 @@ class MugDataset(_FrameDirDataset):
 
 
 class MovingMnistDataset(_FrameDirDataset):
-    def __init__(self, dataset_path, video_length=16, save_path="data/dataset/moving_mnist/preprocessed"):
-        self.video_length = video_length
+    def __init__(self, dataset_path, video_length=16, save_path="data/dataset/moving_mnist/preprocessed", channels=3):
+        """channels=3 is the reference (datasets.py:127 tiles the grey frames to RGB); channels=1 yields the
+        single-plane clips of BASELINE configs[0] from the same preprocessed JPEG tree."""
+        self.video_length, self.channels = video_length, channels
         save_path = Path(save_path)
         if not save_path.exists():
             self.preprocess(dataset_path, save_path)

@@ -126,7 +126,7 @@ int main() {
     CK(hipMemsetAsync(dm, 0, nw * 4, s)); CK(hipMemsetAsync(dv, 0, nw * 4, s));
     const double alpha = 2e-4, b1 = 5e-5, b2 = 0.999, eps = 1e-8, wd = 1e-5;
     const double lr_t = alpha * std::sqrt(1 - b2) / (1 - b1);
-    MCG(mcg_adam_wd((int64_t)nw, dw, dgw, dm, dv, lr_t, b1, b2, eps, wd, s));
+    MCG(mcg_adam_wd((int64_t)nw, dw, dgw, dm, dv, lr_t, b1, b2, eps, wd, 1.0, s));
     CK(hipStreamSynchronize(s));
     std::vector<float> w2(nw);
     CK(hipMemcpy(w2.data(), dw, nw * 4, hipMemcpyDeviceToHost));

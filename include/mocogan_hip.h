@@ -11,7 +11,13 @@
  *   - every function returns 0 on success or a negative mcg_status; nothing throws;
  *   - all pointers are caller-owned DEVICE pointers (fp32 unless noted); no hidden allocation:
  *     scratch is passed in explicitly and sized with the *_workspace_bytes queries;
- *   - `stream` is a hipStream_t passed as void*; calls are asynchronous on it;
+ *   - `stream` is a hipStream_t passed as void*; calls are asynchronous on it; the library keeps no mutable
+ *     process state (every knob, e.g. the GEMM block tile, travels in the call's arguments), so calls on
+ *     different streams / host threads do not interact;
+ *   - size limit: the conv kernels address each tensor with 32-bit byte offsets checked by the buffer hardware,
+ *     so every x, y and w of a mcg_conv_* call must stay below 2 GiB (MCG_ERR_UNSUPPORTED otherwise).  The largest
+ *     tensor of the reference's networks is D_V's first activation, 3.4 MB per clip: at most 630 clips per call,
+ *     i.e. a per-GPU batch of 315 (D runs real and fake clips as one call); the reference's default batch is 100;
  *   - activations are channels-last fp32, [N][T][H][W][C] with C padded to a multiple of 4
  *     (2-D tensors have T = 1); padded channels hold zeros;
  *   - conv / deconv weights use ONE layout for every layer: w[Co][kt][kh][kw][Ci] with
@@ -74,10 +80,6 @@ typedef struct mcg_conv_geom {
 } mcg_conv_geom;
 
 int mcg_version(void);
-/* test / tuning hook: force the GEMM block tile of the conv kernels (0 = auto, 1 = 128x128,
- * 2 = 128x64, 3 = 64x64); adding 100 / 200 also forces the K-step depth to 32 / 64.
- * Process-global; not part of the reference-facing surface. */
-void mcg_set_tile_override(int tile);
 
 /* ---- implicit-GEMM convolution on the fp32 MFMA (v_mfma_f32_32x32x2_f32) ------------------- */
 
@@ -208,10 +210,12 @@ int mcg_loss_gen(int N, int C, const float* y_fake_i, const float* y_fake_v, con
                  int with_ce, float* loss_out, float* g_i, float* g_v, void* stream);
 
 /* ---- optimiser (train.py:93-101: Chainer Adam + WeightDecay hook) --------------------------- */
-/* g += wd*p; m += (1-b1)(g-m); v += (1-b2)(g*g-v); p -= lr_t * m / (sqrt(v) + eps), with
- * lr_t = alpha*sqrt(1-b2^t)/(1-b1^t) computed by the caller in double. */
+/* g' = grad_scale*g + wd*p; m += (1-b1)(g'-m); v += (1-b2)(g'*g'-v); p -= lr_t * m / (sqrt(v) + eps), with
+ * lr_t = alpha*sqrt(1-b2^t)/(1-b1^t) computed by the caller in double.  grad_scale is 1 on a single device
+ * (the reference) and 1/world under data parallelism, where g holds the all-reduced SUM of the ranks' gradients:
+ * the mean is formed here instead of in a separate pass over the gradient. */
 int mcg_adam_wd(int64_t n, float* p, const float* g, float* m, float* v, double lr_t, double beta1,
-                double beta2, double eps, double wd, void* stream);
+                double beta2, double eps, double wd, double grad_scale, void* stream);
 
 /* out[i] = sigma * N(0,1), the same Philox stream mcg_bn_act_fwd / mcg_pack_clip draw from. */
 int mcg_randn(int64_t n, float sigma, uint64_t seed, uint64_t stream_id, float* out, void* stream);

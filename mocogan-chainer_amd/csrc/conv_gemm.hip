@@ -21,6 +21,7 @@
 // validity bit-masks over the 16 taps precomputed once per block.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #include "mocogan_hip.h"
 
 namespace {
@@ -918,7 +919,7 @@ int make_geom(const mcg_conv_geom* c, Geom& g) {
 int launch_status() { return hipGetLastError() == hipSuccess ? MCG_OK : MCG_ERR_LAUNCH; }
 
 template <int BM, int BN, int BK, bool BF = false>
-void launch_fprop(const Geom& g, const float* x, const float* w, const float* bias, float* y, hipStream_t s) {
+int launch_fprop(const Geom& g, const float* x, const float* w, const float* bias, float* y, hipStream_t s) {
     FpropP<BM, BN, BK> p;
     p.g = g; p.x = x; p.w = w; p.bias = bias; p.y = y;
     p.M = g.N * g.To * g.Ho * g.Wo; p.K = g.taps * g.Ci;
@@ -929,14 +930,15 @@ void launch_fprop(const Geom& g, const float* x, const float* w, const float* bi
     p.kchunk = ((ksteps + splits - 1) / splits) * BK;
     splits = (p.K + p.kchunk - 1) / p.kchunk;
     if (splits == 1) p.kchunk = p.K > 0 ? ((p.K + BK - 1) / BK) * BK : BK;
-    else (void)hipMemsetAsync(y, 0, (size_t)p.M * g.Co * sizeof(float), s);
+    else if (hipMemsetAsync(y, 0, (size_t)p.M * g.Co * sizeof(float), s) != hipSuccess) return MCG_ERR_LAUNCH;   // the atomics need a cleared y
     dim3 grid((p.M + BM - 1) / BM, (g.Co + BN - 1) / BN, splits);
     if (BF) hipLaunchKernelGGL((gemm_bf16_kernel<FpropP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
     else hipLaunchKernelGGL((gemm_kernel<FpropP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
+    return MCG_OK;
 }
 
 template <int BM, int BN, int BK, bool BF = false>
-void launch_dgrad(const Geom& g, const float* y, const float* w, const float* bias, float* x, int act, int acc, hipStream_t s) {
+int launch_dgrad(const Geom& g, const float* y, const float* w, const float* bias, float* x, int act, int acc, hipStream_t s) {
     DgradP<BM, BN, BK> p;
     p.g = g; p.y = y; p.w = w; p.bias = bias; p.x = x; p.act = act; p.accumulate = acc;
     p.M = g.N * g.Ti * g.Ho * g.Wo; p.K = g.kt * 4 * g.Co;
@@ -948,7 +950,7 @@ void launch_dgrad(const Geom& g, const float* y, const float* w, const float* bi
     if (splits < 1) splits = 1;
     p.kchunk = ((ksteps + splits - 1) / splits) * BK;
     splits = (p.K + p.kchunk - 1) / p.kchunk;
-    if (splits > 1 && !acc) (void)hipMemsetAsync(x, 0, (size_t)g.N * frame * sizeof(float), s);
+    if (splits > 1 && !acc && hipMemsetAsync(x, 0, (size_t)g.N * frame * sizeof(float), s) != hipSuccess) return MCG_ERR_LAUNCH;
     p.gxm = (p.M + BM - 1) / BM; p.gyn = (g.Ci + BN - 1) / BN; p.tiles8 = (p.gxm * p.gyn + 7) / 8;
 #ifndef MCG_NO_CLASS_ADJ
     dim3 grid(8 * p.tiles8 * 4 * splits, 1, 1);
@@ -957,10 +959,11 @@ void launch_dgrad(const Geom& g, const float* y, const float* w, const float* bi
 #endif
     if (BF) hipLaunchKernelGGL((gemm_bf16_kernel<DgradP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
     else hipLaunchKernelGGL((gemm_kernel<DgradP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
+    return MCG_OK;
 }
 
 template <int BM, int BN, int BK, bool BF = false>
-void launch_wgrad(const Geom& g, const float* x, const float* y, float* dw, hipStream_t s) {
+int launch_wgrad(const Geom& g, const float* x, const float* y, float* dw, hipStream_t s) {
     WgradP<BM, BN, BK> p;
     p.g = g; p.x = x; p.y = y; p.dw = dw;
     p.Mpix = g.N * g.To * g.Ho * g.Wo; p.Kf = g.taps * g.Ci;
@@ -977,16 +980,17 @@ void launch_wgrad(const Geom& g, const float* x, const float* y, float* dw, hipS
     dim3 grid((g.Co + BM - 1) / BM, (p.Kf + BN - 1) / BN, splits);
     if (BF) hipLaunchKernelGGL((gemm_bf16_kernel<WgradP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
     else hipLaunchKernelGGL((gemm_kernel<WgradP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
+    return MCG_OK;
 }
 
 // tile / K-depth / MFMA-type dispatch of the launch_* templates
 #define MCG_TILES(fn, t, BK, BF, ...)                                   \
     do {                                                                \
-        if ((t) == 1) fn<128, 128, BK, BF>(__VA_ARGS__);                \
-        else if ((t) == 2) fn<128, 64, BK, BF>(__VA_ARGS__);            \
-        else if ((t) == 4) fn<256, 64, 32, BF>(__VA_ARGS__);            \
-        else if ((t) == 5) fn<64, 256, 32, BF>(__VA_ARGS__);            \
-        else fn<64, 64, BK, BF>(__VA_ARGS__);                           \
+        if ((t) == 1) st = fn<128, 128, BK, BF>(__VA_ARGS__);           \
+        else if ((t) == 2) st = fn<128, 64, BK, BF>(__VA_ARGS__);       \
+        else if ((t) == 4) st = fn<256, 64, 32, BF>(__VA_ARGS__);       \
+        else if ((t) == 5) st = fn<64, 256, 32, BF>(__VA_ARGS__);       \
+        else st = fn<64, 64, BK, BF>(__VA_ARGS__);                      \
     } while (0)
 #define MCG_DISPATCH(fn, t, bk64, bf, ...)                              \
     do {                                                                \
@@ -994,8 +998,10 @@ void launch_wgrad(const Geom& g, const float* x, const float* y, float* dw, hipS
         else    { if (bk64) MCG_TILES(fn, t, 64, false, __VA_ARGS__); else MCG_TILES(fn, t, 32, false, __VA_ARGS__); }    \
     } while (0)
 
-int g_tile_override = 0;   // 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64 (tests / tuning)
-int g_bk_override = 0;     // 0 auto, 32 or 64
+// a launch status that also reports a failed clear of a split-K output (st) -- the atomics would otherwise add onto stale data
+int finish(int st) { return st != MCG_OK ? st : launch_status(); }
+
+std::once_flag g_c4_lds_once;      // dgrad_c4_kernel<4> needs the 64 KiB dynamic-LDS opt-in once per process (one process per GPU)
 
 }  // namespace
 
@@ -1005,11 +1011,6 @@ extern "C" void mcg_debug_stamps(unsigned long long* out, int reset) {
     if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)); }
 }
 #endif
-
-extern "C" void mcg_set_tile_override(int t) {
-    t %= 1000;
-    g_tile_override = t % 100; g_bk_override = t >= 100 ? (t / 100) * 32 : 0;
-}
 
 extern "C" int mcg_conv_fprop(const mcg_conv_geom* c, const float* x, const float* w, const float* bias,
                               float* y, void* stream) {
@@ -1021,8 +1022,8 @@ extern "C" int mcg_conv_fprop(const mcg_conv_geom* c, const float* x, const floa
     long long M = (long long)g.N * g.To * g.Ho * g.Wo;
     // Tile choice (measured on MI355X, tools/bench_layers.py): 128x128 only when there are enough tiles
     // that the last partial round of blocks does not matter, else 128x64, else 64x64 to fill 256 CUs.
-    int t = g_tile_override ? g_tile_override : g.tile;
-    const int bk = g_tile_override || g_bk_override ? g_bk_override : g.bk;
+    int t = g.tile;
+    const int bk = g.bk;
     const long long mt = (M + 127) / 128;
     if (!t) t = g.Co <= 64 ? 2 : (mt * ((g.Co + 127) / 128) >= 1024 ? 1 : (mt * ((g.Co + 63) / 64) >= 512 ? 2 : 3));
     // 64-deep K-steps halve the per-step overhead (barriers, LDS refill, address math) and pay off when the
@@ -1030,7 +1031,7 @@ extern "C" int mcg_conv_fprop(const mcg_conv_geom* c, const float* x, const floa
     const long long nblk = ((M + (t == 3 ? 63 : 127)) / (t == 3 ? 64 : 128)) * ((g.Co + (t == 1 ? 127 : 63)) / (t == 1 ? 128 : 64));
     const bool bk64 = (g.taps * g.Ci) % 64 == 0 && (bk ? bk == 64 : (nblk < 1024 || g.prec == MCG_PREC_BF16));
     MCG_DISPATCH(launch_fprop, t, bk64, g.prec == MCG_PREC_BF16, g, x, w, bias, y, s);
-    return launch_status();
+    return finish(st);
 }
 
 extern "C" int mcg_conv_dgrad(const mcg_conv_geom* c, const float* y, const float* w, const float* bias,
@@ -1042,16 +1043,17 @@ extern "C" int mcg_conv_dgrad(const mcg_conv_geom* c, const float* y, const floa
     if (act != MCG_ACT_NONE && act != MCG_ACT_TANH) return MCG_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     long long M = (long long)g.N * g.Ti * g.Ho * g.Wo;
-    int t = g_tile_override ? g_tile_override : g.tile;
-    const int bk = g_tile_override || g_bk_override ? g_bk_override : g.bk;
+    int t = g.tile;
+    const int bk = g.bk;
     if (!t && g.Ci == 4 && g.Co == 64 && (g.Wo & 15) == 0) {      // VALU kernel for the padded 3-channel clip
         const int runs = (int)(M / 16);                          // M = N*Ti*Ho*Wo half-resolution positions
         const int per_block = (NTHREADS / 64) * C4_RUNS_PER_WAVE;
         dim3 grid((runs + per_block - 1) / per_block, 1, 1);
         const size_t lds = (size_t)g.kt * 16 * 64 * sizeof(f32x4);
         if (g.kt == 4) {
-            static bool attr_set = false;                        // 64 KiB of dynamic LDS needs the opt-in once
-            if (!attr_set) { (void)hipFuncSetAttribute((const void*)dgrad_c4_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+            hipError_t attr = hipSuccess;
+            std::call_once(g_c4_lds_once, [&] { attr = hipFuncSetAttribute((const void*)dgrad_c4_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+            if (attr != hipSuccess) return MCG_ERR_LAUNCH;
             hipLaunchKernelGGL(dgrad_c4_kernel<4>, grid, dim3(NTHREADS), lds, s, g, y, w, bias, x, act, accumulate, runs);
         } else {
             hipLaunchKernelGGL(dgrad_c4_kernel<1>, grid, dim3(NTHREADS), lds, s, g, y, w, bias, x, act, accumulate, runs);
@@ -1066,7 +1068,7 @@ extern "C" int mcg_conv_dgrad(const mcg_conv_geom* c, const float* y, const floa
     const long long nblk = 4 * ((M + (t == 3 ? 63 : 127)) / (t == 3 ? 64 : 128)) * ((g.Ci + (t == 1 ? 127 : 63)) / (t == 1 ? 128 : 64));
     const bool bk64 = (g.kt * 4 * g.Co) % 64 == 0 && (bk ? bk == 64 : (nblk < 1024 || g.prec == MCG_PREC_BF16));
     MCG_DISPATCH(launch_dgrad, t, bk64, g.prec == MCG_PREC_BF16, g, y, w, bias, x, act, accumulate, s);
-    return launch_status();
+    return finish(st);
 }
 
 extern "C" int mcg_conv_wgrad(const mcg_conv_geom* c, const float* x, const float* y, float* dw, void* stream) {
@@ -1076,12 +1078,12 @@ extern "C" int mcg_conv_wgrad(const mcg_conv_geom* c, const float* x, const floa
     if (!x || !dw || !y) return MCG_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     int Kf = g.taps * g.Ci;
-    int t = g_tile_override ? g_tile_override : g.tile;
-    const int bk = g_tile_override || g_bk_override ? g_bk_override : g.bk;
+    int t = g.tile;
+    const int bk = g.bk;
     if (!t) t = (g.Co <= 64 || Kf <= 64) ? 3 : 1;
     const bool bk64 = bk ? bk == 64 : g.prec == MCG_PREC_BF16;
     MCG_DISPATCH(launch_wgrad, t, bk64, g.prec == MCG_PREC_BF16, g, x, y, dw, s);
-    return launch_status();
+    return finish(st);
 }
 
 // ---- fully-connected layers on the GEMM core (called by mcg_fc_fprop / mcg_fc_wgrad in small_ops.hip when the
@@ -1099,7 +1101,7 @@ extern "C" int mcg_detail_fc_fprop_gemm(int M, int K, int N, const float* x, con
     p.kchunk = ((ksteps + splits - 1) / splits) * BK;
     splits = (K + p.kchunk - 1) / p.kchunk;
     hipStream_t s = (hipStream_t)stream;
-    if (splits > 1) (void)hipMemsetAsync(y, 0, (size_t)M * N * sizeof(float), s);
+    if (splits > 1 && hipMemsetAsync(y, 0, (size_t)M * N * sizeof(float), s) != hipSuccess) return MCG_ERR_LAUNCH;
     dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN, splits);
     hipLaunchKernelGGL((gemm_kernel<FcFpropP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
     return launch_status();

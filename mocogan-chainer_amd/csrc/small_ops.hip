@@ -649,10 +649,10 @@ __global__ __launch_bounds__(NT) void loss_gen_kernel(int N, int C, const float*
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void adam_wd_kernel(long long n, float* __restrict__ p, const float* __restrict__ g,
                                                      float* __restrict__ m, float* __restrict__ v, float lr, float b1c,
-                                                     float b2c, float eps, float wd) {
+                                                     float b2c, float eps, float wd, float gscale) {
     for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n; i += (long long)gridDim.x * NT) {
         float pv = p[i];
-        float gg = g[i] + wd * pv;
+        float gg = g[i] * gscale + wd * pv;      // gscale = 1 / world: the all-reduced SUM becomes the mean here (x 1.0f is exact)
         float mv = m[i], vv = v[i];
         mv += b1c * (gg - mv);
         vv += b2c * (gg * gg - vv);
@@ -878,11 +878,11 @@ extern "C" int mcg_loss_gen(int N, int C, const float* y_fake_i, const float* y_
 }
 
 extern "C" int mcg_adam_wd(int64_t n, float* p, const float* g, float* m, float* v, double lr_t, double beta1, double beta2, double eps,
-                           double wd, void* stream) {
+                           double wd, double grad_scale, void* stream) {
     if (!p || !g || !m || !v || n <= 0) return MCG_ERR_BAD_ARG;
     // hyper-parameters arrive as doubles so that (1 - beta) is rounded to fp32 once, like Chainer's python-float arithmetic
     hipLaunchKernelGGL(adam_wd_kernel, dim3(ew_grid(n)), dim3(NT), 0, (hipStream_t)stream, (long long)n, p, g, m, v, (float)lr_t,
-                       (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)wd);
+                       (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)wd, (float)grad_scale);
     return launch_status();
 }
 

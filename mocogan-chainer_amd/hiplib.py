@@ -37,7 +37,6 @@ _GP = C.POINTER(ConvGeom)
 # name -> (restype, argtypes); mirrors include/mocogan_hip.h one to one
 SIGNATURES = {
     "mcg_version": (_I, []),
-    "mcg_set_tile_override": (None, [_I]),
     "mcg_conv_fprop": (_I, [_GP, _P, _P, _P, _P, _P]),
     "mcg_conv_dgrad": (_I, [_GP, _P, _P, _P, _P, _I, _I, _P]),
     "mcg_conv_wgrad": (_I, [_GP, _P, _P, _P, _P]),
@@ -60,7 +59,7 @@ SIGNATURES = {
     "mcg_gru_seq_bwd": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "mcg_loss_dis": (_I, [_I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
     "mcg_loss_gen": (_I, [_I, _I, _P, _P, _P, _I, _P, _P, _P, _P]),
-    "mcg_adam_wd": (_I, [_I64, _P, _P, _P, _P, _D, _D, _D, _D, _D, _P]),
+    "mcg_adam_wd": (_I, [_I64, _P, _P, _P, _P, _D, _D, _D, _D, _D, _D, _P]),
     "mcg_randn": (_I, [_I64, _F, _U64, _U64, _P, _P]),
 }
 
@@ -85,8 +84,22 @@ def load():
     return lib
 
 
+_tile_override = 0
+
+
 def set_tile_override(t):
-    load().mcg_set_tile_override(int(t))
+    """Tests / tuning tools: a default for mcg_conv_geom.tile of every conv call that does not set one itself
+    (0 = none).  Lives here, in the caller: the library has no process-global state."""
+    global _tile_override
+    _tile_override = int(t)
+
+
+def _with_override(g):
+    if not _tile_override or g.tile:
+        return g
+    gg = ConvGeom.from_buffer_copy(g)
+    gg.tile = _tile_override
+    return gg
 
 
 _SYNC_EVERY_CALL = os.environ.get("MCG_SYNC", "0") == "1"     # debugging aid: serialise host and device
@@ -296,15 +309,18 @@ def _scratch_like(g, which):
 # thin typed wrappers (tensors in; nothing allocated here except the one-off tuning scratch)
 # ------------------------------------------------------------------------------------------
 def _fprop(g, x, w, bias, y):
+    g = _with_override(g)
     _check(load().mcg_conv_fprop(C.byref(g), _p(x), _p(_dense(w)), _p(bias), _p(_dense(y)), _stream()), "mcg_conv_fprop")
 
 
 def _dgrad(g, y, w, bias, x, act, accumulate):
+    g = _with_override(g)
     _check(load().mcg_conv_dgrad(C.byref(g), _p(_dense(y)), _p(_dense(w)), _p(bias), _p(x), act, int(accumulate), _stream()),
            "mcg_conv_dgrad")
 
 
 def _wgrad(g, x, y, dw):
+    g = _with_override(g)
     _check(load().mcg_conv_wgrad(C.byref(g), _p(x), _p(_dense(y)), _p(_dense(dw)), _stream()), "mcg_conv_wgrad")
 
 
@@ -421,9 +437,9 @@ def loss_gen(N, Cn, y_i, y_v, t_fake, with_ce, loss_out, g_i, g_v):
                                _p(_dense(g_i)), _p(_dense(g_v)), _stream()), "mcg_loss_gen")
 
 
-def adam_wd(p, g, m, v, lr_t, beta1, beta2, eps, wd):
+def adam_wd(p, g, m, v, lr_t, beta1, beta2, eps, wd, grad_scale=1.0):
     _check(load().mcg_adam_wd(p.numel(), _p(_dense(p)), _p(_dense(g)), _p(_dense(m)), _p(_dense(v)), lr_t, beta1, beta2, eps, wd,
-                              _stream()), "mcg_adam_wd")
+                              grad_scale, _stream()), "mcg_adam_wd")
 
 
 def randn(out, sigma, seed, stream_id):

@@ -29,11 +29,12 @@ class AdamHyper:
         return self.alpha * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
 
 
-def adam_update(net, hyper):
-    """optimizer.update() tail: hooks, t += 1, per-parameter Adam -- one launch over the flat buffers."""
+def adam_update(net, hyper, grad_scale=1.0):
+    """optimizer.update() tail: hooks, t += 1, per-parameter Adam -- one launch over the flat buffers.
+    grad_scale: 1 / world under data parallelism (the flat gradient then holds the SUM over the ranks)."""
     net.t += 1
     fp = net.fp
-    hl.adam_wd(fp.p, fp.g, fp.m, fp.v, hyper.lr(net.t), hyper.beta1, hyper.beta2, hyper.eps, hyper.weight_decay)
+    hl.adam_wd(fp.p, fp.g, fp.m, fp.v, hyper.lr(net.t), hyper.beta1, hyper.beta2, hyper.eps, hyper.weight_decay, grad_scale)
 
 
 class GradExchange:
@@ -41,13 +42,15 @@ class GradExchange:
     (RCCL over xGMI on the GPU box, gloo in the CPU tests).  No reference counterpart: the
     reference is single-device (train.py:87-91).  Each rank runs the step on its own shard of
     the batch with its own BatchNorm statistics; gradients are averaged, so every rank applies
-    the same Adam update and the replicas stay bit-identical."""
+    the same Adam update and the replicas stay bit-identical.  The collective SUMS; the division by the world
+    size happens inside the Adam kernel (``grad_scale``), not in a pass of its own."""
 
     def __init__(self, group=None):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.grad_scale = 1.0 / self.world
 
     def start(self, flat_grad):
         """Asynchronous SUM all-reduce of a (slice of a) flat gradient; returns a handle for finish()."""
@@ -56,12 +59,12 @@ class GradExchange:
         return (self.dist.all_reduce(flat_grad, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True), flat_grad)
 
     def finish(self, handle, flat_grad=None):
-        """Wait for the collective and turn the sum into the mean."""
+        """Wait for the collective (stream-ordered on RCCL: the current stream waits, the host does not).  The
+        buffer then holds the SUM over the ranks; adam_update(..., grad_scale=self.grad_scale) makes it the mean."""
         if handle is None:
             return
-        work, buf = handle
+        work, _ = handle
         work.wait()
-        buf.mul_(1.0 / self.world)
 
     def all_reduce_sum(self, t):
         """In-place SUM over the ranks, ordered on the current stream (synchronised BatchNorm's per-channel sums)."""
@@ -205,6 +208,7 @@ class TrainStep:
         # (model/updater.py:97-98,107-108 as one 2n batch per net; per-call BatchNorm statistics, real first)
         cd = di.out_channels
         ex = self.exchange
+        gs = ex.grad_scale if ex else 1.0
         main = torch.cuda.current_stream()
         side = self.side if self.side is not None else main
         side.wait_stream(main)                                        # x_fake is ready
@@ -233,12 +237,12 @@ class TrainStep:
         with torch.cuda.stream(side):
             if ex:
                 ex.finish(work_i)                                    # D_I's exchange overlapped D_V's backward
-            adam_update(di, self.hyper['image_dis'])
+            adam_update(di, self.hyper['image_dis'], gs)
         if ex:
             rest = [ex.start(dv.fp.g[:lo]), ex.start(dv.fp.g[hi:])]
             for h in late + rest:
                 ex.finish(h)
-        adam_update(dv, self.hyper['video_dis'])
+        adam_update(dv, self.hyper['video_dis'], gs)
         main.wait_stream(side)                                        # D_I's logits and updated weights (Q5)
         # ------------------------------------------------ image_gen_optimizer.update(loss_gen, ...)   :113
         gen.zero_grad()
@@ -260,7 +264,7 @@ class TrainStep:
             rest_g = [ex.start(gen.fp.g[:lo_g]), ex.start(gen.fp.g[hi_g:])]
             for h in late_g + rest_g:
                 ex.finish(h)
-        adam_update(gen, self.hyper['image_gen'])
+        adam_update(gen, self.hyper['image_gen'], gs)
         self.iteration += 1
         return {'x_fake': x_fake, 't_fake': t_fake, 't': t, 'gx_fake': gx, 'saved_gen': s_gen, 'saved_fake_i': s_fake_i, 'saved_fake_v': s_fake_v,
                 'y_real_i': y_real_i, 'y_real_v': y_real_v, 'y_fake_i': y_fake_i, 'y_fake_v': y_fake_v}

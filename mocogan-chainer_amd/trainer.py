@@ -61,6 +61,17 @@ class SerialIterator:
     def epoch_detail(self):
         return self.epoch + self.current_position / len(self.dataset)
 
+    def load_state(self, epoch, current_position, order=None, is_new_epoch=None, previous_epoch_detail=None):
+        """Restore the position a snapshot recorded (Chainer's SerialIterator.serialize: current_position, epoch,
+        is_new_epoch, order, previous_epoch_detail).  ``order`` None keeps the current permutation."""
+        self.epoch, self.current_position = int(epoch), int(current_position)
+        if order is not None and len(order) == len(self.dataset):
+            self._order = np.asarray(order, dtype=np.int64).copy()
+        if is_new_epoch is not None:
+            self.is_new_epoch = bool(is_new_epoch)
+        if previous_epoch_detail is not None:
+            self._previous_epoch_detail = float(previous_epoch_detail)
+
     def next(self):
         n = len(self.dataset)
         if not self._repeat and self.epoch > 0:
@@ -98,8 +109,9 @@ class PrefetchIterator(SerialIterator):
 
     * index order, wrap-around batches, ``epoch`` / ``is_new_epoch`` / ``epoch_detail`` are exactly those
       of SerialIterator for the same NumPy seed: the index lists are drawn by the same code, only earlier;
-    * workers are *spawned* (never forked from a process that may have touched the GPU) and import only
-      ``datasets.py``; random crop offsets are drawn in the workers, each seeded from (seed, batch number), so
+    * workers are *spawned* (never forked from a process that may have touched the GPU); their work functions live
+      in the torch-free ``datasets.py`` (spawn also re-imports the parent's main module, so a script that wants
+      light workers keeps its heavy imports inside ``main()``, as train.py does); random crop offsets are drawn in the workers, each seeded from (seed, batch number), so
       a run is reproducible but not sample-identical to the serial loop;
     * datasets that offer ``get_example_raw`` ship uint8 frames (a quarter of the bytes through the pipes
       and over PCIe); ``next_device_batch`` copies them from pinned memory on a side stream and normalises /
@@ -123,6 +135,16 @@ class PrefetchIterator(SerialIterator):
             for f in futs:
                 f.cancel()
         self._queue = []
+        self._head = self._state()
+
+    def load_state(self, epoch, current_position, order=None, is_new_epoch=None, previous_epoch_detail=None):
+        """As SerialIterator.load_state; the look-ahead (batches already queued from the old position) is dropped
+        and restarts from the restored position."""
+        for _, futs in self._queue:
+            for f in futs:
+                f.cancel()
+        self._queue = []
+        super().load_state(epoch, current_position, order, is_new_epoch, previous_epoch_detail)
         self._head = self._state()
 
     # -- bookkeeping: SerialIterator.next() minus the loading ------------------------------------------
@@ -275,8 +297,13 @@ class Trainer:
     # whole-run snapshot (extensions.snapshot): models, optimizers, counters
     def state(self):
         u = self.updater
-        d = {'updater/iteration': np.asarray(u.iteration), 'updater/iterator:main/epoch': np.asarray(u.get_iterator('main').epoch),
-             'updater/iterator:main/current_position': np.asarray(u.get_iterator('main').current_position)}
+        it = u.get_iterator('main')
+        d = {'updater/iteration': np.asarray(u.iteration), 'updater/iterator:main/epoch': np.asarray(it.epoch),
+             'updater/iterator:main/current_position': np.asarray(it.current_position),
+             'updater/iterator:main/is_new_epoch': np.asarray(bool(it.is_new_epoch)),
+             'updater/iterator:main/previous_epoch_detail': np.asarray(float(getattr(it, '_previous_epoch_detail', -1.0)))}
+        if getattr(it, '_order', None) is not None:                 # Chainer's SerialIterator serializes its permutation too
+            d['updater/iterator:main/order'] = np.asarray(it._order)
         for name, link in u.links().items():
             for k, v in link.impl.export_reference_params().items():
                 d['updater/model:%s/%s' % (name, k)] = v
@@ -290,9 +317,18 @@ class Trainer:
     def load_state(self, d):
         u = self.updater
         u.iteration = int(d['updater/iteration'])
+        if hasattr(u, '_step'):
+            # the device step's own counter keys the Philox streams (add_noise, latent codes) and the frame index:
+            # a resumed run must continue that sequence, not replay iterations 0..k
+            u._step.iteration = u.iteration
         it = u.get_iterator('main')
-        it.epoch = int(d['updater/iterator:main/epoch'])
-        it.current_position = int(d['updater/iterator:main/current_position'])
+        opt = lambda k: d['updater/iterator:main/' + k] if 'updater/iterator:main/' + k in d else None
+        args = (int(d['updater/iterator:main/epoch']), int(d['updater/iterator:main/current_position']), opt('order'),
+                opt('is_new_epoch'), opt('previous_epoch_detail'))
+        if hasattr(it, 'load_state'):
+            it.load_state(*args)
+        else:
+            it.epoch, it.current_position = args[0], args[1]
         for name, link in u.links().items():
             pre = 'updater/model:%s/' % name
             link.impl.load_reference_params({k[len(pre):]: v for k, v in d.items() if k.startswith(pre)})

@@ -169,3 +169,115 @@ def test_shipped_tile_table_is_well_formed():
         assert isinstance(code, int) and 0 <= code % 100 <= 5 and (code // 100) % 10 <= 2 and code // 1000 <= 2, code
         assert tuple(key) not in seen
         seen.add(tuple(key))
+
+
+def test_prefetch_iterator_resumes_from_a_restored_position():
+    """load_state must drop the look-ahead queued from the old position; a resumed PrefetchIterator has to
+    show what a SerialIterator restored to the same state shows (reference: --resume, train.py:162-163)."""
+    from mocogan_chainer_amd.trainer import SerialIterator, PrefetchIterator
+    from datasets import SyntheticDataset
+    ds = SyntheticDataset(12, num_labels=6)
+    np.random.seed(11)
+    a = SerialIterator(ds, 4)
+    for _ in range(4):                                       # into epoch 1
+        a.next()
+    saved = (a.epoch, a.current_position, a._order.copy(), a.is_new_epoch, a._previous_epoch_detail)
+    rs = np.random.get_state()
+    ref = []
+    for _ in range(5):
+        b = a.next()
+        ref.append(([x[1] for x in b], a.epoch, a.is_new_epoch, a.current_position))
+    np.random.seed(99)                                       # a fresh process: different permutation, position 0
+    p = PrefetchIterator(ds, 4, n_workers=2, prefetch=3, chunk=2)
+    try:
+        p.next()                                             # the look-ahead is now queued from the wrong place
+        p.load_state(*saved)
+        np.random.set_state(rs)                              # (Chainer restores the order, not NumPy's global generator)
+        assert (p.epoch, p.current_position) == saved[:2]
+        for r in ref:
+            b = p.next()
+            assert ([x[1] for x in b], p.epoch, p.is_new_epoch, p.current_position) == r
+    finally:
+        p.close()
+
+
+def test_trainer_state_round_trips_the_iterator_and_the_step_counter():
+    """Trainer.state()/load_state(): Chainer's SerialIterator keys (epoch, current_position, order, ...) and the device
+    step's own iteration counter, which keys the Philox streams and the frame index."""
+    from mocogan_chainer_amd import trainer as T
+    from datasets import SyntheticDataset
+
+    class _Impl:
+        t = 3
+
+        def export_reference_params(self):
+            return {'dc1/W': np.ones(2, np.float32)}
+
+        def export_adam_state(self):
+            return {'t': 3, 'm': {'dc1/W': np.zeros(2, np.float32)}, 'v': {'dc1/W': np.zeros(2, np.float32)}}
+
+        def trainable_keys(self):
+            return ['dc1/W']
+
+        def load_reference_params(self, d):
+            self.loaded = d
+
+        def load_adam_state(self, st):
+            self.t = st['t']
+
+    class _Link:
+        def __init__(self):
+            self.impl = _Impl()
+
+    class _Step:
+        iteration = 0
+
+    class _U:
+        def __init__(self, it):
+            self.iteration, self._it, self._step, self._links = 0, it, _Step(), {'image_gen': _Link()}
+
+        def get_iterator(self, name):
+            return self._it
+
+        def links(self):
+            return self._links
+
+    np.random.seed(5)
+    it = T.SerialIterator(SyntheticDataset(10, 6), 4)
+    for _ in range(4):
+        it.next()
+    u = _U(it)
+    u.iteration = 4
+    d = T.Trainer(u, (1, 'epoch')).state()
+    assert {'updater/iterator:main/order', 'updater/iterator:main/is_new_epoch', 'updater/iterator:main/previous_epoch_detail'} <= set(d)
+    np.random.seed(6)
+    it2 = T.SerialIterator(SyntheticDataset(10, 6), 4)
+    u2 = _U(it2)
+    T.Trainer(u2, (1, 'epoch')).load_state(d)
+    assert u2.iteration == 4 and u2._step.iteration == 4
+    assert (it2.epoch, it2.current_position, it2.is_new_epoch) == (it.epoch, it.current_position, it.is_new_epoch)
+    assert np.array_equal(it2._order, it._order)
+
+
+def test_bench_self_launches_its_ranks(tmp_path):
+    """`python bench.py --gpus N` with no WORLD_SIZE starts the N ranks itself (torch.distributed.run as a child
+    process), relays rank 0's single JSON line and the exit code; fewer visible GPUs than ranks is a clear error, never
+    a hang.  MCG_BENCH_DRYRUN=1 swaps the GPU work for a gloo rendezvous + MAX all-reduce, so the launcher runs here."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MCG_BENCH_DRYRUN='1')
+    env.pop('WORLD_SIZE', None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1'],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['steps'] == 3 and line['dry_run'] is True and line['max_over_ranks_check'] == 2.0
+    if not torch.cuda.is_available():                        # this container: no GPU -> the real launch refuses, quickly
+        env.pop('MCG_BENCH_DRYRUN')
+        r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'], capture_output=True, text=True,
+                           env=env, timeout=600)
+        assert r.returncode == 2 and 'GPU(s) visible' in r.stderr

@@ -42,7 +42,8 @@ def _worker(rank, world, port, q):
         half = flat.numel() // 2                            # two buckets in flight, like D_V's gradient
         handles = [ex.start(flat[:half]), ex.start(flat[half:])]   # async all-reduce (SUM) ...
         for h in handles:
-            ex.finish(h)                                    # ... wait, then / world
+            ex.finish(h)                                    # ... wait: the buffers hold the SUM over the ranks
+        flat *= ex.grad_scale                               # what mcg_adam_wd's grad_scale argument does on the device
         o = 0
         for k in keys:
             n = grads[k].size

@@ -207,3 +207,21 @@ def test_train_on_a_moving_mnist_file(tmp_path, monkeypatch):
     frames = sorted((tmp_path / 'data' / 'dataset' / 'moving_mnist' / 'preprocessed' / '00000').glob('*.jpg'))
     assert len(frames) == 20
     assert all(np.isfinite(v) for v in tr.updater.observation.values())
+
+
+def test_train_on_single_channel_moving_mnist(tmp_path, monkeypatch):
+    """BASELINE configs[0] names 16x1x64x64 clips: --channel 1 trains the single-plane networks (in/out_channels = 1)
+    on the same preprocessed JPEG tree (the reference tiles the grey frames to RGB, datasets.py:127)."""
+    import train
+    rng = np.random.RandomState(0)
+    np.save(tmp_path / 'mnist_test_seq.npy', rng.randint(0, 255, (20, 6, 64, 64)).astype(np.uint8))
+    monkeypatch.chdir(tmp_path)
+    tr = train.main(['--dataset_type', 'mnist', '--dataset', str(tmp_path / 'mnist_test_seq.npy'), '--batchsize', '3', '--max_epoch', '1',
+                     '--n_filters_gen', '8', '--save_name', 'mm1', '--snapshot_interval', '5', '--channel', '1',
+                     '--log_tensorboard_interval', '100'])
+    assert tr.updater.iteration == 2 and tr.updater.epoch == 1
+    assert tr.updater.image_gen.out_channels == 1 and tr.updater.video_dis.in_channels == 1
+    assert tr.updater.get_iterator('main').dataset[0][0].shape == (1, 16, 64, 64)
+    assert all(np.isfinite(v) for v in tr.updater.observation.values())
+    with np.load(tmp_path / 'result' / 'mm1' / 'image_gen_epoch_fianl.npz') as f:
+        assert f['dc5/W'].shape == (8, 1, 4, 4)

@@ -1,0 +1,210 @@
+"""Parity at the reference's TRUE channel widths (n_filters = 64) with the SHIPPED tile table, a free-running
+three-iteration check, and the single-channel (Moving-MNIST shape) networks.
+
+* per layer: D_V dc2..dc4, D_I dc2..dc4 and G dc2..dc4 geometries at a batch the float64 oracle finishes in
+  seconds, every tile code mocogan-chainer_amd/tuned_tiles_mi355x.json holds for that layer and pass (incl. the
+  split-K codes 1xxx / 2xxx) forced through mcg_conv_geom.tile, forward rel-L2 <= 1e-5 and gradients <= 1e-4
+  against oracle.functions.conv3d_* (reference arithmetic: model/net.py:133-136,174-178, 45-48);
+* free running: three update_core iterations in which the device keeps its OWN parameters and Adam state, weights
+  rel-L2 <= 1e-4 against the oracle (reference model/updater.py:111-113);
+* C = 1: BASELINE configs[0] names 16x1x64x64 clips."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import functions as F
+from oracle import net as onet
+from oracle import updater as oupd
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FWD_TOL, BWD_TOL = 1e-5, 1e-4
+F64 = np.float64
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    assert torch.cuda.is_available()
+    import mocogan_chainer_amd.hiplib as hl
+    import mocogan_chainer_amd.layout as lay
+    import mocogan_chainer_amd.nets as nets
+    import mocogan_chainer_amd.step as step
+    hl.load()
+    return hl, lay, nets, step
+
+
+def dev(a, dtype=torch.float32):
+    return torch.tensor(np.asarray(a), dtype=dtype, device="cuda")
+
+
+def rel_l2(a, b):
+    a = a.detach().cpu().double().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, F64)
+    b = np.asarray(b, F64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+def shipped_codes(kind, T, H, Ci, Co, kt, precision=0):
+    """every tile code the shipped table holds for this (pass, layer geometry), over all batch sizes it was tuned at"""
+    table = json.load(open(os.path.join(ROOT, 'mocogan-chainer_amd', 'tuned_tiles_mi355x.json')))
+    codes = set()
+    for key, code in table:
+        # key = (pass, N, Ti, Hi, Wi, Ci, Co, kt, x_perm_n, precision, ...)
+        if key[0] == kind and tuple(key[2:8]) == (T, H, H, Ci, Co, kt) and key[9] == precision:
+            codes.add(int(code))
+    return sorted(codes)
+
+
+# (name, N, Ti, H, Ci, Co, kt): x side [N][Ti][H][H][Ci], y side [N][Ti-kt+1][H/2][H/2][Co]
+FULL_WIDTH_LAYERS = [
+    ("D_V.dc2", 2, 13, 32, 64, 128, 4),
+    ("D_V.dc3", 2, 10, 16, 128, 256, 4),
+    ("D_V.dc4", 2, 7, 8, 256, 512, 4),
+    ("D_I.dc2", 3, 1, 32, 64, 128, 1),
+    ("D_I.dc3", 3, 1, 16, 128, 256, 1),
+    ("D_I.dc4", 3, 1, 8, 256, 512, 1),
+    ("G.dc2", 6, 1, 8, 256, 512, 1),         # conv form of the generator's deconvolutions: x side = their OUTPUT
+    ("G.dc3", 4, 1, 16, 128, 256, 1),
+    ("G.dc4", 2, 1, 32, 64, 128, 1),
+]
+
+
+@pytest.mark.parametrize("layer", FULL_WIDTH_LAYERS, ids=[l[0] for l in FULL_WIDTH_LAYERS])
+def test_true_width_layers_with_shipped_tiles_match_the_oracle(pkg, layer):
+    hl, lay, _, _ = pkg
+    name, N, Ti, H, Ci, Co, kt = layer
+    rng = np.random.RandomState(abs(hash(name)) % 2 ** 31)
+    x = rng.uniform(-1, 1, (N, Ci, Ti, H, H))
+    W = rng.randn(Co, Ci, kt, 4, 4) * np.sqrt(2.0 / ((Ci + Co) * 16 * kt))          # GlorotNormal scale (model/net.py:131,172)
+    b = rng.randn(Co) * 0.1
+    stride, pad = (1, 2, 2), (0, 1, 1)
+    y_ref = F.conv3d_fwd(x, W, b, stride, pad)
+    gy = rng.randn(*y_ref.shape)
+    gx_ref, gW_ref, _ = F.conv3d_bwd(x, W, gy, stride, pad)
+    xd, wd, bd, gyd = lay.act_to_dev(dev(x)), lay.conv_w_to_dev(dev(W)), dev(b), lay.act_to_dev(dev(gy))
+    ran = {}
+    for kind in ("fprop", "dgrad", "wgrad"):
+        codes = shipped_codes(kind, Ti, H, Ci, Co, kt)
+        assert codes, "the shipped tile table has no entry for %s %s" % (name, kind)
+        for code in sorted(set(codes) | {0}):                          # 0 = the library's own heuristic
+            g = hl.make_geom(N, Ti, H, H, Ci, Co, kt)
+            g.tile = code
+            if kind == "fprop":
+                yd = torch.full((N, g.To, g.Ho, g.Wo, Co), 3.0, device="cuda")
+                hl.conv_fprop(g, xd, wd, bd, yd)
+                err, tol = rel_l2(lay.act_from_dev(yd, Co), y_ref), FWD_TOL
+            elif kind == "dgrad":
+                gxd = torch.full_like(xd, 7.0)
+                hl.conv_dgrad(g, gyd, wd, None, gxd)
+                err, tol = rel_l2(lay.act_from_dev(gxd, Ci), gx_ref), BWD_TOL
+            else:
+                dwd = torch.zeros_like(wd)
+                hl.conv_wgrad(g, xd, gyd, dwd)
+                err, tol = rel_l2(lay.conv_w_from_dev(dwd, Ci, 3), gW_ref), BWD_TOL
+            ran[(kind, code)] = err
+            assert err < tol, (name, kind, code, err)
+    print(name, {"%s/%d" % k: "%.1e" % v for k, v in ran.items()})
+
+
+def _f64(p):
+    return {k: (v.astype(F64) if v.dtype.kind == 'f' else v) for k, v in p.items()}
+
+
+def _inject(lay, rnd):
+    d = rnd['gen']
+    inject = {'t': rnd['t'], 'gen': {'h0': dev(d['h0']), 'e': dev(d['e']), 'zc': dev(d['zc']),
+                                     'labels': None if d['labels'] is None else dev(d['labels'], torch.int32)}}
+    for k in ('noise_i_real', 'noise_v_real', 'noise_i_fake', 'noise_v_fake'):
+        inject[k] = [lay.act_to_dev(dev(a)) for a in rnd[k]]
+    return inject
+
+
+def _params_rel_l2(net, ref):
+    got = net.export_reference_params()
+    num = den = 0.0
+    for k, v in ref.items():
+        if v.dtype.kind != 'f' or 'avg_' in k:
+            continue
+        if k.startswith('dc') and k.endswith('/b') and ('bn%s/gamma' % k[2]) in ref:
+            continue        # pre-BatchNorm biases: exact-zero gradient on the device, rounding noise in the oracle (nets._Net.BIAS_NOTE)
+        a = np.asarray(got[k].cpu() if torch.is_tensor(got[k]) else got[k], F64)
+        num += float(((a - v) ** 2).sum())
+        den += float((v ** 2).sum())
+    return (num / den) ** 0.5
+
+
+def test_free_running_three_iterations_stay_within_1e4(pkg):
+    """The device keeps its own parameters, Adam moments and BatchNorm statistics for three iterations (no teacher
+    forcing); oracle and device see the same randomness.  SURVEY 8c: weights rel-L2 <= 1e-4 after 3 steps; losses and
+    the generated clip at the forward tolerance."""
+    hl, lay, nets, step = pkg
+    model, nf, n, dim_zl = 'infogan', 8, 4, 6
+    rng = np.random.RandomState(3)
+    gen = _f64(onet.init_generator(rng, dim_zl=dim_zl, n_filters=nf))
+    di = _f64(onet.init_discriminator(rng, 2, 3, 7, nf))
+    dv = _f64(onet.init_discriminator(rng, 3, 3, 7, nf))
+    G, DI, DV = nets.GenNet(dim_zl=dim_zl, n_filters=nf), nets.DisNet(2, 3, 7, nf, use_noise=True), nets.DisNet(3, 3, 7, nf, use_noise=True)
+    og, oi, ov = (oupd.new_adam_state(q) for q in (gen, di, dv))
+    for net, p, st in ((G, gen, og), (DI, di, oi), (DV, dv, ov)):       # identical START only
+        net.load_reference_params(p)
+        net.load_adam_state(st)
+    ts = step.TrainStep(model, G, DI, DV)
+    for it in range(3):
+        x_real = rng.uniform(-1, 1, (n, 3, 16, 64, 64))
+        t_real = rng.randint(0, 6, n)
+        rnd = oupd.draw_step_randomness(rng, model, n, 3, nf, dim_zl=dim_zl, dtype=F64)
+        ref = oupd.update_core(model, gen, di, dv, og, oi, ov, x_real, t_real, rnd, dim_zl=dim_zl, keep=True)
+        out = ts.run(dev(x_real), dev(t_real, torch.int32), _inject(lay, rnd))
+        l = ts.losses()
+        assert abs(l['image_dis/loss'] - ref['loss_dis_i']) < 1e-5 and abs(l['video_dis/loss'] - ref['loss_dis_v']) < 1e-5, it
+        assert abs(l['image_gen/loss'] - ref['loss_gen']) < 1e-5, it
+        assert rel_l2(lay.act_from_dev(out['x_fake'], 3), ref['x_fake'][:, :3]) < 1e-5, it
+    errs = {name: _params_rel_l2(net, p) for name, net, p in (('G', G, gen), ('D_I', DI, di), ('D_V', DV, dv))}
+    print('free-running parameters rel-L2 after 3 iterations:', errs)
+    assert all(e < 1e-4 for e in errs.values()), errs
+    assert G.t == DI.t == DV.t == 3
+
+
+def test_single_channel_networks_and_step(pkg):
+    """in_channels / out_channels = 1 (16x1x64x64 clips, no labels): discriminators, generator and one full iteration."""
+    hl, lay, nets, step = pkg
+    nf, n = 8, 3
+    rng = np.random.RandomState(41)
+    gen = _f64(onet.init_generator(rng, dim_zl=0, out_channels=1, n_filters=nf))
+    di = _f64(onet.init_discriminator(rng, 2, 1, 1, nf))
+    dv = _f64(onet.init_discriminator(rng, 3, 1, 1, nf))
+    G, DI, DV = nets.GenNet(dim_zl=0, out_channels=1, n_filters=nf), nets.DisNet(2, 1, 1, nf, use_noise=True), nets.DisNet(3, 1, 1, nf, use_noise=True)
+    og, oi, ov = (oupd.new_adam_state(q) for q in (gen, di, dv))
+    for net, p, st in ((G, gen, og), (DI, di, oi), (DV, dv, ov)):
+        net.load_reference_params(p)
+        net.load_adam_state(st)
+    # net level: generator forward, clip tensor [n][T][64][64][4] with three zero planes
+    draw = onet.gen_draw(rng, n, dim_zl=0, dtype=F64)
+    import copy
+    x_ref, _, _ = onet.gen_forward(copy.deepcopy(gen), draw)
+    xd, _ = G.forward(n, {'h0': dev(draw['h0']), 'e': dev(draw['e']), 'zc': dev(draw['zc']), 'labels': None}, update_stats=False)
+    assert rel_l2(lay.act_from_dev(xd, 1), x_ref.transpose(1, 2, 0, 3, 4)) < 1e-5
+    assert float(xd[..., 1:].abs().max()) == 0.0
+    # step level
+    ts = step.TrainStep('normal', G, DI, DV)
+    x_real = rng.uniform(-1, 1, (n, 1, 16, 64, 64))
+    rnd = oupd.draw_step_randomness(rng, 'normal', n, 1, nf, dim_zl=0, dtype=F64)
+    ref = oupd.update_core('normal', gen, di, dv, og, oi, ov, x_real, None, rnd, dim_zl=0, keep=True)
+    out = ts.run(dev(x_real), None, _inject(lay, rnd))
+    l = ts.losses()
+    assert abs(l['image_dis/loss'] - ref['loss_dis_i']) < 1e-5 and abs(l['video_dis/loss'] - ref['loss_dis_v']) < 1e-5
+    assert abs(l['image_gen/loss'] - ref['loss_gen']) < 1e-5
+    assert rel_l2(lay.act_from_dev(out['x_fake'], 1), ref['x_fake'][:, :1]) < 1e-5
+    tight = ref['min_margin'] > 2e-6
+    gtol = 1e-4 if tight else 0.15
+    assert rel_l2(lay.act_from_dev(out['gx_fake'], 1), ref['gx_fake']) < gtol, ref['min_margin']
+    for name, net, refg in (('D_I', DI, ref['grads_dis_i']), ('D_V', DV, ref['grads_dis_v']), ('G', G, ref['grads_gen'])):
+        got = net.export_reference_grads()
+        for k in refg:
+            if k.endswith('/W'):
+                assert rel_l2(got[k], refg[k]) < gtol, (name, k, ref['min_margin'])
+    errs = {name: _params_rel_l2(net, p) for name, net, p in (('G', G, gen), ('D_I', DI, di), ('D_V', DV, dv))}
+    assert all(e < (1e-4 if tight else 1e-2) for e in errs.values()), errs

@@ -24,15 +24,29 @@ def _dot(a, b):
     return float(torch.dot(a.reshape(-1).double(), b.reshape(-1).double()))
 
 
-@pytest.mark.parametrize("precision,tol", [("f32", 2e-5), ("bf16", 2e-2)])
-def test_conv_passes_are_adjoint_and_linear_at_full_size(precision, tol):
+def _step_layers(batch):
+    """the geometries ONE iteration at this per-GPU batch launches: D runs real and fake clips as one call of
+    2 * batch (fprop / wgrad / dgrad for its own loss) and batch alone for G's loss; G runs 16 * batch frames"""
+    seen, out = set(), []
+    for lay_ in _layers(batch) + [l for l in _layers(2 * batch) if l[0].startswith('D_')]:
+        if lay_[1:7] not in seen:
+            seen.add(lay_[1:7])
+            out.append(lay_)
+    return out
+
+
+@pytest.mark.parametrize("precision,tol,batch", [("f32", 2e-5, 32), ("bf16", 2e-2, 32), ("bf16", 2e-2, 256)],
+                         ids=["f32-b32", "bf16-b32", "bf16-b256-configs2"])
+def test_conv_passes_are_adjoint_and_linear_at_full_size(precision, tol, batch):
+    """batch 32 = BASELINE configs[1]; bf16 at batch 256 = configs[2] (the shipped tile table holds its geometries:
+    D at 512 and 256 clips, G at 4096 frames)."""
     import mocogan_chainer_amd.hiplib as hl
     hl.load()
     hl.set_autotune(True)
     gen = torch.Generator(device='cuda')
     gen.manual_seed(5)
     try:
-        for name, N, T, H, Ci, Co, kt, ci_real in _layers(32):
+        for name, N, T, H, Ci, Co, kt, ci_real in _step_layers(batch):
             g = hl.make_geom(N, T, H, H, Ci, Co, kt, precision=precision)
             x = torch.randn((N, T, H, H, Ci), device='cuda', generator=gen)
             if Ci == 4:
@@ -59,6 +73,7 @@ def test_conv_passes_are_adjoint_and_linear_at_full_size(precision, tol):
             hl.conv_fprop(g, 2 * x - 3 * x2, w, None, y3)
             err = float(torch.linalg.vector_norm((y3 - (2 * y - 3 * y2)).double()) / torch.linalg.vector_norm(y3.double()))
             assert err < (5e-6 if precision == "f32" else 2e-2), (name, err)
+            del x, x2, y, y2, y3, gy, gx, gw, w
     finally:
         hl.set_autotune(False)
 

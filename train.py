@@ -11,11 +11,9 @@ from pathlib import Path
 
 import numpy as np
 
-from model.net import ImageGenerator, ImageDiscriminator, VideoDiscriminator
-from model.updater import Updater
-from datasets import MugDataset, MovingMnistDataset, SyntheticDataset
-from util import log_tensorboard
-from mocogan_chainer_amd import trainer as T
+from datasets import MugDataset, MovingMnistDataset, SyntheticDataset      # torch-free: all a loader worker needs
+# (model.net, model.updater, util and the trainer -- torch and the HIP binding -- are imported inside main(): the
+#  loader's spawned worker processes re-import this module and must stay light)
 
 
 def parse_args(argv=None):
@@ -50,6 +48,9 @@ def parse_args(argv=None):
     p.add_argument('--model', default='normal', choices=['normal', 'cgan', 'infogan'], help='model variant')
     p.add_argument('--synthetic_size', type=int, default=256, help='clips in the synthetic dataset')
     p.add_argument('--seed', type=int, default=0)
+    p.add_argument('--channel', type=int, default=3, choices=[1, 3],
+                   help="colour planes of the clips: 3 = the reference's constant (train.py:49); 1 = grey-scale clips "
+                        "(the Moving-MNIST shape 16x1x64x64; mnist and synthetic datasets)")
     # MI355X-path options (no counterpart in the reference's train.py)
     p.add_argument('--mfma', choices=['f32', 'bf16'], default='f32',
                    help="operand type of the convolution GEMMs (accumulation, parameters, Adam: always fp32)")
@@ -65,11 +66,15 @@ def parse_args(argv=None):
 
 def main(argv=None):
     args = parse_args(argv)
-    size, channel, video_length = 64, 3, 16                     # train.py:48-50
+    size, channel, video_length = 64, args.channel, 16           # train.py:48-50 (channel is the constant 3 there)
     use_noise, noise_sigma = True, 0.2                           # train.py:56-57
     nf = args.n_filters_gen                                      # the reference passes n_filters_gen to all three nets
 
     import torch
+    from model.net import ImageGenerator, ImageDiscriminator, VideoDiscriminator
+    from model.updater import Updater
+    from util import log_tensorboard
+    from mocogan_chainer_amd import trainer as T
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     if not torch.cuda.is_available():
@@ -88,9 +93,11 @@ def main(argv=None):
     np.random.seed(args.seed)                                    # identical initial weights on every rank
 
     if args.dataset_type == "mug":
+        if channel != 3:
+            raise ValueError('--channel 1 needs --dataset_type mnist or synthetic (MUG clips are RGB)')
         num_labels, train_dataset = 6, MugDataset(args.dataset, video_length)
     elif args.dataset_type == "mnist":
-        num_labels, train_dataset = 0, MovingMnistDataset(args.dataset, video_length)
+        num_labels, train_dataset = 0, MovingMnistDataset(args.dataset, video_length, channels=channel)
     else:
         num_labels, train_dataset = 6, SyntheticDataset(args.synthetic_size, 6, channel, video_length, size, seed=rank)
 
@@ -146,6 +153,16 @@ def main(argv=None):
                        trigger=(args.log_tensorboard_interval, 'epoch'))
     if args.resume:
         T.load_npz(args.resume, trainer)
+    if exchange is not None:
+        # Data parallel (no reference counterpart).  Replicas are identical by construction (same seed) and stay so
+        # because every rank applies the same averaged gradient; rank 0's parameters, Adam moments and running
+        # statistics are still broadcast once, after construction / resume, so that nothing depends on that.
+        # Epoch semantics: every rank walks the WHOLE dataset in its own order with its own batchsize, i.e. one
+        # "epoch" is world-size passes over the data and --max_epoch counts those; BatchNorm running statistics
+        # are per rank and rank 0's are the ones saved.
+        for link in (image_gen, image_dis, video_dis):
+            net = link.impl
+            exchange.broadcast_params([net.fp.p, net.fp.m, net.fp.v] + list(net.running.values()))
 
     if rank == 0:
         # the reference's start-up banner (train.py:165-187), same lines and order
