@@ -101,6 +101,50 @@ int mcg_conv_dgrad(const mcg_conv_geom* g, const float* y, const float* w, const
  * atomics (split-K over pixels). */
 int mcg_conv_wgrad(const mcg_conv_geom* g, const float* x, const float* y, float* dw, void* stream);
 
+/* ---- fused epilogues of mcg_conv_fprop / mcg_conv_dgrad ---------------------------------------------------
+ * What the reference does as separate Chainer function calls right after (forward) or before (backward) a
+ * convolution -- BatchNormalization's statistics, leaky_relu + add_noise behind D's first layer
+ * (model/net.py:148-149,189-190), the per-channel sums of BatchNormalization's backward, the leaky_relu mask of the
+ * first layer's gradient -- computed on the GEMM's accumulators before they are stored, so the tensors are not read
+ * again by a pass of their own.  All sums are per block tile and combined in a fixed order by the *_from_partials
+ * entry points below: no float atomics, results are reproducible.
+ *
+ * "rows" are the rows of the launch's OUTPUT ([pixels][C], C = Co for fprop, Ci for dgrad); with groups == 2 the
+ * batch items n < N/2 form statistics group 0 and the others group 1 (D runs the real and the fake clips of an
+ * iteration as one batch but Chainer normalises each call on its own, model/updater.py:97-98,107-108).
+ * Fused epilogues need the launch to own whole output elements: they are refused (MCG_ERR_UNSUPPORTED) together with
+ * a split-K tile code, tanh, accumulate, or a strided / permuted x in dgrad. */
+enum { MCG_SUMS_NONE = 0,
+       MCG_SUMS_STATS = 1,     /* (sum v, sum v^2) of the stored values          -> mcg_bn_stats_from_partials      */
+       MCG_SUMS_BN_BWD = 2,    /* (sum g', sum g' x_hat), g' = v * act'(bn(y))   -> mcg_bn_act_bwd_from_partials   */
+       MCG_SUMS_COL = 3 };     /* (sum v, -)                                     -> mcg_colsum_from_partials       */
+typedef struct mcg_conv_epilogue {
+    int32_t sums;               /* MCG_SUMS_* */
+    int32_t groups;             /* 1 or 2 statistics groups (halves of the batch) */
+    float* part;                /* [n_slots][groups][2][C] floats, mcg_conv_epilogue_part_bytes() */
+    const float* bn_y;          /* MCG_SUMS_BN_BWD: the BatchNorm input saved by the forward pass, laid out like the output */
+    const float* bn_stats[2];   /*                  per group: the 4*C floats mcg_bn_stats wrote */
+    int32_t bn_act;             /*                  MCG_ACT_RELU / MCG_ACT_LRELU behind that BatchNorm */
+    /* fprop only: out = act(conv + bias) + noise, and the sign of the pre-activation as one bit per element */
+    int32_t act;                /* MCG_ACT_NONE (nothing of this block applies) or MCG_ACT_LRELU */
+    const float* addend[2];     /* per group: pre-scaled noise laid out like the group's output rows, or NULL */
+    float sigma;                /* else sigma * N(0,1) from Philox4x32-10 (seed, stream_id[group]) when sigma > 0: one
+                                 * counter per (row quad, channel) of the group's output -- element (m, c) is normal
+                                 * m & 3 of counter (m >> 2) * C + c (mcg_randn_rowquad draws the same stream) */
+    uint64_t seed, stream_id[2];
+    uint32_t* mask_out;         /* [rows][(C+31)/32] words, bit c & 31 of word c >> 5 set <=> pre-activation >= 0; or NULL */
+    /* dgrad only: v *= (mask bit ? 1 : 0.2) -- leaky_relu's backward from the bits the forward pass stored */
+    const uint32_t* mask_in;
+    /* out (host side, valid after the call): */
+    int32_t n_slots, slot_stride;   /* part holds n_slots slots, slot_stride floats apart; group i starts i*2*C in */
+} mcg_conv_epilogue;
+/* upper bound of the bytes `part` needs for this geometry (any tile choice); pass = 0 fprop, 1 dgrad */
+int64_t mcg_conv_epilogue_part_bytes(const mcg_conv_geom* g, int pass, int groups);
+int mcg_conv_fprop_ex(const mcg_conv_geom* g, const float* x, const float* w, const float* bias, float* y,
+                      mcg_conv_epilogue* ep, void* stream);
+int mcg_conv_dgrad_ex(const mcg_conv_geom* g, const float* y, const float* w, const float* bias, float* x,
+                      mcg_conv_epilogue* ep, void* stream);
+
 /* ---- full-window layers: D's dc5 (model/net.py:137,178) and G's dc1 (model/net.py:44) ------ */
 /* x is [M][K] (one dense window per row), y is [M][Co], w is [Co][K]. */
 int mcg_fc_fprop(int M, int K, int Co, const float* x, const float* w, const float* bias,
@@ -167,6 +211,19 @@ int mcg_bn_act_bwd_from_sums(int64_t M, int64_t M_total, int C, const float* g_o
                              const double* global_sums, float* gx, float* dgamma, float* dbeta,
                              void* workspace, void* stream);
 
+/* The second halves of the three passes above, starting from per-tile partial sums written by a fused conv
+ * epilogue (part / n_slots / slot_stride as returned in mcg_conv_epilogue; `part` already offset to the group):
+ *   mcg_bn_stats_from_partials   == mcg_bn_stats' finalize      (M = rows of the group)
+ *   mcg_bn_act_bwd_from_partials == mcg_bn_act_bwd without its reduction pass over g_out and y
+ *   mcg_colsum_from_partials     == mcg_colsum_acc without its pass over g */
+int mcg_bn_stats_from_partials(int64_t M, int C, const float* part, int n_slots, int slot_stride, const float* gamma,
+                               const float* beta, float* stats, float* avg_mean, float* avg_var, float eps, float decay,
+                               void* stream);
+int mcg_bn_act_bwd_from_partials(int64_t M, int C, const float* g_out, const float* y, const float* stats,
+                                 const float* gamma, int act, const float* part, int n_slots, int slot_stride, float* gx,
+                                 float* dgamma, float* dbeta, void* workspace, void* stream);
+int mcg_colsum_from_partials(int C, const float* part, int n_slots, int slot_stride, float* db, void* stream);
+
 /* db += column sums of g [M][C] (bias gradient of every conv/deconv). */
 int mcg_colsum_acc(int64_t M, int C, const float* g, float* db, void* workspace, void* stream);
 
@@ -219,6 +276,9 @@ int mcg_adam_wd(int64_t n, float* p, const float* g, float* m, float* v, double 
 
 /* out[i] = sigma * N(0,1), the same Philox stream mcg_bn_act_fwd / mcg_pack_clip draw from. */
 int mcg_randn(int64_t n, float sigma, uint64_t seed, uint64_t stream_id, float* out, void* stream);
+/* out[M][C] = sigma * N(0,1) in the element order of the fused first-layer epilogue (mcg_conv_epilogue.sigma):
+ * element (m, c) is normal m & 3 of Philox counter (m >> 2) * C + c.  M % 4 == 0. */
+int mcg_randn_rowquad(int64_t M, int C, float sigma, uint64_t seed, uint64_t stream_id, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,8 @@ def _stale():
     if not os.path.exists(out):
         return True
     t = os.path.getmtime(out)
-    deps = [os.path.join(HERE, s) for s in SOURCES] + [os.path.join(ROOT, "include", "mocogan_hip.h")]
+    deps = [os.path.join(HERE, s) for s in SOURCES] + [os.path.join(HERE, "csrc", "mcg_common.h"),
+                                                       os.path.join(ROOT, "include", "mocogan_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

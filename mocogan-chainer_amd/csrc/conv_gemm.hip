@@ -23,6 +23,7 @@
 #include <stdint.h>
 #include <mutex>
 #include "mocogan_hip.h"
+#include "mcg_common.h"
 
 namespace {
 
@@ -58,6 +59,23 @@ struct Geom {
     int tile, bk;      // caller's choice (mcg_conv_geom.tile): tile 0 = library heuristic, 1/2/3; bk 0 = heuristic, 32/64
     int ksplit;        // fprop / dgrad: number of K splits (1, 2 or 4) from mcg_conv_geom.tile / 1000
 };
+
+// Fused epilogue of fprop / dgrad (mcg_conv_epilogue on the device side).  mode == 0: the plain store.
+typedef unsigned long long u64;
+enum { EPI_STATS = 1, EPI_BNBWD = 2, EPI_COL = 4, EPI_SUMS = 7, EPI_ACT = 8, EPI_MASKMUL = 16 };
+struct Epi {
+    int mode;
+    int groups;                 // 1 or 2
+    int half_n;                 // groups == 2: batch items >= half_n are group 1
+    long long grp_rows;         // rows of one group (fprop with noise: local row index = row - group * grp_rows)
+    float* part; int slot_stride;
+    const float* bn_y; const float* bn_stats[2]; int bn_act;
+    const float* addend[2]; float sigma; u64 seed; u64 stream[2];
+    u32* mask_out; const u32* mask_in; int mask_cb;
+};
+struct RowInfo { long long base; long long pix; int grp; bool ok; };   // base: element offset of the row's column 0 in the output
+
+constexpr float EPI_LRELU_SLOPE = 0.2f;          // model/net.py:149-155,190-196
 
 __device__ __forceinline__ long long x_batch_off(const Geom& g, int n) {
     if (g.perm_n) return (long long)(n % g.perm_n) * g.xs0 + (long long)(n / g.perm_n) * g.xs1;
@@ -96,7 +114,9 @@ struct FpropP {
     static constexpr bool A_KC = true, B_KC = true;
     static constexpr int ORDER = 0;
     static constexpr int NA = BM * BK / 4 / NTHREADS, NB = BN * BK / 4 / NTHREADS;
+    static constexpr bool HAS_EPI = true;
     Geom g;
+    Epi e;
     const float* x; const float* w; const float* bias; float* y;
     int M, K;
     int kchunk;         // K range of one blockIdx.z (multiple of BK; == K without split-K)
@@ -173,6 +193,16 @@ struct FpropP {
         if (kchunk >= K) y[(long long)m * g.Co + n] = v + (bias ? bias[n] : 0.f);
         else atomicAdd(y + (long long)m * g.Co + n, v + (bias && zz == 0 ? bias[n] : 0.f));
     }
+    // ---- fused epilogue interface ----
+    __device__ int out_cols() const { return g.Co; }
+    __device__ float* out_ptr() const { return y; }
+    __device__ int slot(int bx, int /*bz*/) const { return bx; }
+    __device__ RowInfo row_info(int m) const {
+        RowInfo r;
+        r.ok = m < M; r.base = (long long)m * g.Co; r.pix = m;
+        r.grp = (e.groups == 2 && (long long)m >= e.grp_rows) ? 1 : 0;
+        return r;
+    }
 };
 
 // ---------------- dgrad (one output-parity class per blockIdx.z) ----------------
@@ -181,7 +211,9 @@ struct DgradP {
     static constexpr bool A_KC = true, B_KC = false;
     static constexpr int ORDER = 1;
     static constexpr int NA = BM * BK / 4 / NTHREADS, NB = BN * BK / 4 / NTHREADS;
+    static constexpr bool HAS_EPI = true;
     Geom g;
+    Epi e;
     const float* y; const float* w; const float* bias; float* x;
     int M, K, act, accumulate;   // M = N*Ti*Ho*Wo pixels of ONE parity class; K = kt*4*Co
     int ph, pw;
@@ -305,11 +337,27 @@ struct DgradP {
         if (accumulate) v += x[o];
         x[o] = v;
     }
+    // ---- fused epilogue interface (dense x only: make_epi checks) ----
+    __device__ int out_cols() const { return g.Ci; }
+    __device__ float* out_ptr() const { return x; }
+    __device__ int slot(int bx, int bz) const { return (bz & 3) * gxm + bx; }
+    __device__ RowInfo row_info(int m) const {
+        RowInfo r;
+        r.ok = m < M;
+        const int mm = r.ok ? m : 0;
+        int w2 = mm & (g.Wo - 1), h2 = (mm >> g.lgWo) & (g.Ho - 1), q = mm >> (g.lgWo + g.lgHo);
+        int t = div_N(g, q), nb = q - t * g.N;
+        r.pix = ((long long)(nb * g.Ti + t) * g.Hi + 2 * h2 + ph) * g.Wi + 2 * w2 + pw;
+        r.base = r.pix * g.Ci;
+        r.grp = (e.groups == 2 && nb >= e.half_n) ? 1 : 0;
+        return r;
+    }
 };
 
 // ---------------- wgrad (blockIdx.z = pixel split) ----------------
 template <int BM, int BN, int BK>
 struct WgradP {
+    static constexpr bool HAS_EPI = false;
     static constexpr bool A_KC = false, B_KC = false;
     static constexpr int ORDER = 2;
     static constexpr int NA = BM * BK / 4 / NTHREADS, NB = BN * BK / 4 / NTHREADS;
@@ -369,6 +417,7 @@ struct WgradP {
 // split over K (blockIdx.z) because M x N is only a handful of tiles.
 template <int BM, int BN, int BK>
 struct FcFpropP {
+    static constexpr bool HAS_EPI = false;
     static constexpr bool A_KC = true, B_KC = true;
     static constexpr int ORDER = 0;
     static constexpr int NA = BM * BK / 4 / NTHREADS, NB = BN * BK / 4 / NTHREADS;
@@ -410,6 +459,7 @@ struct FcFpropP {
 // split over m (blockIdx.z), fp32 atomics -- the structure of WgradP without the pixel gather.
 template <int BM, int BN, int BK>
 struct FcWgradP {
+    static constexpr bool HAS_EPI = false;
     static constexpr bool A_KC = false, B_KC = false;
     static constexpr int ORDER = 2;
     static constexpr int NA = BM * BK / 4 / NTHREADS, NB = BN * BK / 4 / NTHREADS;
@@ -448,9 +498,129 @@ struct FcWgradP {
 };
 
 // ------------------------------------------------------------------------------------------
+// Fused epilogue (fprop / dgrad): everything the step does to a convolution's output element by element, or as a
+// per-channel sum over it, applied to the accumulators in their MFMA layout before the one store.
+//   * a lane of a 32x32 accumulator tile holds ONE column (channel) and 16 rows, in four quads of consecutive
+//     rows: per-channel sums are lane-local, then one cross-half shuffle, one LDS exchange between the waves that
+//     share the columns, and ONE partial per (block tile, group, channel): deterministic, no atomics;
+//   * the sign mask of D's first layer is a wave ballot: its two halves are the 32-column words of two rows;
+//   * in-kernel noise draws one Philox counter per (row quad, channel), whose four normals belong to the four
+//     rows the lane holds of that channel -- no normal is generated twice and none crosses lanes.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float epi_act_mask(float v, int act) {
+    if (act == MCG_ACT_RELU) return v > 0.f ? 1.f : 0.f;
+    if (act == MCG_ACT_LRELU) return v < 0.f ? EPI_LRELU_SLOPE : 1.f;
+    return 1.f;
+}
+
+template <class P, int BM, int BN, int WM, int WN, int TM, int TN, int EPI>
+__device__ __forceinline__ void fused_epilogue(const P& p, f32x16 (&acc)[TM][TN], int m0, int n0, int bx, int bz,
+                                               int tid, float* red) {
+    // EPI selects what this instantiation can do (each class has its own register needs; the plain kernel is EPI = 0):
+    //   1: column sums of the stored values (BN statistics, bias gradient) and the stored leaky_relu mask (dgrad)
+    //   2: the sums of BatchNorm's backward pass          3: leaky_relu + noise + mask bits (D's first layer)
+    constexpr int ENABLED = EPI == 1 ? (EPI_STATS | EPI_COL | EPI_MASKMUL) : EPI == 2 ? EPI_BNBWD : EPI_ACT;
+    const Epi& e = p.e;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+    const int C = p.out_cols();
+    float* out = p.out_ptr();
+    const int mode = e.mode & ENABLED;
+    const bool philox = (mode & EPI_ACT) && !e.addend[0] && e.sigma > 0.f;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {                       // one 32-column block at a time: its per-column constants stay live
+        const int col = n0 + wn0 + b * 32 + li;
+        const bool cok = col < C;
+        const float bv = (p.bias && cok) ? p.bias[col] : 0.f;
+        float s0[2] = {0.f, 0.f}, s1[2] = {0.f, 0.f};
+        float mu[2] = {0.f, 0.f}, is[2] = {0.f, 0.f}, sc[2] = {0.f, 0.f}, sh[2] = {0.f, 0.f};
+        if (mode & EPI_BNBWD) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+                if (g < e.groups && cok) {
+                    const float* st = g ? e.bn_stats[1] : e.bn_stats[0];        // (no dynamic index into the kernel argument)
+                    mu[g] = st[col]; is[g] = st[C + col]; sc[g] = st[2 * C + col]; sh[g] = st[3 * C + col];
+                }
+        }
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int row0 = m0 + wm0 + a * 32 + 8 * q + 4 * lh;
+                asm volatile("" : "+v"(row0));           // keeps the row decode INSIDE this iteration: hoisted out of the
+                                                         // column loop, the 16 * TM decoded rows would cost a wave of occupancy
+                f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                if (philox) {            // rows row0 .. row0+3 lie in one group (grp_rows % 4 == 0: make_epi)
+                    const RowInfo r0 = p.row_info(row0);
+                    const long long lrow = r0.pix - (r0.grp ? e.grp_rows : 0);
+                    z = mcg::randn4((u64)((lrow >> 2) * C + col), e.seed, r0.grp ? e.stream[1] : e.stream[0]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const RowInfo ri = p.row_info(row0 + i);
+                    float v = acc[a][b][4 * q + i] + bv;
+                    const bool ok = ri.ok && cok;
+                    const long long o = ri.base + col;
+                    if (mode & EPI_ACT) {
+                        const bool pos = !(v < 0.f);
+                        if (e.mask_out) {
+                            const u64 bal = __ballot(pos);                       // low half: this row at lh = 0, high half: at lh = 1
+                            const int cb = (n0 + wn0 + b * 32) >> 5;
+                            if (li == 0 && ri.ok && cb < e.mask_cb) e.mask_out[ri.pix * e.mask_cb + cb] = lh ? (u32)(bal >> 32) : (u32)bal;
+                        }
+                        v = pos ? v : v * EPI_LRELU_SLOPE;
+                        if (e.addend[0]) { if (ok) v += (ri.grp ? e.addend[1] : e.addend[0])[(ri.pix - (ri.grp ? e.grp_rows : 0)) * C + col]; }
+                        else v = fmaf(e.sigma, z[i], v);
+                    }
+                    if (mode & EPI_MASKMUL) {
+                        const u32 wd = ok ? e.mask_in[ri.pix * e.mask_cb + (col >> 5)] : 0xffffffffu;
+                        v = ((wd >> (col & 31)) & 1u) ? v : v * EPI_LRELU_SLOPE;
+                    }
+                    if (ok) out[o] = v;
+                    if (mode & EPI_SUMS) {
+                        float t0 = v, t1 = v * v;
+                        if (mode & EPI_BNBWD) {
+                            const float yv = ok ? e.bn_y[o] : 0.f;
+                            const float gb = v * epi_act_mask(fmaf(yv, ri.grp ? sc[1] : sc[0], ri.grp ? sh[1] : sh[0]), e.bn_act);
+                            t0 = gb; t1 = gb * (yv - (ri.grp ? mu[1] : mu[0])) * (ri.grp ? is[1] : is[0]);
+                        }
+                        if (!ok) { t0 = 0.f; t1 = 0.f; }
+                        if (ri.grp) { s0[1] += t0; s1[1] += t1; } else { s0[0] += t0; s1[0] += t1; }
+                    }
+                }
+            }
+        if (mode & EPI_SUMS) {
+            // lanes l and l + 32 hold the same column; the WM waves that share the columns meet in LDS below
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                s0[g] += __shfl_xor(s0[g], 32, 64);
+                s1[g] += __shfl_xor(s1[g], 32, 64);
+                if (lh == 0) {
+                    float* d = red + (((wave / WN) * BN + wn0 + b * 32 + li) * 2 + g) * 2;
+                    d[0] = s0[g]; d[1] = s1[g];
+                }
+            }
+        }
+    }
+    if (mode & EPI_SUMS) {
+        __syncthreads();
+        const int slot = p.slot(bx, bz);
+        for (int idx = tid; idx < BN * 4; idx += NTHREADS) {
+            const int c = idx >> 2, g = (idx >> 1) & 1, w = idx & 1;
+            if (g >= e.groups || n0 + c >= C) continue;
+            float t = 0.f;
+#pragma unroll
+            for (int wm = 0; wm < WM; ++wm) t += red[((wm * BN + c) * 2 + g) * 2 + w];
+            e.part[(long long)slot * e.slot_stride + (g * 2 + w) * C + n0 + c] = t;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // The GEMM core
 // ------------------------------------------------------------------------------------------
-template <class P, int BM, int BN, int BK>
+template <class P, int BM, int BN, int BK, int EPI = 0>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(P p) {
     // wave grid: 2 x 2, except for the long tiles 256x64 (4 x 1) and 64x256 (1 x 4) whose waves keep 64x64 outputs
     constexpr int WM = (BM >= 4 * BN) ? 4 : (BN >= 4 * BM) ? 1 : 2, WN = 4 / WM;
@@ -600,6 +770,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(P p) {
         atomicAdd(&g_stamp[4], 1ull);
     }
 #endif
+    if constexpr (EPI != 0) {           // its own instantiation: the plain kernel keeps its register allocation
+        fused_epilogue<P, BM, BN, WM, WN, TM, TN, EPI>(p, acc, m0, n0, bx, bz, tid, lds);
+        return;
+    }
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
     for (int a = 0; a < TM; ++a)
@@ -637,7 +811,7 @@ __device__ __forceinline__ s16x4 lds_tr16(const u16* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p);
 }
 
-template <class P, int BM, int BN, int BK>
+template <class P, int BM, int BN, int BK, int EPI = 0>
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(P p) {
     // wave grid: 2 x 2, except for the long tiles 256x64 (4 x 1) and 64x256 (1 x 4) whose waves keep 64x64 outputs
     constexpr int WM = (BM >= 4 * BN) ? 4 : (BN >= 4 * BM) ? 1 : 2, WN = 4 / WM;
@@ -753,6 +927,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(P p) {
         k0 = kn;
     }
 
+    if constexpr (EPI != 0) {
+        fused_epilogue<P, BM, BN, WM, WN, TM, TN, EPI>(p, acc, m0, n0, bx, bz, tid, reinterpret_cast<float*>(lds));
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -877,6 +1055,9 @@ __global__ __launch_bounds__(NTHREADS) void dgrad_c4_kernel(Geom g, const float*
     }
 }
 
+// which fused-epilogue instantiation serves this combination of options (make_epi rejects the others)
+int epi_class(int mode) { return (mode & EPI_ACT) ? 3 : (mode & EPI_BNBWD) ? 2 : 1; }
+
 int ilog2_exact(int v) {
     if (v <= 0 || (v & (v - 1))) return -1;
     int l = 0;
@@ -919,11 +1100,12 @@ int make_geom(const mcg_conv_geom* c, Geom& g) {
 int launch_status() { return hipGetLastError() == hipSuccess ? MCG_OK : MCG_ERR_LAUNCH; }
 
 template <int BM, int BN, int BK, bool BF = false>
-int launch_fprop(const Geom& g, const float* x, const float* w, const float* bias, float* y, hipStream_t s) {
+int launch_fprop(const Geom& g, const float* x, const float* w, const float* bias, float* y, const Epi& e, mcg_conv_epilogue* ep, hipStream_t s) {
     FpropP<BM, BN, BK> p;
-    p.g = g; p.x = x; p.w = w; p.bias = bias; p.y = y;
+    p.g = g; p.e = e; p.x = x; p.w = w; p.bias = bias; p.y = y;
     p.M = g.N * g.To * g.Ho * g.Wo; p.K = g.taps * g.Ci;
-    int splits = g.ksplit;
+    if (ep) { ep->n_slots = (p.M + BM - 1) / BM; ep->slot_stride = e.slot_stride; }
+    int splits = e.mode ? 1 : g.ksplit;                         // a fused epilogue needs whole output elements
     const int ksteps = (p.K + BK - 1) / BK;
     if (splits > ksteps / 8) splits = ksteps / 8;               // keep >= 8 K-steps per block
     if (splits < 1) splits = 1;
@@ -932,19 +1114,26 @@ int launch_fprop(const Geom& g, const float* x, const float* w, const float* bia
     if (splits == 1) p.kchunk = p.K > 0 ? ((p.K + BK - 1) / BK) * BK : BK;
     else if (hipMemsetAsync(y, 0, (size_t)p.M * g.Co * sizeof(float), s) != hipSuccess) return MCG_ERR_LAUNCH;   // the atomics need a cleared y
     dim3 grid((p.M + BM - 1) / BM, (g.Co + BN - 1) / BN, splits);
-    if (BF) hipLaunchKernelGGL((gemm_bf16_kernel<FpropP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
+    if (e.mode) {
+        const int cls = epi_class(e.mode);
+#define MCG_EPI_LAUNCH(K_) do { if (BF) hipLaunchKernelGGL((gemm_bf16_kernel<FpropP<BM, BN, BK>, BM, BN, BK, K_>), grid, dim3(NTHREADS), 0, s, p); \
+                                else hipLaunchKernelGGL((gemm_kernel<FpropP<BM, BN, BK>, BM, BN, BK, K_>), grid, dim3(NTHREADS), 0, s, p); } while (0)
+        if (cls == 1) MCG_EPI_LAUNCH(1); else if (cls == 2) MCG_EPI_LAUNCH(2); else MCG_EPI_LAUNCH(3);
+#undef MCG_EPI_LAUNCH
+    } else if (BF) hipLaunchKernelGGL((gemm_bf16_kernel<FpropP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
     else hipLaunchKernelGGL((gemm_kernel<FpropP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
     return MCG_OK;
 }
 
 template <int BM, int BN, int BK, bool BF = false>
-int launch_dgrad(const Geom& g, const float* y, const float* w, const float* bias, float* x, int act, int acc, hipStream_t s) {
+int launch_dgrad(const Geom& g, const float* y, const float* w, const float* bias, float* x, int act, int acc, const Epi& e, mcg_conv_epilogue* ep, hipStream_t s) {
     DgradP<BM, BN, BK> p;
-    p.g = g; p.y = y; p.w = w; p.bias = bias; p.x = x; p.act = act; p.accumulate = acc;
+    p.g = g; p.e = e; p.y = y; p.w = w; p.bias = bias; p.x = x; p.act = act; p.accumulate = acc;
     p.M = g.N * g.Ti * g.Ho * g.Wo; p.K = g.kt * 4 * g.Co;
+    if (ep) { ep->n_slots = 4 * ((p.M + BM - 1) / BM); ep->slot_stride = e.slot_stride; }
     const long long frame = (long long)g.Ti * g.Hi * g.Wi * g.Ci;
     const bool dense_x = !g.perm_n && g.xs0 == frame;
-    int splits = (act == MCG_ACT_NONE && (acc || dense_x)) ? g.ksplit : 1;
+    int splits = (act == MCG_ACT_NONE && (acc || dense_x) && !e.mode) ? g.ksplit : 1;
     const int ksteps = (p.K + BK - 1) / BK;
     if (splits > ksteps / 8) splits = ksteps / 8;
     if (splits < 1) splits = 1;
@@ -957,7 +1146,13 @@ int launch_dgrad(const Geom& g, const float* y, const float* w, const float* bia
 #else
     dim3 grid(p.gxm, p.gyn, 4 * splits);
 #endif
-    if (BF) hipLaunchKernelGGL((gemm_bf16_kernel<DgradP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
+    if (e.mode) {
+        const int cls = epi_class(e.mode);
+#define MCG_EPI_LAUNCH(K_) do { if (BF) hipLaunchKernelGGL((gemm_bf16_kernel<DgradP<BM, BN, BK>, BM, BN, BK, K_>), grid, dim3(NTHREADS), 0, s, p); \
+                                else hipLaunchKernelGGL((gemm_kernel<DgradP<BM, BN, BK>, BM, BN, BK, K_>), grid, dim3(NTHREADS), 0, s, p); } while (0)
+        if (cls == 1) MCG_EPI_LAUNCH(1); else MCG_EPI_LAUNCH(2);          // (class 3 is fprop only: make_epi)
+#undef MCG_EPI_LAUNCH
+    } else if (BF) hipLaunchKernelGGL((gemm_bf16_kernel<DgradP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
     else hipLaunchKernelGGL((gemm_kernel<DgradP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
     return MCG_OK;
 }
@@ -984,6 +1179,9 @@ int launch_wgrad(const Geom& g, const float* x, const float* y, float* dw, hipSt
 }
 
 // tile / K-depth / MFMA-type dispatch of the launch_* templates
+#ifdef MCG_FAST_BUILD       // compile-time experiments: one tile, one K depth, fp32 only
+#define MCG_TILES(fn, t, BK, BF, ...) do { st = fn<128, 128, 32, false>(__VA_ARGS__); } while (0)
+#else
 #define MCG_TILES(fn, t, BK, BF, ...)                                   \
     do {                                                                \
         if ((t) == 1) st = fn<128, 128, BK, BF>(__VA_ARGS__);           \
@@ -992,6 +1190,7 @@ int launch_wgrad(const Geom& g, const float* x, const float* y, float* dw, hipSt
         else if ((t) == 5) st = fn<64, 256, 32, BF>(__VA_ARGS__);       \
         else st = fn<64, 64, BK, BF>(__VA_ARGS__);                      \
     } while (0)
+#endif
 #define MCG_DISPATCH(fn, t, bk64, bf, ...)                              \
     do {                                                                \
         if (bf) { if (bk64) MCG_TILES(fn, t, 64, true, __VA_ARGS__); else MCG_TILES(fn, t, 32, true, __VA_ARGS__); }      \
@@ -1012,12 +1211,58 @@ extern "C" void mcg_debug_stamps(unsigned long long* out, int reset) {
 }
 #endif
 
-extern "C" int mcg_conv_fprop(const mcg_conv_geom* c, const float* x, const float* w, const float* bias,
-                              float* y, void* stream) {
+namespace {
+
+// mcg_conv_epilogue -> Epi (validated on the host); pass 0 = fprop (C = Co), 1 = dgrad (C = Ci)
+int make_epi(const mcg_conv_epilogue* ep, const Geom& g, int pass, Epi& e) {
+    e = Epi{};
+    if (!ep) return MCG_OK;
+    const int C = pass == 0 ? g.Co : g.Ci;
+    if (ep->groups != 1 && ep->groups != 2) return MCG_ERR_BAD_ARG;
+    if (ep->groups == 2 && (g.N & 1)) return MCG_ERR_BAD_ARG;
+    if (ep->sums < MCG_SUMS_NONE || ep->sums > MCG_SUMS_COL) return MCG_ERR_BAD_ARG;
+    e.groups = ep->groups; e.half_n = g.N / 2;
+    e.grp_rows = pass == 0 ? (long long)(g.N / ep->groups) * g.To * g.Ho * g.Wo : 0;
+    e.slot_stride = ep->groups * 2 * C;
+    e.mask_cb = (C + 31) / 32;
+    if (ep->sums != MCG_SUMS_NONE) {
+        if (!ep->part) return MCG_ERR_BAD_ARG;
+        e.part = ep->part;
+        e.mode |= ep->sums == MCG_SUMS_STATS ? EPI_STATS : ep->sums == MCG_SUMS_BN_BWD ? EPI_BNBWD : EPI_COL;
+        if (ep->sums == MCG_SUMS_BN_BWD) {
+            if (!ep->bn_y || !ep->bn_stats[0] || (ep->groups == 2 && !ep->bn_stats[1])) return MCG_ERR_BAD_ARG;
+            if (ep->bn_act != MCG_ACT_RELU && ep->bn_act != MCG_ACT_LRELU) return MCG_ERR_UNSUPPORTED;
+            e.bn_y = ep->bn_y; e.bn_stats[0] = ep->bn_stats[0]; e.bn_stats[1] = ep->bn_stats[1]; e.bn_act = ep->bn_act;
+        }
+    }
+    if (ep->act != MCG_ACT_NONE) {
+        if (pass != 0 || ep->act != MCG_ACT_LRELU) return MCG_ERR_UNSUPPORTED;
+        if (ep->addend[0] && ep->groups == 2 && !ep->addend[1]) return MCG_ERR_BAD_ARG;
+        if (!ep->addend[0] && ep->sigma > 0.f && (e.grp_rows & 3)) return MCG_ERR_UNSUPPORTED;    // a row quad must not straddle two groups
+        e.mode |= EPI_ACT;
+        e.addend[0] = ep->addend[0]; e.addend[1] = ep->addend[1];
+        e.sigma = ep->sigma; e.seed = ep->seed; e.stream[0] = ep->stream_id[0]; e.stream[1] = ep->stream_id[1];
+        e.mask_out = ep->mask_out;
+    } else if (ep->mask_out) return MCG_ERR_BAD_ARG;
+    if (ep->mask_in) {
+        if (pass != 1) return MCG_ERR_UNSUPPORTED;
+        e.mode |= EPI_MASKMUL; e.mask_in = ep->mask_in;
+    }
+    if (e.mode && g.ksplit > 1) return MCG_ERR_UNSUPPORTED;        // partial tiles cannot carry an epilogue
+    if ((e.mode & EPI_ACT) && (e.mode & ~EPI_ACT)) return MCG_ERR_UNSUPPORTED;            // one class per launch (epi_class)
+    if ((e.mode & EPI_BNBWD) && (e.mode & ~EPI_BNBWD)) return MCG_ERR_UNSUPPORTED;
+    return MCG_OK;
+}
+
+int conv_fprop_impl(const mcg_conv_geom* c, const float* x, const float* w, const float* bias, float* y,
+                    mcg_conv_epilogue* ep, void* stream) {
     Geom g;
     int st = make_geom(c, g);
     if (st) return st;
     if (!x || !w || !y) return MCG_ERR_BAD_ARG;
+    Epi e;
+    if ((st = make_epi(ep, g, 0, e)) != MCG_OK) return st;
+    if (!e.mode) ep = nullptr;
     hipStream_t s = (hipStream_t)stream;
     long long M = (long long)g.N * g.To * g.Ho * g.Wo;
     // Tile choice (measured on MI355X, tools/bench_layers.py): 128x128 only when there are enough tiles
@@ -1030,22 +1275,61 @@ extern "C" int mcg_conv_fprop(const mcg_conv_geom* c, const float* x, const floa
     // grid is small (few resident waves to hide it: measured on dc4); big grids prefer the higher occupancy of 32.
     const long long nblk = ((M + (t == 3 ? 63 : 127)) / (t == 3 ? 64 : 128)) * ((g.Co + (t == 1 ? 127 : 63)) / (t == 1 ? 128 : 64));
     const bool bk64 = (g.taps * g.Ci) % 64 == 0 && (bk ? bk == 64 : (nblk < 1024 || g.prec == MCG_PREC_BF16));
-    MCG_DISPATCH(launch_fprop, t, bk64, g.prec == MCG_PREC_BF16, g, x, w, bias, y, s);
+    MCG_DISPATCH(launch_fprop, t, bk64, g.prec == MCG_PREC_BF16, g, x, w, bias, y, e, ep, s);
     return finish(st);
 }
 
-extern "C" int mcg_conv_dgrad(const mcg_conv_geom* c, const float* y, const float* w, const float* bias,
-                              float* x, int act, int accumulate, void* stream) {
+int conv_dgrad_impl(const mcg_conv_geom* c, const float* y, const float* w, const float* bias, float* x, int act, int accumulate,
+                    mcg_conv_epilogue* ep, void* stream);
+
+}  // namespace
+
+extern "C" int mcg_conv_fprop(const mcg_conv_geom* c, const float* x, const float* w, const float* bias, float* y, void* stream) {
+    return conv_fprop_impl(c, x, w, bias, y, nullptr, stream);
+}
+extern "C" int mcg_conv_fprop_ex(const mcg_conv_geom* c, const float* x, const float* w, const float* bias, float* y,
+                                 mcg_conv_epilogue* ep, void* stream) {
+    if (ep) { ep->n_slots = 0; ep->slot_stride = 0; }
+    return conv_fprop_impl(c, x, w, bias, y, ep, stream);
+}
+extern "C" int mcg_conv_dgrad(const mcg_conv_geom* c, const float* y, const float* w, const float* bias, float* x, int act,
+                              int accumulate, void* stream) {
+    return conv_dgrad_impl(c, y, w, bias, x, act, accumulate, nullptr, stream);
+}
+extern "C" int mcg_conv_dgrad_ex(const mcg_conv_geom* c, const float* y, const float* w, const float* bias, float* x,
+                                 mcg_conv_epilogue* ep, void* stream) {
+    if (ep) { ep->n_slots = 0; ep->slot_stride = 0; }
+    return conv_dgrad_impl(c, y, w, bias, x, MCG_ACT_NONE, 0, ep, stream);
+}
+extern "C" int64_t mcg_conv_epilogue_part_bytes(const mcg_conv_geom* c, int pass, int groups) {
+    if (!c || groups < 1 || groups > 2) return 0;
+    const long long rows = pass == 0 ? (long long)c->N * c->To * c->Ho * c->Wo : (long long)c->N * c->Ti * c->Ho * c->Wo;
+    const long long slots = (pass == 0 ? 1 : 4) * ((rows + 63) / 64);          // the smallest block tile has 64 rows
+    return slots * groups * 2 * (pass == 0 ? c->Co : c->Ci) * (long long)sizeof(float);
+}
+
+namespace {
+
+int conv_dgrad_impl(const mcg_conv_geom* c, const float* y, const float* w, const float* bias, float* x, int act, int accumulate,
+                    mcg_conv_epilogue* ep, void* stream) {
+
     Geom g;
     int st = make_geom(c, g);
     if (st) return st;
     if (!x || !w || !y) return MCG_ERR_BAD_ARG;
     if (act != MCG_ACT_NONE && act != MCG_ACT_TANH) return MCG_ERR_UNSUPPORTED;
+    Epi e;
+    if ((st = make_epi(ep, g, 1, e)) != MCG_OK) return st;
+    if (!e.mode) ep = nullptr;
+    if (e.mode) {                                                // the epilogue addresses x as a dense [pixels][Ci] tensor
+        const long long frame_ = (long long)g.Ti * g.Hi * g.Wi * g.Ci;
+        if (g.perm_n || g.xs0 != frame_ || act != MCG_ACT_NONE || accumulate) return MCG_ERR_UNSUPPORTED;
+    }
     hipStream_t s = (hipStream_t)stream;
     long long M = (long long)g.N * g.Ti * g.Ho * g.Wo;
     int t = g.tile;
     const int bk = g.bk;
-    if (!t && g.Ci == 4 && g.Co == 64 && (g.Wo & 15) == 0) {      // VALU kernel for the padded 3-channel clip
+    if (!t && !e.mode && g.Ci == 4 && g.Co == 64 && (g.Wo & 15) == 0) {      // VALU kernel for the padded 3-channel clip
         const int runs = (int)(M / 16);                          // M = N*Ti*Ho*Wo half-resolution positions
         const int per_block = (NTHREADS / 64) * C4_RUNS_PER_WAVE;
         dim3 grid((runs + per_block - 1) / per_block, 1, 1);
@@ -1067,9 +1351,11 @@ extern "C" int mcg_conv_dgrad(const mcg_conv_geom* c, const float* y, const floa
     }
     const long long nblk = 4 * ((M + (t == 3 ? 63 : 127)) / (t == 3 ? 64 : 128)) * ((g.Ci + (t == 1 ? 127 : 63)) / (t == 1 ? 128 : 64));
     const bool bk64 = (g.kt * 4 * g.Co) % 64 == 0 && (bk ? bk == 64 : (nblk < 1024 || g.prec == MCG_PREC_BF16));
-    MCG_DISPATCH(launch_dgrad, t, bk64, g.prec == MCG_PREC_BF16, g, y, w, bias, x, act, accumulate, s);
+    MCG_DISPATCH(launch_dgrad, t, bk64, g.prec == MCG_PREC_BF16, g, y, w, bias, x, act, accumulate, e, ep, s);
     return finish(st);
 }
+
+}  // namespace
 
 extern "C" int mcg_conv_wgrad(const mcg_conv_geom* c, const float* x, const float* y, float* dw, void* stream) {
     Geom g;

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "mocogan_hip.h"
+#include "mcg_common.h"
 
 namespace {
 
@@ -15,38 +16,7 @@ constexpr float LRELU_SLOPE = 0.2f;  // model/net.py:149-155,190-196
 
 int launch_status() { return hipGetLastError() == hipSuccess ? MCG_OK : MCG_ERR_LAUNCH; }
 
-// ------------------------------------------------------------------------------------------
-// Philox4x32-10 (Salmon et al., Random123) + Box-Muller.  counter = (idx_lo, idx_hi, stream_lo,
-// stream_hi), key = (seed_lo, seed_hi); one call yields the 4 normals of one float4.
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                              uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
-__device__ __forceinline__ f32x4 randn4(uint64_t idx4, uint64_t seed, uint64_t stream_id) {
-    uint32_t r[4];
-    philox4x32_10((uint32_t)idx4, (uint32_t)(idx4 >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32),
-                  (uint32_t)seed, (uint32_t)(seed >> 32), r);
-    const float S = 2.3283064365386963e-10f;   // 2^-32
-    float u1 = ((float)r[0] + 1.0f) * S, u2 = (float)r[1] * S;
-    float u3 = ((float)r[2] + 1.0f) * S, u4 = (float)r[3] * S;
-    u1 = fminf(u1, 1.0f); u3 = fminf(u3, 1.0f);
-    float ra = sqrtf(-2.0f * logf(u1)), rb = sqrtf(-2.0f * logf(u3));
-    float s1, c1, s2, c2;
-    sincospif(2.0f * u2, &s1, &c1);
-    sincospif(2.0f * u4, &s2, &c2);
-    f32x4 o = {ra * c1, ra * s1, rb * c2, rb * s2};
-    return o;
-}
+using mcg::randn4;
 
 __device__ __forceinline__ float act_fwd(float v, int act) {
     if (act == MCG_ACT_RELU) return fmaxf(v, 0.f);
@@ -131,13 +101,15 @@ PartPlan plan_partial(long long M, int C) {
 // sums its slice in double, slices are combined through LDS in a fixed order (deterministic).
 constexpr int FIN_CH = 8, FIN_SL = 32;
 
-__device__ __forceinline__ bool reduce_partials(int nblocks, int C, const float* __restrict__ part, int& c, double& s, double& ss) {
+__device__ __forceinline__ bool reduce_partials(int nblocks, int C, const float* __restrict__ part, int& c, double& s, double& ss,
+                                                long long stride = 0) {
+    if (stride == 0) stride = 2LL * C;                        // col_partial_kernel's own layout; fused conv epilogues pass theirs
     __shared__ double red[2][FIN_SL][FIN_CH];
     const int cl = threadIdx.x % FIN_CH, sl = threadIdx.x / FIN_CH;
     c = blockIdx.x * FIN_CH + cl;
     double a = 0, b2 = 0;
     if (c < C)
-        for (int b = sl; b < nblocks; b += FIN_SL) { a += part[(long long)b * 2 * C + c]; b2 += part[(long long)b * 2 * C + C + c]; }
+        for (int b = sl; b < nblocks; b += FIN_SL) { a += part[(long long)b * stride + c]; b2 += part[(long long)b * stride + C + c]; }
     red[0][sl][cl] = a; red[1][sl][cl] = b2;
     __syncthreads();
     if (sl != 0 || c >= C) return false;
@@ -148,9 +120,9 @@ __device__ __forceinline__ bool reduce_partials(int nblocks, int C, const float*
 
 __global__ __launch_bounds__(FIN_CH * FIN_SL) void bn_stats_finalize_kernel(int nblocks, int C, double inv_m, double adjust, const float* __restrict__ part,
                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                         float* __restrict__ stats, float* avg_mean, float* avg_var, float eps, float decay) {
+                                         float* __restrict__ stats, float* avg_mean, float* avg_var, float eps, float decay, long long stride) {
     int c; double s, ss;
-    if (!reduce_partials(nblocks, C, part, c, s, ss)) return;
+    if (!reduce_partials(nblocks, C, part, c, s, ss, stride)) return;
     double mean = s * inv_m;
     double var = ss * inv_m - mean * mean;
     if (var < 0) var = 0;
@@ -170,9 +142,9 @@ __global__ __launch_bounds__(FIN_CH * FIN_SL) void bn_stats_finalize_kernel(int 
 // coef[0..C) = gamma*inv_std, [C..2C) = ggamma/M, [2C..3C) = gbeta/M ; dgamma/dbeta accumulated
 __global__ __launch_bounds__(FIN_CH * FIN_SL) void bn_bwd_finalize_kernel(int nblocks, int C, double inv_m, const float* __restrict__ part,
                                        const float* __restrict__ stats, const float* __restrict__ gamma,
-                                       float* __restrict__ coef, float* dgamma, float* dbeta) {
+                                       float* __restrict__ coef, float* dgamma, float* dbeta, long long stride) {
     int c; double gb, gg;
-    if (!reduce_partials(nblocks, C, part, c, gb, gg)) return;
+    if (!reduce_partials(nblocks, C, part, c, gb, gg, stride)) return;
     coef[c] = gamma[c] * stats[C + c];
     coef[C + c] = (float)(gg * inv_m);
     coef[2 * C + c] = (float)(gb * inv_m);
@@ -223,9 +195,9 @@ __global__ void bn_bwd_from_sums_kernel(int C, double inv_m_total, const double*
     if (dbeta) dbeta[c] += (float)local_sums[c];
 }
 
-__global__ __launch_bounds__(FIN_CH * FIN_SL) void colsum_finalize_kernel(int nblocks, int C, const float* __restrict__ part, float* db) {
+__global__ __launch_bounds__(FIN_CH * FIN_SL) void colsum_finalize_kernel(int nblocks, int C, const float* __restrict__ part, float* db, long long stride) {
     int c; double s, unused;
-    if (!reduce_partials(nblocks, C, part, c, s, unused)) return;
+    if (!reduce_partials(nblocks, C, part, c, s, unused, stride)) return;
     db[c] += (float)s;
 }
 
@@ -670,6 +642,18 @@ __global__ __launch_bounds__(NT) void randn_kernel(long long n, float sigma, uin
     }
 }
 
+// element (m, c) = normal (m & 3) of Philox counter (m >> 2) * C + c: the order in which the fused first-layer epilogue of
+// conv_gemm.hip draws its noise (a lane of the MFMA accumulator holds four consecutive rows of one channel)
+__global__ __launch_bounds__(NT) void randn_rowquad_kernel(long long quads, int C, float sigma, uint64_t seed, uint64_t stream_id, float* __restrict__ out) {
+    const long long n = quads * C;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n; i += (long long)gridDim.x * NT) {
+        const long long mq = i / C; const int c = (int)(i - mq * C);
+        f32x4 z = randn4((uint64_t)i, seed, stream_id);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[(mq * 4 + k) * C + c] = sigma * z[k];
+    }
+}
+
 bool bad_c(int C) { return C <= 0 || (C & 3); }
 // the column-reduction kernels give each thread one channel quad and stride the rows by NT / (C/4):
 // C must be 4 * 2^k, k <= 8 (every width the reference can produce from a power-of-two n_filters)
@@ -694,7 +678,17 @@ extern "C" int mcg_bn_stats(int64_t M, int C, const float* y, const float* gamma
     hipLaunchKernelGGL(col_partial_kernel<0>, dim3(pl.blocks), dim3(NT), 0, s, (long long)M, C, pl.rows_per_block, y, nullptr, nullptr, 0, part);
     double adjust = (double)M / (M - 1.0 > 1.0 ? M - 1.0 : 1.0);
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, pl.blocks, C, 1.0 / (double)M, adjust,
-                       part, gamma, beta, stats, avg_mean, avg_var, eps, decay);
+                       part, gamma, beta, stats, avg_mean, avg_var, eps, decay, 0LL);
+    return launch_status();
+}
+
+extern "C" int mcg_bn_stats_from_partials(int64_t M, int C, const float* part, int n_slots, int slot_stride, const float* gamma, const float* beta,
+                                          float* stats, float* avg_mean, float* avg_var, float eps, float decay, void* stream) {
+    if (!part || !gamma || !beta || !stats || M <= 0 || C <= 0 || n_slots <= 0 || slot_stride < 2 * C) return MCG_ERR_BAD_ARG;
+    if ((avg_mean == nullptr) != (avg_var == nullptr)) return MCG_ERR_BAD_ARG;
+    double adjust = (double)M / (M - 1.0 > 1.0 ? M - 1.0 : 1.0);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, (hipStream_t)stream, n_slots, C, 1.0 / (double)M,
+                       adjust, part, gamma, beta, stats, avg_mean, avg_var, eps, decay, (long long)slot_stride);
     return launch_status();
 }
 
@@ -724,9 +718,29 @@ extern "C" int mcg_bn_act_bwd(int64_t M, int C, const float* g_out, const float*
         coef = part + (long long)MAX_PART * 2 * C;
         hipLaunchKernelGGL(col_partial_kernel<1>, dim3(pl.blocks), dim3(NT), 0, s, (long long)M, C, pl.rows_per_block, g_out, y, stats, act, part);
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, pl.blocks, C, 1.0 / (double)M, part, stats, gamma,
-                           coef, dgamma, dbeta);
+                           coef, dgamma, dbeta, 0LL);
     }
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(NT), 0, s, n4, C, g_out, y, stats, coef, act, gx);
+    return launch_status();
+}
+
+extern "C" int mcg_bn_act_bwd_from_partials(int64_t M, int C, const float* g_out, const float* y, const float* stats, const float* gamma, int act,
+                                            const float* part, int n_slots, int slot_stride, float* gx, float* dgamma, float* dbeta,
+                                            void* workspace, void* stream) {
+    if (!g_out || !y || !gx || !stats || !gamma || !part || !workspace || M <= 0 || bad_c(C) || n_slots <= 0 || slot_stride < 2 * C) return MCG_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    float* coef = (float*)workspace + (long long)MAX_PART * 2 * C;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, n_slots, C, 1.0 / (double)M, part, stats, gamma,
+                       coef, dgamma, dbeta, (long long)slot_stride);
+    long long n4 = (long long)M * (C >> 2);
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(NT), 0, s, n4, C, g_out, y, stats, coef, act, gx);
+    return launch_status();
+}
+
+extern "C" int mcg_colsum_from_partials(int C, const float* part, int n_slots, int slot_stride, float* db, void* stream) {
+    if (!part || !db || C <= 0 || n_slots <= 0 || slot_stride < 2 * C) return MCG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, (hipStream_t)stream, n_slots, C, part, db,
+                       (long long)slot_stride);
     return launch_status();
 }
 
@@ -783,7 +797,7 @@ extern "C" int mcg_colsum_acc(int64_t M, int C, const float* g, float* db, void*
     PartPlan pl = plan_partial(M, C);
     float* part = (float*)workspace;
     hipLaunchKernelGGL(col_partial_kernel<2>, dim3(pl.blocks), dim3(NT), 0, s, (long long)M, C, pl.rows_per_block, g, nullptr, nullptr, 0, part);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, pl.blocks, C, part, db);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, pl.blocks, C, part, db, 0LL);
     return launch_status();
 }
 
@@ -883,6 +897,12 @@ extern "C" int mcg_adam_wd(int64_t n, float* p, const float* g, float* m, float*
     // hyper-parameters arrive as doubles so that (1 - beta) is rounded to fp32 once, like Chainer's python-float arithmetic
     hipLaunchKernelGGL(adam_wd_kernel, dim3(ew_grid(n)), dim3(NT), 0, (hipStream_t)stream, (long long)n, p, g, m, v, (float)lr_t,
                        (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)wd, (float)grad_scale);
+    return launch_status();
+}
+
+extern "C" int mcg_randn_rowquad(int64_t M, int C, float sigma, uint64_t seed, uint64_t stream_id, float* out, void* stream) {
+    if (!out || M <= 0 || (M & 3) || C <= 0) return MCG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(randn_rowquad_kernel, dim3(ew_grid((M / 4) * C)), dim3(NT), 0, (hipStream_t)stream, (long long)(M / 4), C, sigma, seed, stream_id, out);
     return launch_status();
 }
 

@@ -31,8 +31,20 @@ class ConvGeom(C.Structure):
                 ("x_stride0", C.c_int64), ("x_stride1", C.c_int64)]
 
 
+SUMS_NONE, SUMS_STATS, SUMS_BN_BWD, SUMS_COL = 0, 1, 2, 3
+
+
+class ConvEpilogue(C.Structure):
+    """mcg_conv_epilogue: what the conv's epilogue fuses (include/mocogan_hip.h)."""
+    _fields_ = [("sums", C.c_int32), ("groups", C.c_int32), ("part", C.c_void_p), ("bn_y", C.c_void_p),
+                ("bn_stats", C.c_void_p * 2), ("bn_act", C.c_int32), ("act", C.c_int32), ("addend", C.c_void_p * 2),
+                ("sigma", C.c_float), ("seed", C.c_uint64), ("stream_id", C.c_uint64 * 2),
+                ("mask_out", C.c_void_p), ("mask_in", C.c_void_p), ("n_slots", C.c_int32), ("slot_stride", C.c_int32)]
+
+
 _P, _I, _I64, _U64, _F, _D = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double
 _GP = C.POINTER(ConvGeom)
+_EP = C.POINTER(ConvEpilogue)
 
 # name -> (restype, argtypes); mirrors include/mocogan_hip.h one to one
 SIGNATURES = {
@@ -40,6 +52,13 @@ SIGNATURES = {
     "mcg_conv_fprop": (_I, [_GP, _P, _P, _P, _P, _P]),
     "mcg_conv_dgrad": (_I, [_GP, _P, _P, _P, _P, _I, _I, _P]),
     "mcg_conv_wgrad": (_I, [_GP, _P, _P, _P, _P]),
+    "mcg_conv_fprop_ex": (_I, [_GP, _P, _P, _P, _P, _EP, _P]),
+    "mcg_conv_dgrad_ex": (_I, [_GP, _P, _P, _P, _P, _EP, _P]),
+    "mcg_conv_epilogue_part_bytes": (_I64, [_GP, _I, _I]),
+    "mcg_bn_stats_from_partials": (_I, [_I64, _I, _P, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P]),
+    "mcg_bn_act_bwd_from_partials": (_I, [_I64, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "mcg_colsum_from_partials": (_I, [_I, _P, _I, _I, _P, _P]),
+    "mcg_randn_rowquad": (_I, [_I64, _I, _F, _U64, _U64, _P, _P]),
     "mcg_fc_fprop": (_I, [_I, _I, _I, _P, _P, _P, _P, _P]),
     "mcg_fc_dgrad": (_I, [_I, _I, _I, _P, _P, _P, _I, _P, _P]),
     "mcg_fc_wgrad": (_I, [_I, _I, _I, _P, _P, _P, _P, _P]),
@@ -324,16 +343,75 @@ def _wgrad(g, x, y, dw):
     _check(load().mcg_conv_wgrad(C.byref(g), _p(x), _p(_dense(y)), _p(_dense(dw)), _stream()), "mcg_conv_wgrad")
 
 
-def conv_fprop(g, x, w, bias, y):
+# ---- fused epilogues (mcg_conv_epilogue) ---------------------------------------------------------
+def _vp(t, dtype=torch.float32):
+    """raw device address (0 for None) for the pointer fields of ConvEpilogue"""
+    p = _p(t, dtype)
+    return None if p is None else p.value
+
+
+def epilogue(sums=SUMS_NONE, groups=1, part=None, bn_y=None, bn_stats=(None, None), bn_act=ACT_NONE, act=ACT_NONE,
+             addend=(None, None), sigma=0.0, seed=0, stream_id=(0, 0), mask_out=None, mask_in=None):
+    """Builds a ConvEpilogue; the tensors must stay alive until the launch has been queued (they are the caller's)."""
+    ep = ConvEpilogue()
+    ep.sums, ep.groups, ep.part, ep.bn_y = sums, groups, _vp(part), _vp(_dense(bn_y))
+    ep.bn_stats[0], ep.bn_stats[1] = _vp(bn_stats[0]), _vp(bn_stats[1] if len(bn_stats) > 1 else None)
+    ep.bn_act, ep.act = bn_act, act
+    ep.addend[0], ep.addend[1] = _vp(_dense(addend[0])), _vp(_dense(addend[1] if len(addend) > 1 else None))
+    ep.sigma, ep.seed = float(sigma), int(seed)
+    ep.stream_id[0], ep.stream_id[1] = int(stream_id[0]), int(stream_id[1] if len(stream_id) > 1 else 0)
+    ep.mask_out, ep.mask_in = _vp(_dense(mask_out), torch.int32), _vp(_dense(mask_in), torch.int32)
+    return ep
+
+
+def epilogue_part_floats(g, kind, groups):
+    """floats the per-tile partial sums of a fused epilogue can need for geometry g ('fprop' | 'dgrad')"""
+    return int(load().mcg_conv_epilogue_part_bytes(C.byref(g), 0 if kind == "fprop" else 1, groups)) // 4
+
+
+def _no_split(g):
+    """the tile code without its split-K part: partial tiles cannot carry an epilogue"""
+    if g.tile < 1000:
+        return g
+    gg = ConvGeom.from_buffer_copy(g)
+    gg.tile = g.tile % 1000
+    return gg
+
+
+def _fprop_ex(g, x, w, bias, y, ep):
+    g = _no_split(_with_override(g))
+    _check(load().mcg_conv_fprop_ex(C.byref(g), _p(x), _p(_dense(w)), _p(bias), _p(_dense(y)), C.byref(ep), _stream()), "mcg_conv_fprop_ex")
+
+
+def _dgrad_ex(g, y, w, bias, x, ep):
+    g = _no_split(_with_override(g))
+    _check(load().mcg_conv_dgrad_ex(C.byref(g), _p(_dense(y)), _p(_dense(w)), _p(bias), _p(_dense(x)), C.byref(ep), _stream()),
+           "mcg_conv_dgrad_ex")
+
+
+def conv_fprop(g, x, w, bias, y, ep=None, must_fuse=False):
+    """ep: a ConvEpilogue to fuse into the launch.  Returns True when it was fused; False when the tile tuned for this
+    geometry splits K (partial tiles cannot carry an epilogue) and must_fuse is off: then the PLAIN convolution ran and
+    the caller does the epilogue's work with the stand-alone passes.  must_fuse drops the split instead."""
     if _autotune and not g.tile:
         g = _tuned("fprop", g, (), 'y', lambda gg, out: _fprop(gg, x, w, bias, out))   # x, w are only read
+    if ep is not None and (must_fuse or _with_override(g).tile < 1000):
+        _launch("fprop", _fprop_ex, g, x, w, bias, y, ep)
+        return True
     _launch("fprop", _fprop, g, x, w, bias, y)
+    return False
 
 
-def conv_dgrad(g, y, w, bias, x, act=ACT_NONE, accumulate=False):
+def conv_dgrad(g, y, w, bias, x, act=ACT_NONE, accumulate=False, ep=None, must_fuse=False):
+    """ep / return value as in conv_fprop (ep needs act == ACT_NONE, no accumulate, dense x)."""
     if _autotune and not g.tile:
         g = _tuned("dgrad", g, (act, int(accumulate)), 'x', lambda gg, out: _dgrad(gg, y, w, bias, out, act, accumulate))
+    if ep is not None and (must_fuse or _with_override(g).tile < 1000):
+        assert act == ACT_NONE and not accumulate
+        _launch("dgrad", _dgrad_ex, g, y, w, bias, x, ep)
+        return True
     _launch("dgrad", _dgrad, g, y, w, bias, x, act, accumulate)
+    return False
 
 
 def conv_wgrad(g, x, y, dw):
@@ -394,6 +472,27 @@ def bn_act_bwd(M, Cn, g_out, y, stats, gamma, act, gx, dgamma, dbeta, ws, sync=N
     _check(load().mcg_bn_act_bwd_from_sums(M, M * sync.world, Cn, _p(g_out), _p(y), _p(stats), _p(gamma), act, _p(local, torch.float64),
                                            _p(glob, torch.float64), _p(_dense(gx)), _p(dgamma), _p(dbeta), _p(ws), _stream()),
            "mcg_bn_act_bwd_from_sums")
+
+
+def bn_stats_from_partials(M, Cn, part, n_slots, slot_stride, gamma, beta, stats, avg_mean, avg_var, eps=2e-5, decay=0.9):
+    """part: the (group's) partial sums a fused conv epilogue wrote (SUMS_STATS)."""
+    _check(load().mcg_bn_stats_from_partials(M, Cn, _p(part), n_slots, slot_stride, _p(gamma), _p(beta), _p(stats), _p(avg_mean),
+                                             _p(avg_var), eps, decay, _stream()), "mcg_bn_stats_from_partials")
+
+
+def bn_act_bwd_from_partials(M, Cn, g_out, y, stats, gamma, act, part, n_slots, slot_stride, gx, dgamma, dbeta, ws):
+    _check(load().mcg_bn_act_bwd_from_partials(M, Cn, _p(_dense(g_out)), _p(_dense(y)), _p(stats), _p(gamma), act, _p(part), n_slots,
+                                               slot_stride, _p(_dense(gx)), _p(dgamma), _p(dbeta), _p(ws), _stream()),
+           "mcg_bn_act_bwd_from_partials")
+
+
+def colsum_from_partials(Cn, part, n_slots, slot_stride, db):
+    _check(load().mcg_colsum_from_partials(Cn, _p(part), n_slots, slot_stride, _p(db), _stream()), "mcg_colsum_from_partials")
+
+
+def randn_rowquad(out, Cn, sigma, seed, stream_id):
+    """out [M][Cn] in the element order of the fused first-layer epilogue"""
+    _check(load().mcg_randn_rowquad(out.numel() // Cn, Cn, sigma, seed, stream_id, _p(_dense(out)), _stream()), "mcg_randn_rowquad")
 
 
 def colsum_acc(M, Cn, g, db, ws):

@@ -16,8 +16,19 @@ import torch
 from . import hiplib as hl
 from . import layout as lay
 
+import os
+
 NOISE_SIGMA_Z = 0.33          # make_hidden: np.random.normal(0, 0.33), model/net.py:55-56
 IMG = 64                      # output size hard-coded in the reference, model/net.py:115
+
+# What runs in the convolutions' epilogues instead of in passes of its own (same arithmetic either way; the
+# stand-alone passes remain the fallback for split-K tiles and synchronised BatchNorm).  MCG_FUSE="" switches all
+# of it off, MCG_FUSE="stats,dc1" a subset (A/B timing, tests of both paths):
+#   stats: BatchNorm statistics (sum, sum of squares per channel) from the producing fprop / deconvolution
+#   dc1  : D's first layer: leaky_relu + add_noise (+ sign bits for backward) in dc1's epilogue, the leaky_relu mask and
+#          dc1's bias gradient in the epilogue of dc2's input-gradient GEMM
+#   bwd  : the per-channel sums of BatchNorm's backward pass from the GEMM that produces the incoming gradient
+FUSE = set(filter(None, os.environ.get('MCG_FUSE', 'stats,dc1,bwd').split(',')))
 
 
 class Config:
@@ -119,6 +130,13 @@ class _Net:
         self.fp = FlatParams(specs, self.device)
         self.t = 0                                             # Adam step counter of this net's optimizer
         self.ws = torch.empty(hl.bn_workspace_floats(1024), dtype=torch.float32, device=self.device)
+        self._part = None                                      # per-tile partial sums of fused conv epilogues (grown on demand)
+
+    def _part_buf(self, geom, kind, groups):
+        n = hl.epilogue_part_floats(geom, kind, groups)
+        if self._part is None or self._part.numel() < n:
+            self._part = torch.empty(n, dtype=torch.float32, device=self.device)
+        return self._part
 
     # ---- reference-layout import / export (also the .npz checkpoint format, train.py:139-144) ----
     def load_reference_params(self, params):
@@ -169,6 +187,7 @@ class _Net:
             setattr(self.fp, b, getattr(self.fp, b).to(device))
         self.running = {k: v.to(device) for k, v in self.running.items()}
         self.ws = self.ws.to(device)
+        self._part = None
         self.device = device
         return self
 
@@ -288,7 +307,9 @@ class DisNet(_Net):
                 return dict(sigma=self.noise_sigma, seed=grp['rng'][0], stream_id=grp['rng'][1] + l - 1)
             return dict()
 
-        saved = {'n': n, 'G': G, 'a': {}, 'y': {}, 'stats': {}}
+        fuse_stats = train and 'stats' in FUSE and self.sync_bn is None
+        fuse_dc1 = 'dc1' in FUSE
+        saved = {'n': n, 'G': G, 'a': {}, 'y': {}, 'stats': {}, 'mask1': None}
         t, h = self._extents(1)
         a = torch.empty((N, t, h, h, self.cp0), device=dev)
         for gi, grp in enumerate(groups):
@@ -297,10 +318,35 @@ class DisNet(_Net):
         for l in (1, 2, 3, 4):
             g = self._geom(l, N)
             co = self.chans[l]
-            y = torch.empty((N, g.To, g.Ho, g.Wo, co), device=dev)
-            hl.conv_fprop(g, a, self.fp.param('dc%d/W' % l), self.fp.param('dc%d/b' % l), y)
-            saved['y'][l] = y
+            w, b = self.fp.param('dc%d/W' % l), self.fp.param('dc%d/b' % l)
             m = n * g.To * g.Ho * g.Wo                       # rows of ONE group
+            if l == 1 and fuse_dc1:
+                # dc1 has no BatchNorm: leaky_relu + add_noise run in its epilogue (model/net.py:148-149,189-190); what
+                # backward needs of the pre-activation -- its sign -- is kept as one bit per element
+                a = torch.empty((N, g.To, g.Ho, g.Wo, co), device=dev)
+                mask = torch.empty((G * m, (co + 31) // 32), dtype=torch.int32, device=dev)
+                na = [noise_args(grp, 2) for grp in groups]
+                kw = {}
+                if na[0]:
+                    assert all(('addend' in x) == ('addend' in na[0]) for x in na)
+                    if 'addend' in na[0]:
+                        kw = dict(addend=[x['addend'] for x in na])
+                    else:
+                        assert all(x['seed'] == na[0]['seed'] for x in na)
+                        kw = dict(sigma=na[0]['sigma'], seed=na[0]['seed'], stream_id=[x['stream_id'] for x in na])
+                hl.conv_fprop(g, saved['a'][1], w, b, a, ep=hl.epilogue(act=hl.ACT_LRELU, groups=G, mask_out=mask, **kw), must_fuse=True)
+                saved['y'][1], saved['mask1'], saved['a'][2] = None, mask, a
+                continue
+            y = torch.empty((N, g.To, g.Ho, g.Wo, co), device=dev)
+            ep = None
+            if l >= 2 and fuse_stats:
+                part = self._part_buf(g, 'fprop', G)
+                ep = hl.epilogue(sums=hl.SUMS_STATS, groups=G, part=part)
+                if not hl.conv_fprop(g, a, w, b, y, ep=ep):
+                    ep = None                                    # split-K tile: the stand-alone statistics pass below
+            else:
+                hl.conv_fprop(g, a, w, b, y)
+            saved['y'][l] = y
             a = torch.empty_like(y)
             if l >= 2:
                 saved['stats'][l] = []
@@ -311,9 +357,14 @@ class DisNet(_Net):
                     name = 'bn%d' % l
                     if train:
                         stats = torch.empty(4 * co, device=dev)
-                        hl.bn_stats(m, co, yg, self.fp.param(name + '/gamma'), self.fp.param(name + '/beta'), stats,
-                                    self.running[name + '/avg_mean'] if update_stats else None,
-                                    self.running[name + '/avg_var'] if update_stats else None, self.ws, sync=self.sync_bn)
+                        rm = self.running[name + '/avg_mean'] if update_stats else None
+                        rv = self.running[name + '/avg_var'] if update_stats else None
+                        if ep is not None:
+                            hl.bn_stats_from_partials(m, co, part[gi * 2 * co:], ep.n_slots, ep.slot_stride, self.fp.param(name + '/gamma'),
+                                                      self.fp.param(name + '/beta'), stats, rm, rv)
+                        else:
+                            hl.bn_stats(m, co, yg, self.fp.param(name + '/gamma'), self.fp.param(name + '/beta'), stats, rm, rv,
+                                        self.ws, sync=self.sync_bn)
                         if update_stats:
                             self.bn_count[name] += 1
                         saved['stats'][l].append(stats)
@@ -333,8 +384,13 @@ class DisNet(_Net):
         """The saved state of group gi alone (views, no copies)."""
         n = saved['n']
         sl = slice(gi * n, (gi + 1) * n)
-        return {'n': n, 'G': 1, 'a': {l: v[sl] for l, v in saved['a'].items()}, 'y': {l: v[sl] for l, v in saved['y'].items()},
-                'stats': {l: [v[gi]] for l, v in saved['stats'].items()}}
+        mask = saved.get('mask1')
+        if mask is not None:
+            rows = mask.shape[0] // saved['G']
+            mask = mask[gi * rows:(gi + 1) * rows]
+        return {'n': n, 'G': 1, 'a': {l: v[sl] for l, v in saved['a'].items()},
+                'y': {l: (None if v is None else v[sl]) for l, v in saved['y'].items()},
+                'stats': {l: [v[gi]] for l, v in saved['stats'].items()}, 'mask1': mask}
 
     def _test_scale_shift(self, name):
         """fixed_batch_normalization (test mode, reference util.py:92): scale/shift from running stats."""
@@ -367,30 +423,59 @@ class DisNet(_Net):
             hl.fc_wgrad(N, k, co5, a5.view(N, k), g_logits, fp.grad('dc5/W').view(co5, k), fp.grad('dc5/b'))
         g = torch.empty_like(a5)
         hl.fc_dgrad(N, k, co5, g_logits, fp.param('dc5/W').view(co5, k), None, 0, g.view(N, k))
+        fuse_bwd = 'bwd' in FUSE and self.sync_bn is None
+        mask1 = saved.get('mask1')
+        pending = None            # (epilogue, partial sums) the GEMM that produced g left for the layer processed next
         for l in (4, 3, 2, 1):
             geom = self._geom(l, N)
             co = self.chans[l]
             y = saved['y'][l]
             m = n * geom.To * geom.Ho * geom.Wo                  # rows of ONE group
-            for gi in range(G):
-                gg, yg = g[gi * n:(gi + 1) * n], y[gi * n:(gi + 1) * n]
-                if l >= 2:
-                    name = 'bn%d' % l
-                    hl.bn_act_bwd(m, co, gg, yg, saved['stats'][l][gi], fp.param(name + '/gamma'), hl.ACT_LRELU, gg,
-                                  fp.grad(name + '/gamma') if param_grads else None,
-                                  fp.grad(name + '/beta') if param_grads else None, self.ws, sync=self.sync_bn)
-                else:
+            if l >= 2:
+                name = 'bn%d' % l
+                for gi in range(G):
+                    gg, yg = g[gi * n:(gi + 1) * n], y[gi * n:(gi + 1) * n]
+                    dg = fp.grad(name + '/gamma') if param_grads else None
+                    db = fp.grad(name + '/beta') if param_grads else None
+                    if pending is not None:
+                        ep, part = pending
+                        hl.bn_act_bwd_from_partials(m, co, gg, yg, saved['stats'][l][gi], fp.param(name + '/gamma'), hl.ACT_LRELU,
+                                                    part[gi * 2 * co:], ep.n_slots, ep.slot_stride, gg, dg, db, self.ws)
+                    else:
+                        hl.bn_act_bwd(m, co, gg, yg, saved['stats'][l][gi], fp.param(name + '/gamma'), hl.ACT_LRELU, gg, dg, db, self.ws,
+                                      sync=self.sync_bn)
+            elif mask1 is None:
+                for gi in range(G):
+                    gg, yg = g[gi * n:(gi + 1) * n], y[gi * n:(gi + 1) * n]
                     hl.bn_act_bwd(m, co, gg, yg, None, None, hl.ACT_LRELU, gg, None, None, self.ws)
+            # (l == 1 with a stored mask: dc2's input-gradient GEMM applied leaky_relu's backward in its epilogue)
             if param_grads:
                 if l == 1:
-                    hl.colsum_acc(m * G, co, g, fp.grad('dc1/b'), self.ws)
+                    if pending is not None:
+                        hl.colsum_from_partials(co, pending[1], pending[0].n_slots, pending[0].slot_stride, fp.grad('dc1/b'))
+                    else:
+                        hl.colsum_acc(m * G, co, g, fp.grad('dc1/b'), self.ws)
                 # dc2..dc4 feed BatchNorm: sum_m gx == 0 exactly (see _Net.BIAS_NOTE), nothing to add
                 self._wgrad(geom, saved['a'][l], g, fp.grad('dc%d/W' % l))
                 if l == 4 and on_late_bucket is not None:
                     self._after_wgrads(on_late_bucket)
+            pending = None
             if l > 1:
                 ga = torch.empty_like(saved['a'][l])
-                hl.conv_dgrad(geom, g, fp.param('dc%d/W' % l), None, ga)
+                w = fp.param('dc%d/W' % l)
+                if l == 2 and mask1 is not None:
+                    part = self._part_buf(geom, 'dgrad', 1) if param_grads else None
+                    ep = hl.epilogue(mask_in=mask1, sums=hl.SUMS_COL if param_grads else hl.SUMS_NONE, groups=1, part=part)
+                    hl.conv_dgrad(geom, g, w, None, ga, ep=ep, must_fuse=True)
+                    pending = (ep, part) if param_grads else None
+                elif l > 2 and fuse_bwd:
+                    part = self._part_buf(geom, 'dgrad', G)
+                    ep = hl.epilogue(sums=hl.SUMS_BN_BWD, groups=G, part=part, bn_y=saved['y'][l - 1], bn_stats=saved['stats'][l - 1],
+                                     bn_act=hl.ACT_LRELU)
+                    if hl.conv_dgrad(geom, g, w, None, ga, ep=ep):
+                        pending = (ep, part)
+                else:
+                    hl.conv_dgrad(geom, g, w, None, ga)
                 g = ga
             elif gx is not None:
                 hl.conv_dgrad(gx_geom if gx_geom is not None else geom, g, fp.param('dc1/W'), None, gx,
@@ -531,15 +616,22 @@ class GenNet(_Net):
         y = torch.empty((frames, 4, 4, c1), device=dev)
         hl.fc_dgrad(frames, k1, self.n_hidden, z, fp.param('dc1/W').view(self.n_hidden, k1), fp.param('dc1/b'), c1,
                     y.view(frames, k1))
+        fuse_stats = train and 'stats' in FUSE and self.sync_bn is None
+        pending = None               # (epilogue, partial sums) of the deconvolution that produced y
         for l in (1, 2, 3, 4):
             co = self.chans[l]
             m = y.numel() // co
             name = 'bn%d' % l
             if train:
                 stats = torch.empty(4 * co, device=dev)
-                hl.bn_stats(m, co, y, fp.param(name + '/gamma'), fp.param(name + '/beta'), stats,
-                            self.running[name + '/avg_mean'] if update_stats else None,
-                            self.running[name + '/avg_var'] if update_stats else None, self.ws, sync=self.sync_bn)
+                rm = self.running[name + '/avg_mean'] if update_stats else None
+                rv = self.running[name + '/avg_var'] if update_stats else None
+                if pending is not None:
+                    ep, part = pending
+                    hl.bn_stats_from_partials(m, co, part, ep.n_slots, ep.slot_stride, fp.param(name + '/gamma'), fp.param(name + '/beta'),
+                                              stats, rm, rv)
+                else:
+                    hl.bn_stats(m, co, y, fp.param(name + '/gamma'), fp.param(name + '/beta'), stats, rm, rv, self.ws, sync=self.sync_bn)
                 if update_stats:
                     self.bn_count[name] += 1
                 saved['stats'][l] = stats
@@ -553,9 +645,18 @@ class GenNet(_Net):
             hl.bn_act_fwd(m, co, y, ss, hl.ACT_RELU, a)
             saved['a'][l + 1] = a
             h = 4 << l
+            pending = None
             if l < 4:
                 y = torch.empty((frames, h, h, self.chans[l + 1]), device=dev)
-                hl.conv_dgrad(self._geom(l + 1, frames), a, fp.param('dc%d/W' % (l + 1)), fp.param('dc%d/b' % (l + 1)), y)
+                geom = self._geom(l + 1, frames)
+                w, b = fp.param('dc%d/W' % (l + 1)), fp.param('dc%d/b' % (l + 1))
+                if fuse_stats:
+                    part = self._part_buf(geom, 'dgrad', 1)
+                    ep = hl.epilogue(sums=hl.SUMS_STATS, groups=1, part=part)
+                    if hl.conv_dgrad(geom, a, w, b, y, ep=ep):
+                        pending = (ep, part)
+                else:
+                    hl.conv_dgrad(geom, a, w, b, y)
         x = torch.empty((n, T, IMG, IMG, self.cp_out), device=dev)
         hl.conv_dgrad(self._geom(5, frames, clip_order_n=n), saved['a'][5], fp.param('dc5/W'), fp.param('dc5/b'), x,
                       act=hl.ACT_TANH)
@@ -579,26 +680,46 @@ class GenNet(_Net):
         hl.set_tag('G')
         g = torch.empty((frames, IMG, IMG, self.cp_out), device=dev)
         hl.tanh_bwd_to_frames(n, T, IMG * IMG * self.cp_out, gx_clip, saved['x'], g)
+        fuse_bwd = 'bwd' in FUSE and self.sync_bn is None
+        pending = None               # (epilogue, partial sums) the GEMM that produced g left for BatchNorm's backward
         for l in (5, 4, 3, 2):
             geom = self._geom(l, frames)
             ci = lay.pad4(self.chans[l])
             m = g.numel() // ci
             if l < 5:
                 name = 'bn%d' % l
-                hl.bn_act_bwd(m, ci, g, saved['y'][l], saved['stats'][l], fp.param(name + '/gamma'), hl.ACT_RELU, g,
-                              fp.grad(name + '/gamma'), fp.grad(name + '/beta'), self.ws, sync=self.sync_bn)
+                if pending is not None:
+                    ep, part = pending
+                    hl.bn_act_bwd_from_partials(m, ci, g, saved['y'][l], saved['stats'][l], fp.param(name + '/gamma'), hl.ACT_RELU, part,
+                                                ep.n_slots, ep.slot_stride, g, fp.grad(name + '/gamma'), fp.grad(name + '/beta'), self.ws)
+                else:
+                    hl.bn_act_bwd(m, ci, g, saved['y'][l], saved['stats'][l], fp.param(name + '/gamma'), hl.ACT_RELU, g,
+                                  fp.grad(name + '/gamma'), fp.grad(name + '/beta'), self.ws, sync=self.sync_bn)
             if l == 5:
                 hl.colsum_acc(m, ci, g, fp.grad('dc5/b'), self.ws)         # dc1..dc4 feed BatchNorm: exact zero
             self._wgrad(geom, g, saved['a'][l], fp.grad('dc%d/W' % l))
             if l == 2 and on_late_bucket is not None:
                 self._after_wgrads(on_late_bucket)
             ga = torch.empty_like(saved['a'][l])
-            hl.conv_fprop(geom, g, fp.param('dc%d/W' % l), None, ga)
+            pending = None
+            if fuse_bwd:             # ga is the gradient w.r.t. relu(bn_{l-1}(y_{l-1})): the sums of that BatchNorm's backward
+                part = self._part_buf(geom, 'fprop', 1)
+                ep = hl.epilogue(sums=hl.SUMS_BN_BWD, groups=1, part=part, bn_y=saved['y'][l - 1], bn_stats=[saved['stats'][l - 1]],
+                                 bn_act=hl.ACT_RELU)
+                if hl.conv_fprop(geom, g, fp.param('dc%d/W' % l), None, ga, ep=ep):
+                    pending = (ep, part)
+            else:
+                hl.conv_fprop(geom, g, fp.param('dc%d/W' % l), None, ga)
             g = ga
         c1 = self.chans[1]
         k1 = 16 * c1
-        hl.bn_act_bwd(frames * 16, c1, g, saved['y'][1], saved['stats'][1], fp.param('bn1/gamma'), hl.ACT_RELU, g,
-                      fp.grad('bn1/gamma'), fp.grad('bn1/beta'), self.ws, sync=self.sync_bn)
+        if pending is not None:
+            ep, part = pending
+            hl.bn_act_bwd_from_partials(frames * 16, c1, g, saved['y'][1], saved['stats'][1], fp.param('bn1/gamma'), hl.ACT_RELU, part,
+                                        ep.n_slots, ep.slot_stride, g, fp.grad('bn1/gamma'), fp.grad('bn1/beta'), self.ws)
+        else:
+            hl.bn_act_bwd(frames * 16, c1, g, saved['y'][1], saved['stats'][1], fp.param('bn1/gamma'), hl.ACT_RELU, g,
+                          fp.grad('bn1/gamma'), fp.grad('bn1/beta'), self.ws, sync=self.sync_bn)
         hl.fc_wgrad(frames, k1, self.n_hidden, g.view(frames, k1), saved['z'], fp.grad('dc1/W').view(self.n_hidden, k1))
         gz = torch.empty_like(saved['z'])
         hl.fc_fprop(frames, k1, self.n_hidden, g.view(frames, k1), fp.param('dc1/W').view(self.n_hidden, k1), None, gz)

@@ -46,3 +46,12 @@ def randn(n, sigma, seed, stream_id):
     out = np.stack([ra * np.cos(2 * np.pi * u2), ra * np.sin(2 * np.pi * u2),
                     rb * np.cos(2 * np.pi * u4), rb * np.sin(2 * np.pi * u4)], axis=1).reshape(-1)
     return sigma * out[:n]
+
+
+def randn_rowquad(M, C, sigma, seed, stream_id):
+    """[M][C] noise in the element order of the fused first-layer epilogue (mcg_conv_epilogue.sigma,
+    mcg_randn_rowquad): element (m, c) is normal m & 3 of counter (m >> 2) * C + c -- the same generator, one
+    counter per (row quad, channel) instead of per 4 consecutive channels.  M % 4 == 0."""
+    assert M % 4 == 0
+    z = randn(M * C, sigma, seed, stream_id).reshape(M // 4, C, 4)          # counter (mq, c) -> its 4 normals
+    return np.ascontiguousarray(z.transpose(0, 2, 1)).reshape(M, C)

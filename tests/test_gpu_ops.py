@@ -408,3 +408,178 @@ def test_adam_weight_decay(hl):
         lr_t = oupd.ADAM_ALPHA * np.sqrt(1 - oupd.ADAM_BETA2 ** t) / (1 - oupd.ADAM_BETA1 ** t)
         hl.adam_wd(pd, dev(g), md, vd, lr_t, oupd.ADAM_BETA1, oupd.ADAM_BETA2, oupd.ADAM_EPS, oupd.WEIGHT_DECAY)
         assert np.abs(pd.cpu().numpy() - p['x/W']).max() < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# fused conv epilogues (mcg_conv_fprop_ex / mcg_conv_dgrad_ex): each must reproduce what the stand-alone passes compute
+# ------------------------------------------------------------------------------------------------------------------
+EPI_CASES = [
+    # N, Ti, H, Ci, Co, kt   (N even: two statistics groups)
+    (4, 5, 16, 8, 64, 4),      # 3-D, one 64-column block
+    (2, 1, 16, 16, 160, 1),    # 2-D, Co not a multiple of the tile, rows not a multiple of the tile
+    (6, 4, 8, 64, 40, 4),      # a group boundary inside a block tile (6*1*4*4 = 96 rows, 48 per group)
+    (2, 6, 32, 4, 8, 4),       # first-layer shape of a narrow net: Ci = 4, fewer than 32 output channels
+]
+
+
+def _mask_bits(mask, C):
+    m = mask.cpu().numpy().astype(np.uint32)
+    cols = np.arange(C)
+    return ((m[:, cols >> 5] >> (cols & 31).astype(np.uint32)) & 1).astype(bool)
+
+
+@pytest.mark.parametrize("case", EPI_CASES)
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 101, 203])
+def test_fprop_epilogue_statistics_and_first_layer(hl, case, tile):
+    N, Ti, H, Ci, Co, kt = case
+    rng = np.random.RandomState(hash(case) % 2**31 + 7)
+    x = rng.uniform(-1, 1, (N, Ci, Ti, H, H))
+    W = rng.randn(Co, Ci, kt, 4, 4) * 0.1
+    b = rng.randn(Co) * 0.3
+    y_ref = F.conv3d_fwd(x, W, b, (1, 2, 2), (0, 1, 1))                   # (N,Co,To,Ho,Wo)
+    lay = L()
+    xd, wd, bd = lay.act_to_dev(dev(x)), lay.conv_w_to_dev(dev(W)), dev(b)
+    for groups in (1, 2):
+        g = hl.make_geom(N, Ti, H, H, xd.shape[-1], Co, kt)
+        g.tile = tile
+        M = N * g.To * g.Ho * g.Wo
+        mg = M // groups
+        # ---- (sum y, sum y^2) per channel and group -> BatchNorm statistics
+        part = torch.full((hl.epilogue_part_floats(g, "fprop", groups),), float('nan'), device="cuda")
+        ep = hl.epilogue(sums=hl.SUMS_STATS, groups=groups, part=part)
+        yd = torch.empty((N, g.To, g.Ho, g.Wo, Co), device="cuda")
+        assert hl.conv_fprop(g, xd, wd, bd, yd, ep=ep)
+        assert rel_l2(lay.act_from_dev(yd, Co), y_ref) < FWD_TOL
+        assert ep.n_slots > 0 and ep.slot_stride == groups * 2 * Co
+        gamma, beta = 1 + 0.1 * rng.randn(Co), 0.1 * rng.randn(Co)
+        for gi in range(groups):
+            yg = y_ref[gi * (N // groups):(gi + 1) * (N // groups)]
+            am, av = np.zeros(Co), np.ones(Co)
+            _, cache = F.bn_train_fwd(yg, gamma, beta, am, av)
+            stats = torch.empty(4 * Co, device="cuda")
+            amd, avd = dev(np.zeros(Co)), dev(np.ones(Co))
+            hl.bn_stats_from_partials(mg, Co, part[gi * 2 * Co:], ep.n_slots, ep.slot_stride, dev(gamma), dev(beta), stats, amd, avd)
+            assert rel_l2(stats[:Co], cache['mean']) < 1e-5 and rel_l2(stats[Co:2 * Co], cache['inv_std']) < 1e-5, (groups, gi)
+            assert rel_l2(amd, am) < 1e-5 and rel_l2(avd, av) < 1e-5
+        # ---- leaky_relu + injected noise + sign bits (D's first layer, parity mode)
+        noise = 0.2 * rng.randn(*y_ref.shape)
+        nd = lay.act_to_dev(dev(noise))
+        ng = N // groups
+        mask = torch.zeros((M, (Co + 31) // 32), dtype=torch.int32, device="cuda")
+        ep = hl.epilogue(act=hl.ACT_LRELU, groups=groups, addend=[nd[i * ng:(i + 1) * ng] for i in range(groups)], mask_out=mask)
+        ad = torch.empty_like(yd)
+        assert hl.conv_fprop(g, xd, wd, bd, ad, ep=ep, must_fuse=True)
+        assert rel_l2(lay.act_from_dev(ad, Co), F.leaky_relu_fwd(y_ref) + noise) < FWD_TOL
+        bits = _mask_bits(mask, Co)
+        pre = lay.act_to_dev(dev(y_ref)).reshape(M, Co).cpu().numpy()
+        sure = np.abs(pre) > 1e-5                                            # away from the kink the sign is unambiguous
+        assert np.array_equal(bits[sure], (pre >= 0)[sure])
+        # ---- the same with in-kernel Philox noise: one counter per (row quad, channel) of each group
+        ep = hl.epilogue(act=hl.ACT_LRELU, groups=groups, sigma=0.2, seed=77, stream_id=[5, 9][:groups], mask_out=mask)
+        hl.conv_fprop(g, xd, wd, bd, ad, ep=ep, must_fuse=True)
+        got = ad.reshape(M, Co).cpu().double().numpy() - np.where(pre >= 0, pre, 0.2 * pre)
+        for gi in range(groups):
+            z = philox.randn_rowquad(mg, Co, 0.2, 77, [5, 9][gi])
+            assert np.abs(got[gi * mg:(gi + 1) * mg] - z).max() < 2e-5, (groups, gi)
+            zd = torch.empty((mg, Co), device="cuda")
+            hl.randn_rowquad(zd, Co, 0.2, 77, [5, 9][gi])
+            assert np.abs(zd.cpu().double().numpy() - z).max() < 2e-6
+
+
+@pytest.mark.parametrize("case", EPI_CASES[:3])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 103, 201])
+def test_dgrad_epilogue_sums_and_mask(hl, case, tile):
+    """dgrad epilogues: (a) column statistics of the output (the generator's deconvolution feeding BatchNorm), (b) the
+    sums of BatchNorm's backward pass over the produced gradient, (c) leaky_relu's backward from stored sign bits plus
+    the bias gradient."""
+    N, Ti, H, Ci, Co, kt = case
+    rng = np.random.RandomState(hash(case) % 2**31 + 11)
+    gy = rng.randn(N, Co, Ti - kt + 1, H // 2, H // 2)
+    W = rng.randn(Co, Ci, kt, 4, 4) * 0.1
+    x0 = np.zeros((N, Ci, Ti, H, H))
+    gx_ref, _, _ = F.conv3d_bwd(x0, W, gy, (1, 2, 2), (0, 1, 1))             # (N,Ci,Ti,H,H)
+    lay = L()
+    gyd, wd = lay.act_to_dev(dev(gy)), lay.conv_w_to_dev(dev(W))
+    Cp = wd.shape[-1]
+    g = hl.make_geom(N, Ti, H, H, Cp, Co, kt)
+    g.tile = tile
+    M = N * Ti * H * H
+    ref_rows = lay.act_to_dev(dev(gx_ref)).reshape(M, Cp).cpu().double().numpy()
+    for groups in (1, 2):
+        mg = M // groups
+        # (a) statistics of the output, with a bias (deconvolution forward)
+        bias = rng.randn(Cp) * 0.2
+        part = torch.full((hl.epilogue_part_floats(g, "dgrad", groups),), float('nan'), device="cuda")
+        ep = hl.epilogue(sums=hl.SUMS_STATS, groups=groups, part=part)
+        xd = torch.empty((N, Ti, H, H, Cp), device="cuda")
+        assert hl.conv_dgrad(g, gyd, wd, dev(bias), xd, ep=ep)
+        out = ref_rows + bias
+        assert rel_l2(xd.reshape(M, Cp), out) < BWD_TOL
+        for gi in range(groups):
+            stats = torch.empty(4 * Cp, device="cuda")
+            hl.bn_stats_from_partials(mg, Cp, part[gi * 2 * Cp:], ep.n_slots, ep.slot_stride, dev(np.ones(Cp)), dev(np.zeros(Cp)), stats, None, None)
+            o = out[gi * mg:(gi + 1) * mg]
+            assert np.abs(stats[:Cp].cpu().numpy() - o.mean(0)).max() < 1e-5 * max(1.0, np.abs(o).max())
+            assert rel_l2(stats[Cp:2 * Cp], 1 / np.sqrt(o.var(0) + 2e-5)) < 1e-5
+        # (b) BatchNorm-backward sums against the stand-alone pass
+        ybn = rng.randn(M, Cp) * 1.3 + 0.2
+        ybnd = dev(ybn).reshape(N, Ti, H, H, Cp)
+        gam = 1 + 0.1 * rng.randn(Cp)
+        ws = torch.empty(hl.bn_workspace_floats(max(Cp, 64)), device="cuda")
+        st = []
+        for gi in range(groups):
+            s_ = torch.empty(4 * Cp, device="cuda")
+            hl.bn_stats(mg, Cp, ybnd.reshape(M, Cp)[gi * mg:(gi + 1) * mg], dev(gam), dev(0.1 * rng.randn(Cp)), s_, None, None, ws)
+            st.append(s_)
+        for act in (hl.ACT_LRELU, hl.ACT_RELU):
+            ep = hl.epilogue(sums=hl.SUMS_BN_BWD, groups=groups, part=part, bn_y=ybnd, bn_stats=st, bn_act=act)
+            assert hl.conv_dgrad(g, gyd, wd, None, xd, ep=ep)
+            assert rel_l2(xd.reshape(M, Cp), ref_rows) < BWD_TOL
+            for gi in range(groups):
+                sl = slice(gi * mg, (gi + 1) * mg)
+                gref, dg_ref, db_ref = torch.empty((mg, Cp), device="cuda"), torch.zeros(Cp, device="cuda"), torch.zeros(Cp, device="cuda")
+                hl.bn_act_bwd(mg, Cp, xd.reshape(M, Cp)[sl].contiguous(), ybnd.reshape(M, Cp)[sl].contiguous(), st[gi], dev(gam), act, gref,
+                              dg_ref, db_ref, ws)
+                got, dg, db = torch.empty((mg, Cp), device="cuda"), torch.zeros(Cp, device="cuda"), torch.zeros(Cp, device="cuda")
+                hl.bn_act_bwd_from_partials(mg, Cp, xd.reshape(M, Cp)[sl].contiguous(), ybnd.reshape(M, Cp)[sl].contiguous(), st[gi], dev(gam),
+                                            act, part[gi * 2 * Cp:], ep.n_slots, ep.slot_stride, got, dg, db, ws)
+                assert rel_l2(got, gref.cpu().double().numpy()) < 1e-5, (groups, gi, act)
+                assert rel_l2(dg, dg_ref.cpu().double().numpy()) < 1e-5 and rel_l2(db, db_ref.cpu().double().numpy()) < 1e-5
+    # (c) leaky_relu backward from sign bits + column sums (dc1's bias gradient)
+    sign = rng.rand(M, Cp) > 0.4
+    words = np.zeros((M, (Cp + 31) // 32), dtype=np.uint32)
+    for c in range(Cp):
+        words[:, c >> 5] |= (sign[:, c].astype(np.uint32) << np.uint32(c & 31))
+    maskd = torch.tensor(words.view(np.int32), device="cuda")
+    part = torch.full((hl.epilogue_part_floats(g, "dgrad", 1),), float('nan'), device="cuda")
+    ep = hl.epilogue(mask_in=maskd, sums=hl.SUMS_COL, groups=1, part=part)
+    xd = torch.empty((N, Ti, H, H, Cp), device="cuda")
+    assert hl.conv_dgrad(g, gyd, wd, None, xd, ep=ep, must_fuse=True)
+    want = ref_rows * np.where(sign, 1.0, 0.2)
+    assert rel_l2(xd.reshape(M, Cp), want) < BWD_TOL
+    db = torch.ones(Cp, device="cuda")
+    hl.colsum_from_partials(Cp, part, ep.n_slots, ep.slot_stride, db)
+    assert np.abs(db.cpu().double().numpy() - (1 + want.sum(0))).max() < 1e-4 * max(1.0, np.abs(want.sum(0)).max())
+
+
+def test_fused_epilogue_refuses_what_it_cannot_own(hl):
+    lay = L()
+    g = hl.make_geom(2, 4, 16, 16, 8, 64, 4)
+    g.tile = 1103                                                          # split-K: partial tiles
+    x = torch.zeros((2, 4, 16, 16, 8), device="cuda")
+    w = torch.zeros((64, 4, 4, 4, 8), device="cuda")
+    y = torch.zeros((2, 1, 8, 8, 64), device="cuda")
+    part = torch.zeros(hl.epilogue_part_floats(g, "fprop", 1), device="cuda")
+    ep = hl.epilogue(sums=hl.SUMS_STATS, groups=1, part=part)
+    assert hl.conv_fprop(g, x, w, None, y, ep=ep) is False                 # declined: the plain launch ran
+    lib = hl.load()
+    import ctypes
+    assert lib.mcg_conv_fprop_ex(ctypes.byref(g), hl._p(x), hl._p(w), None, hl._p(y), ctypes.byref(ep), None) == -2
+    g.tile = 0
+    bad = hl.epilogue(sums=hl.SUMS_STATS, groups=1, part=None)             # sums without a partial buffer
+    with pytest.raises(hl.McgError):
+        hl.conv_fprop(g, x, w, None, y, ep=bad)
+    ep3 = hl.epilogue(sums=hl.SUMS_STATS, groups=2, part=part)
+    g3 = hl.make_geom(3, 4, 16, 16, 8, 64, 4)                              # odd batch cannot form two groups
+    with pytest.raises(hl.McgError):
+        hl.conv_fprop(g3, torch.zeros((3, 4, 16, 16, 8), device="cuda"), w, None, torch.zeros((3, 1, 8, 8, 64), device="cuda"), ep=ep3)
