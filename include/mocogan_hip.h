@@ -215,14 +215,16 @@ int mcg_bn_act_bwd_from_sums(int64_t M, int64_t M_total, int C, const float* g_o
  * epilogue (part / n_slots / slot_stride as returned in mcg_conv_epilogue; `part` already offset to the group):
  *   mcg_bn_stats_from_partials   == mcg_bn_stats' finalize      (M = rows of the group)
  *   mcg_bn_act_bwd_from_partials == mcg_bn_act_bwd without its reduction pass over g_out and y
- *   mcg_colsum_from_partials     == mcg_colsum_acc without its pass over g */
+ *   mcg_colsum_from_partials     == mcg_colsum_acc without its pass over g
+ * workspace: mcg_bn_workspace_bytes(M, C) (large slot counts are first folded into it, in a fixed order). */
 int mcg_bn_stats_from_partials(int64_t M, int C, const float* part, int n_slots, int slot_stride, const float* gamma,
                                const float* beta, float* stats, float* avg_mean, float* avg_var, float eps, float decay,
-                               void* stream);
+                               void* workspace, void* stream);
 int mcg_bn_act_bwd_from_partials(int64_t M, int C, const float* g_out, const float* y, const float* stats,
                                  const float* gamma, int act, const float* part, int n_slots, int slot_stride, float* gx,
                                  float* dgamma, float* dbeta, void* workspace, void* stream);
-int mcg_colsum_from_partials(int C, const float* part, int n_slots, int slot_stride, float* db, void* stream);
+int mcg_colsum_from_partials(int C, const float* part, int n_slots, int slot_stride, float* db, void* workspace,
+                             void* stream);
 
 /* db += column sums of g [M][C] (bias gradient of every conv/deconv). */
 int mcg_colsum_acc(int64_t M, int C, const float* g, float* db, void* workspace, void* stream);

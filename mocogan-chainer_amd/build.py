@@ -23,16 +23,31 @@ def _stale():
 
 
 def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -O3 -fPIC -shared -> lib/libmocogan_hip.so (in-tree)."""
+    """hipcc --offload-arch=gfx950 -O3 -fPIC -> lib/libmocogan_hip.so (in-tree).  The conv GEMM source is compiled as
+    three translation units (one per pass, -DMCG_TU=1..3) next to small_ops.hip, all four in parallel, then linked."""
     if not force and not _stale():
         return lib_path()
     os.makedirs(os.path.join(HERE, "lib"), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17",
-           "-I" + os.path.join(ROOT, "include")] + [os.path.join(HERE, s) for s in SOURCES] + ["-o", lib_path()]
+    extra = os.environ.get("MCG_HIPCC_FLAGS", "").split()        # e.g. -DMCG_STAMPS for the diagnostic builds of tools/
+    objdir = os.path.join(HERE, "lib", "obj")
+    os.makedirs(objdir, exist_ok=True)
+    common = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I" + os.path.join(ROOT, "include")] + extra
+    units = [("conv_gemm_tu%d.o" % tu, ["-DMCG_TU=%d" % tu, os.path.join(HERE, "csrc/conv_gemm.hip")]) for tu in (1, 2, 3)]
+    units.append(("small_ops.o", [os.path.join(HERE, "csrc/small_ops.hip")]))
+    procs = []
+    for obj, args in units:
+        cmd = common + args + ["-c", "-o", os.path.join(objdir, obj)]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [os.path.join(objdir, o) for o, _ in units] + ["-o", lib_path()]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+        print(" ".join(link))
+    subprocess.run(link, check=True)
     return lib_path()
 
 

@@ -1204,7 +1204,7 @@ std::once_flag g_c4_lds_once;      // dgrad_c4_kernel<4> needs the 64 KiB dynami
 
 }  // namespace
 
-#ifdef MCG_STAMPS
+#if defined(MCG_STAMPS) && (!defined(MCG_TU) || MCG_TU == 3)
 extern "C" void mcg_debug_stamps(unsigned long long* out, int reset) {
     hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 8);
     if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)); }
@@ -1254,6 +1254,9 @@ int make_epi(const mcg_conv_epilogue* ep, const Geom& g, int pass, Epi& e) {
     return MCG_OK;
 }
 
+// The three passes can be compiled as separate translation units (-DMCG_TU=1 fprop, 2 dgrad, 3 wgrad + the
+// fully-connected GEMMs) so that the build runs in parallel; without MCG_TU this file is the whole library part.
+#if !defined(MCG_TU) || MCG_TU == 1
 int conv_fprop_impl(const mcg_conv_geom* c, const float* x, const float* w, const float* bias, float* y,
                     mcg_conv_epilogue* ep, void* stream) {
     Geom g;
@@ -1278,12 +1281,14 @@ int conv_fprop_impl(const mcg_conv_geom* c, const float* x, const float* w, cons
     MCG_DISPATCH(launch_fprop, t, bk64, g.prec == MCG_PREC_BF16, g, x, w, bias, y, e, ep, s);
     return finish(st);
 }
+#endif
 
 int conv_dgrad_impl(const mcg_conv_geom* c, const float* y, const float* w, const float* bias, float* x, int act, int accumulate,
                     mcg_conv_epilogue* ep, void* stream);
 
 }  // namespace
 
+#if !defined(MCG_TU) || MCG_TU == 1
 extern "C" int mcg_conv_fprop(const mcg_conv_geom* c, const float* x, const float* w, const float* bias, float* y, void* stream) {
     return conv_fprop_impl(c, x, w, bias, y, nullptr, stream);
 }
@@ -1292,6 +1297,15 @@ extern "C" int mcg_conv_fprop_ex(const mcg_conv_geom* c, const float* x, const f
     if (ep) { ep->n_slots = 0; ep->slot_stride = 0; }
     return conv_fprop_impl(c, x, w, bias, y, ep, stream);
 }
+extern "C" int64_t mcg_conv_epilogue_part_bytes(const mcg_conv_geom* c, int pass, int groups) {
+    if (!c || groups < 1 || groups > 2) return 0;
+    const long long rows = pass == 0 ? (long long)c->N * c->To * c->Ho * c->Wo : (long long)c->N * c->Ti * c->Ho * c->Wo;
+    const long long slots = (pass == 0 ? 1 : 4) * ((rows + 63) / 64);          // the smallest block tile has 64 rows
+    return slots * groups * 2 * (pass == 0 ? c->Co : c->Ci) * (long long)sizeof(float);
+}
+#endif
+
+#if !defined(MCG_TU) || MCG_TU == 2
 extern "C" int mcg_conv_dgrad(const mcg_conv_geom* c, const float* y, const float* w, const float* bias, float* x, int act,
                               int accumulate, void* stream) {
     return conv_dgrad_impl(c, y, w, bias, x, act, accumulate, nullptr, stream);
@@ -1300,12 +1314,6 @@ extern "C" int mcg_conv_dgrad_ex(const mcg_conv_geom* c, const float* y, const f
                                  mcg_conv_epilogue* ep, void* stream) {
     if (ep) { ep->n_slots = 0; ep->slot_stride = 0; }
     return conv_dgrad_impl(c, y, w, bias, x, MCG_ACT_NONE, 0, ep, stream);
-}
-extern "C" int64_t mcg_conv_epilogue_part_bytes(const mcg_conv_geom* c, int pass, int groups) {
-    if (!c || groups < 1 || groups > 2) return 0;
-    const long long rows = pass == 0 ? (long long)c->N * c->To * c->Ho * c->Wo : (long long)c->N * c->Ti * c->Ho * c->Wo;
-    const long long slots = (pass == 0 ? 1 : 4) * ((rows + 63) / 64);          // the smallest block tile has 64 rows
-    return slots * groups * 2 * (pass == 0 ? c->Co : c->Ci) * (long long)sizeof(float);
 }
 
 namespace {
@@ -1356,7 +1364,9 @@ int conv_dgrad_impl(const mcg_conv_geom* c, const float* y, const float* w, cons
 }
 
 }  // namespace
+#endif
 
+#if !defined(MCG_TU) || MCG_TU == 3
 extern "C" int mcg_conv_wgrad(const mcg_conv_geom* c, const float* x, const float* y, float* dw, void* stream) {
     Geom g;
     int st = make_geom(c, g);
@@ -1409,3 +1419,4 @@ extern "C" int mcg_detail_fc_wgrad_gemm(int M, int K, int N, const float* x, con
     hipLaunchKernelGGL((gemm_kernel<FcWgradP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, (hipStream_t)stream, p);
     return launch_status();
 }
+#endif

@@ -97,6 +97,30 @@ PartPlan plan_partial(long long M, int C) {
     return p;
 }
 
+// Conv epilogues leave one partial per block tile -- thousands for the big layers, far more than a finalize block (8
+// channels) can sum at memory latency.  fold_partials_kernel first folds runs of `per` consecutive slots into the
+// workspace with fully coalesced row reads (thread = one channel, NT / cw slots in flight per pass), in a fixed order.
+__global__ __launch_bounds__(NT) void fold_partials_kernel(int n_slots, long long stride, int C, int per, const float* __restrict__ part,
+                                                           float* __restrict__ out) {
+    __shared__ double red[2][NT];
+    const int cw = C < 64 ? C : 64;                         // channels per block (C = 4 * 2^k: cw divides NT)
+    const int c = blockIdx.x * cw + threadIdx.x % cw, rl = threadIdx.x / cw, RL = NT / cw;
+    const int s0 = blockIdx.y * per;
+    int s1 = s0 + per; if (s1 > n_slots) s1 = n_slots;
+    double a = 0, b = 0;
+    if (c < C)
+        for (int sl = s0 + rl; sl < s1; sl += RL) { a += part[(long long)sl * stride + c]; b += part[(long long)sl * stride + C + c]; }
+    red[0][threadIdx.x] = a; red[1][threadIdx.x] = b;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        for (int k = 1; k < RL; ++k) { a += red[0][k * cw + threadIdx.x]; b += red[1][k * cw + threadIdx.x]; }
+        out[(long long)blockIdx.y * 2 * C + c] = (float)a;
+        out[(long long)blockIdx.y * 2 * C + C + c] = (float)b;
+    }
+}
+
+constexpr int FOLD_ABOVE = 96;       // slot counts up to this go straight to the finalize kernels
+
 // Finalize kernels: block = FIN_CH channels x FIN_SL slices of the partial-block list; each thread
 // sums its slice in double, slices are combined through LDS in a fixed order (deterministic).
 constexpr int FIN_CH = 8, FIN_SL = 32;
@@ -655,6 +679,19 @@ __global__ __launch_bounds__(NT) void randn_rowquad_kernel(long long quads, int 
 }
 
 bool bad_c(int C) { return C <= 0 || (C & 3); }
+
+// many conv-epilogue slots -> at most MAX_PART folded partials in `ws` (col_partial_kernel's own layout); returns the
+// partial list the finalize kernel should read
+struct Folded { const float* part; int n; long long stride; };
+Folded fold_slots(const float* part, int n_slots, int slot_stride, int C, float* ws, hipStream_t s) {
+    if (n_slots <= FOLD_ABOVE || !ws || (NT % (C < 64 ? C : 64)) != 0) return {part, n_slots, (long long)slot_stride};
+    int per = 32;
+    if ((n_slots + per - 1) / per > MAX_PART) per = (n_slots + MAX_PART - 1) / MAX_PART;
+    const int chunks = (n_slots + per - 1) / per;
+    const int cw = C < 64 ? C : 64;
+    hipLaunchKernelGGL(fold_partials_kernel, dim3((C + cw - 1) / cw, chunks), dim3(NT), 0, s, n_slots, (long long)slot_stride, C, per, part, ws);
+    return {ws, chunks, 2LL * C};
+}
 // the column-reduction kernels give each thread one channel quad and stride the rows by NT / (C/4):
 // C must be 4 * 2^k, k <= 8 (every width the reference can produce from a power-of-two n_filters)
 bool unsupported_c(int C) { return (C >> 2) > NT || (NT % (C >> 2)) != 0; }
@@ -683,12 +720,13 @@ extern "C" int mcg_bn_stats(int64_t M, int C, const float* y, const float* gamma
 }
 
 extern "C" int mcg_bn_stats_from_partials(int64_t M, int C, const float* part, int n_slots, int slot_stride, const float* gamma, const float* beta,
-                                          float* stats, float* avg_mean, float* avg_var, float eps, float decay, void* stream) {
-    if (!part || !gamma || !beta || !stats || M <= 0 || C <= 0 || n_slots <= 0 || slot_stride < 2 * C) return MCG_ERR_BAD_ARG;
+                                          float* stats, float* avg_mean, float* avg_var, float eps, float decay, void* workspace, void* stream) {
+    if (!part || !gamma || !beta || !stats || M <= 0 || bad_c(C) || n_slots <= 0 || slot_stride < 2 * C) return MCG_ERR_BAD_ARG;
     if ((avg_mean == nullptr) != (avg_var == nullptr)) return MCG_ERR_BAD_ARG;
     double adjust = (double)M / (M - 1.0 > 1.0 ? M - 1.0 : 1.0);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, (hipStream_t)stream, n_slots, C, 1.0 / (double)M,
-                       adjust, part, gamma, beta, stats, avg_mean, avg_var, eps, decay, (long long)slot_stride);
+    const Folded f = fold_slots(part, n_slots, slot_stride, C, (float*)workspace, (hipStream_t)stream);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, (hipStream_t)stream, f.n, C, 1.0 / (double)M,
+                       adjust, f.part, gamma, beta, stats, avg_mean, avg_var, eps, decay, f.stride);
     return launch_status();
 }
 
@@ -730,17 +768,18 @@ extern "C" int mcg_bn_act_bwd_from_partials(int64_t M, int C, const float* g_out
     if (!g_out || !y || !gx || !stats || !gamma || !part || !workspace || M <= 0 || bad_c(C) || n_slots <= 0 || slot_stride < 2 * C) return MCG_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     float* coef = (float*)workspace + (long long)MAX_PART * 2 * C;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, n_slots, C, 1.0 / (double)M, part, stats, gamma,
-                       coef, dgamma, dbeta, (long long)slot_stride);
+    const Folded f = fold_slots(part, n_slots, slot_stride, C, (float*)workspace, s);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, f.n, C, 1.0 / (double)M, f.part, stats, gamma,
+                       coef, dgamma, dbeta, f.stride);
     long long n4 = (long long)M * (C >> 2);
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(NT), 0, s, n4, C, g_out, y, stats, coef, act, gx);
     return launch_status();
 }
 
-extern "C" int mcg_colsum_from_partials(int C, const float* part, int n_slots, int slot_stride, float* db, void* stream) {
-    if (!part || !db || C <= 0 || n_slots <= 0 || slot_stride < 2 * C) return MCG_ERR_BAD_ARG;
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, (hipStream_t)stream, n_slots, C, part, db,
-                       (long long)slot_stride);
+extern "C" int mcg_colsum_from_partials(int C, const float* part, int n_slots, int slot_stride, float* db, void* workspace, void* stream) {
+    if (!part || !db || bad_c(C) || n_slots <= 0 || slot_stride < 2 * C) return MCG_ERR_BAD_ARG;
+    const Folded f = fold_slots(part, n_slots, slot_stride, C, (float*)workspace, (hipStream_t)stream);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, (hipStream_t)stream, f.n, C, f.part, db, f.stride);
     return launch_status();
 }
 

@@ -55,9 +55,9 @@ SIGNATURES = {
     "mcg_conv_fprop_ex": (_I, [_GP, _P, _P, _P, _P, _EP, _P]),
     "mcg_conv_dgrad_ex": (_I, [_GP, _P, _P, _P, _P, _EP, _P]),
     "mcg_conv_epilogue_part_bytes": (_I64, [_GP, _I, _I]),
-    "mcg_bn_stats_from_partials": (_I, [_I64, _I, _P, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P]),
+    "mcg_bn_stats_from_partials": (_I, [_I64, _I, _P, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P]),
     "mcg_bn_act_bwd_from_partials": (_I, [_I64, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P]),
-    "mcg_colsum_from_partials": (_I, [_I, _P, _I, _I, _P, _P]),
+    "mcg_colsum_from_partials": (_I, [_I, _P, _I, _I, _P, _P, _P]),
     "mcg_randn_rowquad": (_I, [_I64, _I, _F, _U64, _U64, _P, _P]),
     "mcg_fc_fprop": (_I, [_I, _I, _I, _P, _P, _P, _P, _P]),
     "mcg_fc_dgrad": (_I, [_I, _I, _I, _P, _P, _P, _I, _P, _P]),
@@ -474,10 +474,10 @@ def bn_act_bwd(M, Cn, g_out, y, stats, gamma, act, gx, dgamma, dbeta, ws, sync=N
            "mcg_bn_act_bwd_from_sums")
 
 
-def bn_stats_from_partials(M, Cn, part, n_slots, slot_stride, gamma, beta, stats, avg_mean, avg_var, eps=2e-5, decay=0.9):
+def bn_stats_from_partials(M, Cn, part, n_slots, slot_stride, gamma, beta, stats, avg_mean, avg_var, ws, eps=2e-5, decay=0.9):
     """part: the (group's) partial sums a fused conv epilogue wrote (SUMS_STATS)."""
     _check(load().mcg_bn_stats_from_partials(M, Cn, _p(part), n_slots, slot_stride, _p(gamma), _p(beta), _p(stats), _p(avg_mean),
-                                             _p(avg_var), eps, decay, _stream()), "mcg_bn_stats_from_partials")
+                                             _p(avg_var), eps, decay, _p(ws), _stream()), "mcg_bn_stats_from_partials")
 
 
 def bn_act_bwd_from_partials(M, Cn, g_out, y, stats, gamma, act, part, n_slots, slot_stride, gx, dgamma, dbeta, ws):
@@ -486,8 +486,8 @@ def bn_act_bwd_from_partials(M, Cn, g_out, y, stats, gamma, act, part, n_slots, 
            "mcg_bn_act_bwd_from_partials")
 
 
-def colsum_from_partials(Cn, part, n_slots, slot_stride, db):
-    _check(load().mcg_colsum_from_partials(Cn, _p(part), n_slots, slot_stride, _p(db), _stream()), "mcg_colsum_from_partials")
+def colsum_from_partials(Cn, part, n_slots, slot_stride, db, ws):
+    _check(load().mcg_colsum_from_partials(Cn, _p(part), n_slots, slot_stride, _p(db), _p(ws), _stream()), "mcg_colsum_from_partials")
 
 
 def randn_rowquad(out, Cn, sigma, seed, stream_id):

@@ -28,7 +28,9 @@ IMG = 64                      # output size hard-coded in the reference, model/n
 #   dc1  : D's first layer: leaky_relu + add_noise (+ sign bits for backward) in dc1's epilogue, the leaky_relu mask and
 #          dc1's bias gradient in the epilogue of dc2's input-gradient GEMM
 #   bwd  : the per-channel sums of BatchNorm's backward pass from the GEMM that produces the incoming gradient
-FUSE = set(filter(None, os.environ.get('MCG_FUSE', 'stats,dc1,bwd').split(',')))
+#          (off by default: measured on MI355X it costs the producing GEMMs more -- they read the saved BatchNorm input
+#          in their epilogue -- than the removed reduction pass took: +0.20 ms against -0.18 ms per iteration at batch 32)
+FUSE = set(filter(None, os.environ.get('MCG_FUSE', 'stats,dc1').split(',')))
 
 
 class Config:
@@ -361,7 +363,7 @@ class DisNet(_Net):
                         rv = self.running[name + '/avg_var'] if update_stats else None
                         if ep is not None:
                             hl.bn_stats_from_partials(m, co, part[gi * 2 * co:], ep.n_slots, ep.slot_stride, self.fp.param(name + '/gamma'),
-                                                      self.fp.param(name + '/beta'), stats, rm, rv)
+                                                      self.fp.param(name + '/beta'), stats, rm, rv, self.ws)
                         else:
                             hl.bn_stats(m, co, yg, self.fp.param(name + '/gamma'), self.fp.param(name + '/beta'), stats, rm, rv,
                                         self.ws, sync=self.sync_bn)
@@ -452,7 +454,7 @@ class DisNet(_Net):
             if param_grads:
                 if l == 1:
                     if pending is not None:
-                        hl.colsum_from_partials(co, pending[1], pending[0].n_slots, pending[0].slot_stride, fp.grad('dc1/b'))
+                        hl.colsum_from_partials(co, pending[1], pending[0].n_slots, pending[0].slot_stride, fp.grad('dc1/b'), self.ws)
                     else:
                         hl.colsum_acc(m * G, co, g, fp.grad('dc1/b'), self.ws)
                 # dc2..dc4 feed BatchNorm: sum_m gx == 0 exactly (see _Net.BIAS_NOTE), nothing to add
@@ -629,7 +631,7 @@ class GenNet(_Net):
                 if pending is not None:
                     ep, part = pending
                     hl.bn_stats_from_partials(m, co, part, ep.n_slots, ep.slot_stride, fp.param(name + '/gamma'), fp.param(name + '/beta'),
-                                              stats, rm, rv)
+                                              stats, rm, rv, self.ws)
                 else:
                     hl.bn_stats(m, co, y, fp.param(name + '/gamma'), fp.param(name + '/beta'), stats, rm, rv, self.ws, sync=self.sync_bn)
                 if update_stats:

@@ -452,13 +452,14 @@ def test_fprop_epilogue_statistics_and_first_layer(hl, case, tile):
         assert rel_l2(lay.act_from_dev(yd, Co), y_ref) < FWD_TOL
         assert ep.n_slots > 0 and ep.slot_stride == groups * 2 * Co
         gamma, beta = 1 + 0.1 * rng.randn(Co), 0.1 * rng.randn(Co)
+        ws = torch.empty(hl.bn_workspace_floats(max(Co, 64)), device="cuda")
         for gi in range(groups):
             yg = y_ref[gi * (N // groups):(gi + 1) * (N // groups)]
             am, av = np.zeros(Co), np.ones(Co)
             _, cache = F.bn_train_fwd(yg, gamma, beta, am, av)
             stats = torch.empty(4 * Co, device="cuda")
             amd, avd = dev(np.zeros(Co)), dev(np.ones(Co))
-            hl.bn_stats_from_partials(mg, Co, part[gi * 2 * Co:], ep.n_slots, ep.slot_stride, dev(gamma), dev(beta), stats, amd, avd)
+            hl.bn_stats_from_partials(mg, Co, part[gi * 2 * Co:], ep.n_slots, ep.slot_stride, dev(gamma), dev(beta), stats, amd, avd, ws)
             assert rel_l2(stats[:Co], cache['mean']) < 1e-5 and rel_l2(stats[Co:2 * Co], cache['inv_std']) < 1e-5, (groups, gi)
             assert rel_l2(amd, am) < 1e-5 and rel_l2(avd, av) < 1e-5
         # ---- leaky_relu + injected noise + sign bits (D's first layer, parity mode)
@@ -510,6 +511,7 @@ def test_dgrad_epilogue_sums_and_mask(hl, case, tile):
         # (a) statistics of the output, with a bias (deconvolution forward)
         bias = rng.randn(Cp) * 0.2
         part = torch.full((hl.epilogue_part_floats(g, "dgrad", groups),), float('nan'), device="cuda")
+        ws0 = torch.empty(hl.bn_workspace_floats(max(Cp, 64)), device="cuda")
         ep = hl.epilogue(sums=hl.SUMS_STATS, groups=groups, part=part)
         xd = torch.empty((N, Ti, H, H, Cp), device="cuda")
         assert hl.conv_dgrad(g, gyd, wd, dev(bias), xd, ep=ep)
@@ -517,7 +519,7 @@ def test_dgrad_epilogue_sums_and_mask(hl, case, tile):
         assert rel_l2(xd.reshape(M, Cp), out) < BWD_TOL
         for gi in range(groups):
             stats = torch.empty(4 * Cp, device="cuda")
-            hl.bn_stats_from_partials(mg, Cp, part[gi * 2 * Cp:], ep.n_slots, ep.slot_stride, dev(np.ones(Cp)), dev(np.zeros(Cp)), stats, None, None)
+            hl.bn_stats_from_partials(mg, Cp, part[gi * 2 * Cp:], ep.n_slots, ep.slot_stride, dev(np.ones(Cp)), dev(np.zeros(Cp)), stats, None, None, ws0)
             o = out[gi * mg:(gi + 1) * mg]
             assert np.abs(stats[:Cp].cpu().numpy() - o.mean(0)).max() < 1e-5 * max(1.0, np.abs(o).max())
             assert rel_l2(stats[Cp:2 * Cp], 1 / np.sqrt(o.var(0) + 2e-5)) < 1e-5
@@ -558,7 +560,7 @@ def test_dgrad_epilogue_sums_and_mask(hl, case, tile):
     want = ref_rows * np.where(sign, 1.0, 0.2)
     assert rel_l2(xd.reshape(M, Cp), want) < BWD_TOL
     db = torch.ones(Cp, device="cuda")
-    hl.colsum_from_partials(Cp, part, ep.n_slots, ep.slot_stride, db)
+    hl.colsum_from_partials(Cp, part, ep.n_slots, ep.slot_stride, db, torch.empty(hl.bn_workspace_floats(max(Cp, 64)), device="cuda"))
     assert np.abs(db.cpu().double().numpy() - (1 + want.sum(0))).max() < 1e-4 * max(1.0, np.abs(want.sum(0)).max())
 
 
