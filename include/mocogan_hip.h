@@ -67,6 +67,8 @@ typedef struct mcg_conv_geom {
     int32_t precision;         /* MCG_PREC_F32 or MCG_PREC_BF16 */
     int32_t tile;              /* GEMM block tile for this call: 0 = library heuristic; 1 = 128x128, 2 = 128x64,
                                 * 3 = 64x64, 4 = 256x64, 5 = 64x256 (the last two always with K-steps of 32);
+                                * 6 = the weight-stationary kernels of the Ci = 4, Co = 64 layers (refused elsewhere;
+                                * what tile 0 picks for those layers);
                                 * +100 / +200 also fixes the K-step depth to 32 / 64; +1000 / +2000
                                 * makes mcg_conv_fprop / mcg_conv_dgrad split the K range over 2 / 4 blocks per tile
                                 * (partial tiles are added atomically onto a cleared output; for long-K layers with
@@ -75,7 +77,9 @@ typedef struct mcg_conv_geom {
                                 * performance knob (the caller may time the candidates once per geometry and
                                 * keep the winner, as mocogan-chainer_amd/hiplib.py does); results are the same
                                 * up to fp32 summation order. */
-    int32_t reserved_;
+    int32_t ci_valid;          /* how many of the Ci channels of x carry data (0 = all): the 3-channel clip is stored with
+                                * Ci = 4, its padded channel and that channel's weights are zero, and the kernels written for
+                                * that layer skip the products with it (same result, 3/4 of the MFMAs) */
     int64_t x_stride0, x_stride1;
 } mcg_conv_geom;
 

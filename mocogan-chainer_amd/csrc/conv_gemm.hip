@@ -58,6 +58,7 @@ struct Geom {
     int prec;          // MCG_PREC_F32 / MCG_PREC_BF16
     int tile, bk;      // caller's choice (mcg_conv_geom.tile): tile 0 = library heuristic, 1/2/3; bk 0 = heuristic, 32/64
     int ksplit;        // fprop / dgrad: number of K splits (1, 2 or 4) from mcg_conv_geom.tile / 1000
+    int cv;            // channels of x that carry data (mcg_conv_geom.ci_valid; == Ci when unspecified)
 };
 
 // Fused epilogue of fprop / dgrad (mcg_conv_epilogue on the device side).  mode == 0: the plain store.
@@ -944,6 +945,129 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(P p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// fprop for Ci == 4, Co == 64 (D's first layer on the 3-channel clip padded to 4; the input gradient of the
+// generator's last layer): K = taps * 4 is only 64 (2-D) or 256 (3-D), so in the generic kernel a block tile lives
+// for 2..8 K-steps and prologue / epilogue dominate (measured 82 TFLOP/s), while every input pixel is fetched by the
+// 16 (x4 in time) output pixels that use it.  Here the WEIGHTS are stationary and the INPUT PATCH of the block's
+// output tile sits in LDS: a block owns 256 output pixels (R = 256 / Wo full rows) of one batch item and walks the
+// output frames; per frame step it adds ONE input frame slab to a ring of kt slabs (every input pixel crosses the
+// fabric about once) and runs K / 2 MFMAs per 32x32 accumulator straight out of LDS -- no global load, no address
+// arithmetic and no barrier inside the K loop (all operand addresses are lane base + immediate).
+//   LDS: w[co][K + 4] (b128 reads conflict-free: row stride 65 * 16 B) | patch[slot][row][parity][hidx][4 ch], where
+//   column wi + 1 = 2 * hidx + parity: the 32 lanes of an accumulator row read the taps kw = 2j + lh of 32 consecutive
+//   wo, i.e. 32 consecutive hidx of ONE parity plane -- consecutive 16-byte slots, conflict-free.
+//   MFMA k pairing: lane half lh takes tap kw = 2j + lh (A: its pixel's 4 channels, B: w[co][a][kh][2j + lh][0..3]).
+// 512 threads = 8 waves (4 x 2), wave tile 64 pixels x 32 channels.
+// ------------------------------------------------------------------------------------------
+struct C4FpropP {
+    Geom g; Epi e;
+    const float* x; const float* w; const float* bias; float* y;
+    int M;                       // N * To * Ho * Wo
+    __device__ int out_cols() const { return g.Co; }
+    __device__ float* out_ptr() const { return y; }
+    __device__ int slot(int bx, int) const { return bx; }
+    __device__ RowInfo row_info(int m) const {
+        RowInfo r;
+        r.ok = m < M; r.base = (long long)m * g.Co; r.pix = m;
+        r.grp = (e.groups == 2 && (long long)m >= e.grp_rows) ? 1 : 0;
+        return r;
+    }
+};
+
+template <int KT, int WO, int EPI, int CV>     // CV: channels of x that carry data (3: the padded RGB clip -> 3 of 4 MFMAs)
+__global__ __launch_bounds__(512) void fprop_c4_kernel(C4FpropP p) {
+    constexpr int BM = 256, BN = 64, K = KT * 64;
+    constexpr int R = BM / WO, PR = 2 * R + 2, WI = 2 * WO;
+    constexpr int PLANE = (WO + 2) * 16, ROW = 2 * PLANE, SLAB = PR * ROW;             // bytes
+    constexpr int WROW = (K + 4) * 4;                                                      // bytes
+    constexpr int ENT = 2 * (WO + 2), NLD = (PR * ENT + 511) / 512;                        // patch entries per row; loads per thread
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* wl = smem;                                  // 64 * WROW
+    unsigned char* pl = smem + 64 * WROW;                      // KT * SLAB
+    float* red = reinterpret_cast<float*>(pl + KT * SLAB);     // epilogue exchange (4 * 64 * 4 floats)
+    const Geom& g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int hblocks = g.Ho / R;
+    const int n = blockIdx.x / hblocks, ho0 = (blockIdx.x - n * hblocks) * R;
+    const __amdgpu_buffer_rsrc_t xr = make_srd(p.x, g.x_bytes);
+
+    // ---- weights -> LDS (once)
+    for (int i = tid; i < 64 * K / 4; i += 512) {
+        const int co = i / (K / 4), k4 = i - co * (K / 4);
+        *reinterpret_cast<f32x4*>(wl + co * WROW + k4 * 16) = *reinterpret_cast<const f32x4*>(p.w + (long long)co * K + k4 * 4);
+    }
+    // ---- patch slabs: entry e of patch row pr is input pixel (hi, wi) = (2 ho0 - 1 + pr, e - 1); outside the image: zeros
+    u32 goff[NLD]; int loff[NLD];
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int idx = tid + 512 * j, pr = idx / ENT, en = idx - pr * ENT;
+        const int hi = 2 * ho0 - 1 + pr, wi = en - 1;
+        const bool ok = pr < PR && (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)WI;
+        goff[j] = ok ? (u32)(((long long)n * g.Ti * g.Hi + hi) * WI + wi) * 16u : OOB;   // + t * Hi * WI * 16 per frame
+        loff[j] = pr < PR ? pr * ROW + (en & 1) * PLANE + (en >> 1) * 16 : -1;
+    }
+    const u32 fbytes = (u32)g.Hi * WI * 16u;
+    f32x4 stage[NLD];
+    auto slab_load = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) stage[j] = bload(xr, goff[j] == OOB ? OOB : goff[j] + (u32)t * fbytes);
+    };
+    auto slab_store = [&](int slot) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j)
+            if (loff[j] >= 0) *reinterpret_cast<f32x4*>(pl + slot * SLAB + loff[j]) = stage[j];
+    };
+#pragma unroll
+    for (int t = 0; t < KT; ++t) { slab_load(t); slab_store(t); }
+    __syncthreads();
+
+    // ---- lane bases of the MFMA operand reads
+    const int wm = wave >> 1, wn = wave & 1;
+    int abase[2];
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx) {
+        const int r = wm * 64 + sidx * 32 + li, hol = r / WO, wo = r - hol * WO;
+        abase[sidx] = (2 * hol) * ROW + lh * PLANE + wo * 16;
+    }
+    const int bbase = (wn * 32 + li) * WROW + lh * 16;
+
+    for (int to = 0; to < g.To; ++to) {
+        const bool more = KT > 1 && to + KT < g.Ti;
+        if (more) slab_load(to + KT);                          // the frame the NEXT step adds; lands under this step's MFMAs
+        f32x16 acc[2][1];
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[sidx][0][r] = 0.f;
+#pragma unroll
+        for (int a = 0; a < KT; ++a) {
+            const int sb = ((to + a) % KT) * SLAB;             // ring position of frame to + a
+#pragma unroll
+            for (int kh = 0; kh < 4; ++kh)
+#pragma unroll
+                for (int j2 = 0; j2 < 2; ++j2) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(wl + bbase + ((a * 4 + kh) * 4 + 2 * j2) * 16);
+#pragma unroll
+                    for (int sidx = 0; sidx < 2; ++sidx) {
+                        const f32x4 av = *reinterpret_cast<const f32x4*>(pl + sb + abase[sidx] + kh * ROW + j2 * 16);
+#pragma unroll
+                        for (int c = 0; c < CV; ++c)               // channels >= CV are zero in x AND in w: their products are skipped
+                            acc[sidx][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c], bv[c], acc[sidx][0], 0, 0, 0);
+                    }
+                }
+        }
+        const int m0 = ((n * g.To + to) * g.Ho + ho0) * WO;
+        fused_epilogue<C4FpropP, BM, BN, 4, 2, 2, 1, EPI>(p, acc, m0, 0, m0 / BM, 0, tid, red);
+        if (KT > 1) {
+            __syncthreads();                                   // every wave is done with the slab of frame `to`
+            if (more) slab_store(to % KT);
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // dgrad for Ci == 4, Co == 64 (the 3-channel clip padded to 4: D's first layer backward and G's
 // last layer forward).  N = 4 output columns would waste 15/16 of a 64-wide MFMA tile, so this case
 // runs on the VALU with fully coalesced loads.  A wave works on a run of 16 consecutive HALF-resolution
@@ -1055,6 +1179,33 @@ __global__ __launch_bounds__(NTHREADS) void dgrad_c4_kernel(Geom g, const float*
     }
 }
 
+// the weight-stationary Ci = 4 forward kernel: geometry it covers (and the only epilogues it carries)
+bool c4_fprop_ok(const Geom& g, const Epi& e) {
+    const long long frame = (long long)g.Ti * g.Hi * g.Wi * g.Ci;
+    return g.Ci == 4 && g.Co == 64 && (g.Wo == 32 || g.Wo == 16) && g.Ho % (256 / g.Wo) == 0 && !g.perm_n && g.xs0 == frame &&
+           g.prec == MCG_PREC_F32 && (e.mode == 0 || e.mode == EPI_ACT);
+}
+
+template <int KT, int WO>
+int launch_fprop_c4(const Geom& g, const float* x, const float* w, const float* bias, float* y, const Epi& e, hipStream_t s) {
+    C4FpropP p;
+    p.g = g; p.e = e; p.x = x; p.w = w; p.bias = bias; p.y = y;
+    p.M = g.N * g.To * g.Ho * g.Wo;
+    constexpr int R = 256 / WO, K = KT * 64;
+    const size_t lds = (size_t)64 * (K + 4) * 4 + (size_t)KT * (2 * R + 2) * 2 * (WO + 2) * 16 + 4096;
+    static std::once_flag once[4];                        // > 64 KiB of dynamic LDS needs the opt-in once per kernel and process
+    hipError_t attr = hipSuccess;
+    const dim3 grid(g.N * (g.Ho / R));
+#define MCG_C4_LAUNCH(EPI_, CV_, SLOT_) do { \
+        std::call_once(once[SLOT_], [&] { attr = hipFuncSetAttribute((const void*)fprop_c4_kernel<KT, WO, EPI_, CV_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }); \
+        if (attr != hipSuccess) return MCG_ERR_LAUNCH; \
+        hipLaunchKernelGGL((fprop_c4_kernel<KT, WO, EPI_, CV_>), grid, dim3(512), lds, s, p); } while (0)
+    if (e.mode & EPI_ACT) { if (g.cv <= 3) MCG_C4_LAUNCH(3, 3, 0); else MCG_C4_LAUNCH(3, 4, 1); }
+    else { if (g.cv <= 3) MCG_C4_LAUNCH(1, 3, 2); else MCG_C4_LAUNCH(1, 4, 3); }
+#undef MCG_C4_LAUNCH
+    return MCG_OK;
+}
+
 // which fused-epilogue instantiation serves this combination of options (make_epi rejects the others)
 int epi_class(int mode) { return (mode & EPI_ACT) ? 3 : (mode & EPI_BNBWD) ? 2 : 1; }
 
@@ -1072,8 +1223,10 @@ int make_geom(const mcg_conv_geom* c, Geom& g) {
     g.perm_n = c->x_perm_n; g.xs0 = c->x_stride0; g.xs1 = c->x_stride1;
     g.taps = c->kt * 16;
     g.prec = c->precision;
+    if (c->ci_valid < 0 || c->ci_valid > c->Ci) return MCG_ERR_BAD_ARG;
+    g.cv = c->ci_valid ? c->ci_valid : c->Ci;
     if (g.prec != MCG_PREC_F32 && g.prec != MCG_PREC_BF16) return MCG_ERR_BAD_ARG;
-    if (c->tile < 0 || c->tile % 100 > 5 || (c->tile / 100) % 10 > 2 || c->tile / 1000 > 2) return MCG_ERR_BAD_ARG;
+    if (c->tile < 0 || c->tile % 100 > 6 || (c->tile / 100) % 10 > 2 || c->tile / 1000 > 2) return MCG_ERR_BAD_ARG;
     g.tile = c->tile % 100; g.bk = ((c->tile / 100) % 10) * 32; g.ksplit = 1 << (c->tile / 1000);
     g.lgHo = ilog2_exact(g.Ho); g.lgWo = ilog2_exact(g.Wo);
     g.lgCi = ilog2_exact(g.Ci); g.lgCo = ilog2_exact(g.Co);
@@ -1272,6 +1425,13 @@ int conv_fprop_impl(const mcg_conv_geom* c, const float* x, const float* w, cons
     // that the last partial round of blocks does not matter, else 128x64, else 64x64 to fill 256 CUs.
     int t = g.tile;
     const int bk = g.bk;
+    if ((t == 0 || t == 6) && c4_fprop_ok(g, e)) {                 // the 3-channel clip padded to 4: weight-stationary kernel
+        if (ep) { ep->n_slots = 0; ep->slot_stride = e.slot_stride; }
+        if (g.kt == 4) st = g.Wo == 32 ? launch_fprop_c4<4, 32>(g, x, w, bias, y, e, s) : launch_fprop_c4<4, 16>(g, x, w, bias, y, e, s);
+        else st = g.Wo == 32 ? launch_fprop_c4<1, 32>(g, x, w, bias, y, e, s) : launch_fprop_c4<1, 16>(g, x, w, bias, y, e, s);
+        return finish(st);
+    }
+    if (t == 6) return MCG_ERR_UNSUPPORTED;
     const long long mt = (M + 127) / 128;
     if (!t) t = g.Co <= 64 ? 2 : (mt * ((g.Co + 127) / 128) >= 1024 ? 1 : (mt * ((g.Co + 63) / 64) >= 512 ? 2 : 3));
     // 64-deep K-steps halve the per-step overhead (barriers, LDS refill, address math) and pay off when the

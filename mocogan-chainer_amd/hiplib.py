@@ -27,7 +27,7 @@ class ConvGeom(C.Structure):
     _fields_ = [("N", C.c_int32), ("Ti", C.c_int32), ("Hi", C.c_int32), ("Wi", C.c_int32), ("Ci", C.c_int32),
                 ("To", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32), ("Co", C.c_int32),
                 ("kt", C.c_int32), ("x_perm_n", C.c_int32), ("precision", C.c_int32),
-                ("tile", C.c_int32), ("reserved_", C.c_int32),
+                ("tile", C.c_int32), ("ci_valid", C.c_int32),
                 ("x_stride0", C.c_int64), ("x_stride1", C.c_int64)]
 
 
@@ -156,10 +156,12 @@ PREC_F32, PREC_BF16 = 0, 1
 PRECISIONS = {"f32": PREC_F32, "fp32": PREC_F32, "bf16": PREC_BF16, PREC_F32: PREC_F32, PREC_BF16: PREC_BF16}
 
 
-def make_geom(N, Ti, Hi, Wi, Ci, Co, kt, x_stride0=None, x_perm_n=0, x_stride1=0, precision=PREC_F32):
-    """Geometry of one k4 s(1,2,2) p(0,1,1) layer; x side [N][Ti][Hi][Wi][Ci], y side dense."""
+def make_geom(N, Ti, Hi, Wi, Ci, Co, kt, x_stride0=None, x_perm_n=0, x_stride1=0, precision=PREC_F32, ci_valid=0):
+    """Geometry of one k4 s(1,2,2) p(0,1,1) layer; x side [N][Ti][Hi][Wi][Ci], y side dense.  ci_valid: channels of x
+    that carry data (0 = all Ci): 3 for the RGB clip stored with Ci = 4."""
     g = ConvGeom()
     g.precision = PRECISIONS[precision]
+    g.ci_valid = ci_valid
     g.N, g.Ti, g.Hi, g.Wi, g.Ci = N, Ti, Hi, Wi, Ci
     g.To, g.Ho, g.Wo, g.Co, g.kt = Ti - kt + 1, Hi // 2, Wi // 2, Co, kt
     g.x_perm_n = x_perm_n

@@ -275,7 +275,7 @@ class DisNet(_Net):
     def _geom(self, l, n, x_stride0=None):
         t, h = self._extents(l)
         return hl.make_geom(n, t, h, h, lay.pad4(self.chans[l - 1]), self.chans[l], self.kt, x_stride0=x_stride0,
-                            precision=self.precision)
+                            precision=self.precision, ci_valid=self.chans[l - 1])
 
     # ---- forward ---------------------------------------------------------------------------
     def forward(self, n, first_input, noise=None, rng=None, update_stats=True):
@@ -577,8 +577,8 @@ class GenNet(_Net):
         if clip_order_n:
             T = frames // clip_order_n
             return hl.make_geom(frames, 1, h, h, ci, self.chans[l - 1], 1, x_stride0=T * h * h * ci,
-                                x_perm_n=clip_order_n, x_stride1=h * h * ci, precision=self.precision)
-        return hl.make_geom(frames, 1, h, h, ci, self.chans[l - 1], 1, precision=self.precision)
+                                x_perm_n=clip_order_n, x_stride1=h * h * ci, precision=self.precision, ci_valid=self.chans[l])
+        return hl.make_geom(frames, 1, h, h, ci, self.chans[l - 1], 1, precision=self.precision, ci_valid=self.chans[l])
 
     # ---- latent draws (model/net.py:55-56,66,71,92,102) ------------------------------------------
     def draw(self, n, rng):

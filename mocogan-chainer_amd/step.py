@@ -250,9 +250,22 @@ class TrainStep:
         hl.loss_gen(n, cd, y_fake_i, y_fake_v, t_fake, with_ce, self.loss[2:3], gi, gv)
         gx = torch.empty_like(xf)
         s_fake_v, s_fake_i = dv.select_group(s_v, 1), di.select_group(s_i, 1)
-        dv.backward(s_fake_v, gv, False, gx=gx)                      # new D_V weights, old activations (Q5)
-        gi_geom = hl.make_geom(n, 1, H, W, cp, di.chans[1], 1, x_stride0=T * hw * cp, precision=di.precision)
-        di.backward(s_fake_i, gi, False, gx=gx[:, t], gx_geom=gi_geom, gx_accumulate=True)
+        if self.side is not None:
+            # the two discriminators' input gradients are independent until they meet in frame t of the clip gradient:
+            # D_I's (small kernels) runs on the side stream beside D_V's and lands in a buffer of its own
+            gxi = torch.empty((n, 1, H, W, cp), device=self.device)
+            self.side.wait_stream(main)                              # loss_gen's gradients
+            with torch.cuda.stream(self.side):
+                di.backward(s_fake_i, gi, False, gx=gxi)
+            for tns in (gi, gxi):
+                tns.record_stream(self.side)
+            dv.backward(s_fake_v, gv, False, gx=gx)                  # new D_V weights, old activations (Q5)
+            main.wait_stream(self.side)
+            gx[:, t].add_(gxi[:, 0])                                 # the same two addends as the accumulating launch below
+        else:
+            dv.backward(s_fake_v, gv, False, gx=gx)                  # new D_V weights, old activations (Q5)
+            gi_geom = hl.make_geom(n, 1, H, W, cp, di.chans[1], 1, x_stride0=T * hw * cp, precision=di.precision, ci_valid=di.chans[0])
+            di.backward(s_fake_i, gi, False, gx=gx[:, t], gx_geom=gi_geom, gx_accumulate=True)
         if cgan:
             gxg = torch.zeros_like(x_fake)
             gxg[..., :c_img] = gx[..., :c_img]                       # label planes carry no gradient to G

@@ -585,3 +585,58 @@ def test_fused_epilogue_refuses_what_it_cannot_own(hl):
     g3 = hl.make_geom(3, 4, 16, 16, 8, 64, 4)                              # odd batch cannot form two groups
     with pytest.raises(hl.McgError):
         hl.conv_fprop(g3, torch.zeros((3, 4, 16, 16, 8), device="cuda"), w, None, torch.zeros((3, 1, 8, 8, 64), device="cuda"), ep=ep3)
+
+
+C4_CASES = [
+    # N, Ti, H, kt     (Ci = 3 padded to 4, Co = 64: D's first layer / the generator's last layer read backwards)
+    (2, 6, 32, 4),       # Wo = 16: one block of 256 output pixels per batch item, three frame steps through the slab ring
+    (3, 1, 32, 1),       # 2-D
+    (2, 5, 64, 4),       # Wo = 32: four blocks per batch item
+    (2, 1, 64, 1),
+]
+
+
+@pytest.mark.parametrize("case", C4_CASES)
+def test_weight_stationary_first_layer_kernels(hl, case):
+    """tile code 6 (and the heuristic, tile 0) runs the weight-stationary Ci = 4 kernels; they must agree with the
+    oracle like the generic GEMM kernels (tile 2), with and without the fused first-layer epilogue."""
+    N, Ti, H, kt = case
+    Ci, Co = 3, 64
+    rng = np.random.RandomState(hash(case) % 2**31 + 3)
+    x = rng.uniform(-1, 1, (N, Ci, Ti, H, H))
+    W = rng.randn(Co, Ci, kt, 4, 4) * 0.1
+    b = rng.randn(Co) * 0.2
+    y_ref = F.conv3d_fwd(x, W, b, (1, 2, 2), (0, 1, 1))
+    lay = L()
+    xd, wd, bd = lay.act_to_dev(dev(x)), lay.conv_w_to_dev(dev(W)), dev(b)
+    for tile, cv in ((6, 3), (6, 0), (0, 3), (2, 3)):         # cv = 3: the kernels skip the products with the padded channel
+        g = hl.make_geom(N, Ti, H, H, 4, Co, kt, ci_valid=cv)
+        g.tile = tile
+        yd = torch.full((N, g.To, g.Ho, g.Wo, Co), 5.0, device="cuda")
+        hl.conv_fprop(g, xd, wd, bd, yd)
+        assert rel_l2(lay.act_from_dev(yd, Co), y_ref) < FWD_TOL, tile
+        M = N * g.To * g.Ho * g.Wo
+        for groups in ((1, 2) if N % 2 == 0 else (1,)):
+            noise = 0.2 * rng.randn(*y_ref.shape)
+            nd = lay.act_to_dev(dev(noise))
+            ng = N // groups
+            mask = torch.zeros((M, 2), dtype=torch.int32, device="cuda")
+            ep = hl.epilogue(act=hl.ACT_LRELU, groups=groups, addend=[nd[i * ng:(i + 1) * ng] for i in range(groups)], mask_out=mask)
+            ad = torch.empty_like(yd)
+            hl.conv_fprop(g, xd, wd, bd, ad, ep=ep, must_fuse=True)
+            assert rel_l2(lay.act_from_dev(ad, Co), F.leaky_relu_fwd(y_ref) + noise) < FWD_TOL, (tile, groups)
+            pre = lay.act_to_dev(dev(y_ref)).reshape(M, Co).cpu().numpy()
+            sure = np.abs(pre) > 1e-5
+            assert np.array_equal(_mask_bits(mask, Co)[sure], (pre >= 0)[sure]), (tile, groups)
+            mg = M // groups
+            ep = hl.epilogue(act=hl.ACT_LRELU, groups=groups, sigma=0.2, seed=5, stream_id=[11, 12][:groups], mask_out=mask)
+            hl.conv_fprop(g, xd, wd, bd, ad, ep=ep, must_fuse=True)
+            got = ad.reshape(M, Co).cpu().double().numpy() - np.where(pre >= 0, pre, 0.2 * pre)
+            for gi in range(groups):
+                assert np.abs(got[gi * mg:(gi + 1) * mg] - philox.randn_rowquad(mg, Co, 0.2, 5, [11, 12][gi])).max() < 2e-5
+    g = hl.make_geom(2, 5, 16, 16, 8, 64, 4)                  # not a first-layer geometry: the code is refused
+    g.tile = 6
+    z = torch.zeros(1, device="cuda")
+    with pytest.raises(hl.McgError):
+        hl.conv_fprop(g, torch.zeros((2, 5, 16, 16, 8), device="cuda"), torch.zeros((64, 4, 4, 4, 8), device="cuda"), None,
+                      torch.zeros((2, 2, 8, 8, 64), device="cuda"))

@@ -50,6 +50,7 @@ def main():
     ap.add_argument('--only', default='')
     ap.add_argument('--precision', default='f32', choices=['f32', 'bf16'])
     ap.add_argument('--net', default='', help='restrict to layers whose name starts with this (e.g. D_V)')
+    ap.add_argument('--layer', default='', help='restrict to layers whose name contains this (e.g. dc1)')
     ap.add_argument('--autotune', action='store_true', help='time the tile candidates per geometry first')
     ap.add_argument('--save-tiles', default='', help='write the tuned choices to this JSON file')
     ap.add_argument('--tiles', default='', help='use the tile choices of this JSON file (no tuning launches)')
@@ -64,7 +65,9 @@ def main():
     for name, N, T, H, Ci, Co, kt, ci_real in layers(args.batch):
         if args.net and not name.startswith(args.net):
             continue
-        g = hl.make_geom(N, T, H, H, Ci, Co, kt, precision=args.precision)
+        if args.layer and args.layer not in name:
+            continue
+        g = hl.make_geom(N, T, H, H, Ci, Co, kt, precision=args.precision, ci_valid=ci_real)
         x = torch.randn((N, T, H, H, Ci), device='cuda')
         y = torch.randn((N, g.To, g.Ho, g.Wo, Co), device='cuda')
         w = torch.randn((Co, kt, 4, 4, Ci), device='cuda') * 0.05
