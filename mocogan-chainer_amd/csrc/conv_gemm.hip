@@ -1068,6 +1068,145 @@ __global__ __launch_bounds__(512) void fprop_c4_kernel(C4FpropP p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// dgrad for Ci == 4 (<= 3 data channels), Co == 64 on the MATRIX pipe -- the input gradient of D's first layer.
+// With 3..4 output columns the parity-class GEMM of DgradP leaves the MFMA tile empty, and the VALU kernel below runs
+// at a quarter of the matrix rate.  Here the taps move to the N side:
+//     Z[pix_o][(a, kh, kw, ci)] = sum_co y[pix_o][co] * w[co][a][kh][kw][ci]          (dense GEMM, K = 64, N = kt * 48)
+//     x[pix_i][ci]              = sum over the (<= 4 per temporal tap) (pix_o, kh, kw) that hit pix_i of Z   (col2im)
+// and the col2im happens in LDS: a block owns R = 128 / Wo rows of y of one batch item and walks the output frames; per
+// frame and temporal tap a it computes Z_a (128 pixels x 48 columns, v_mfma_f32_16x16x4_f32: N in units of 16),
+// stages it in LDS, and every thread GATHERS, in a fixed order, the four taps of "its" input pixels into a ring of kt
+// input-frame accumulators; a frame leaves the ring when its last temporal tap has been added.  The two top and two
+// bottom rows of a block's input window also receive taps from the neighbouring block: those rows are added with
+// atomicAdd onto the zeroed x -- exactly two addends per element, and 0 + a + b == 0 + b + a in floating point, so the
+// result does not depend on the order.  No bias / activation / accumulate (the caller falls back to the VALU kernel).
+// ------------------------------------------------------------------------------------------
+struct C4DgradP {
+    Geom g;
+    const float* y; const float* w; float* x;
+};
+
+template <int KT, int WO>
+__global__ __launch_bounds__(512) void dgrad_c4_mfma_kernel(C4DgradP p) {
+    constexpr int PIX = 128, R = PIX / WO, WI = 2 * WO, XR = 2 * R + 2;       // y pixels per step; input rows of the window
+    constexpr int YLD = 68, WLD = 68, ZLD = 52;                              // LDS row strides (floats)
+    constexpr int NPX = XR * WI, PPT = (NPX + 511) / 512;                    // input pixels of the window; per thread
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* yl = sm;                                  // [PIX][YLD]
+    float* wl = yl + PIX * YLD;                      // [KT * 48][WLD]: wl[(a * 16 + kh * 4 + kw) * 3 + ci][co]
+    float* zl = wl + KT * 48 * WLD;                  // [PIX][ZLD]
+    f32x4* al = reinterpret_cast<f32x4*>(zl + PIX * ZLD);                   // [KT][XR][WI] accumulators (x, y, z = ci 0..2)
+    const Geom& g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hblocks = g.Ho / R;
+    const int n = blockIdx.x / hblocks, h0 = (blockIdx.x - n * hblocks) * R;
+    const __amdgpu_buffer_rsrc_t yr = make_srd(p.y, g.y_bytes);
+
+    // ---- weights -> LDS, transposed to [column][co]
+    for (int i = tid; i < KT * 48 * 64; i += 512) {
+        const int co = i & 63, col = i >> 6, ci = col % 3, tap = col / 3;    // tap = a * 16 + kh * 4 + kw
+        wl[col * WLD + co] = p.w[((long long)co * g.taps + tap) * 4 + ci];
+    }
+    for (int i = tid; i < KT * NPX; i += 512) al[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- per-thread gather plan: input pixel -> its four (kh, kw) taps: offset into zl (floats) or -1
+    int gz[PPT][4];
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+        const int px = tid + 512 * q, hl = px / WI, wi = px - hl * WI;      // hl: row of the window, hi = 2 h0 - 1 + hl
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int kh = (hl & 1) + 2 * (k >> 1), kw = ((wi + 1) & 1) + 2 * (k & 1);
+            const int hol = (hl - kh) / 2, wo = (wi + 1 - kw) / 2;            // both differences are even
+            const bool ok = px < NPX && hl - kh >= 0 && hol < R && wi + 1 - kw >= 0 && wo < WO;
+            gz[q][k] = ok ? (hol * WO + wo) * ZLD + (kh * 4 + kw) * 3 : -1;
+        }
+    }
+    // y tile loader: thread -> (pixel, 16-byte chunk)
+    u32 yoff[PIX * 16 / 512];
+#pragma unroll
+    for (int j = 0; j < PIX * 16 / 512; ++j) {
+        const int s = tid + 512 * j, pix = s >> 4, c4 = s & 15, hol = pix / WO, wo = pix - hol * WO;
+        yoff[j] = (u32)((((long long)n * g.To * g.Ho + h0 + hol) * WO + wo) * 64 + c4 * 4) * 4u;   // + to * Ho * WO * 256 per frame
+    }
+    const u32 yframe = (u32)g.Ho * WO * 256u;
+    f32x4 ystage[PIX * 16 / 512];
+#pragma unroll
+    for (int j = 0; j < PIX * 16 / 512; ++j) ystage[j] = bload(yr, yoff[j]);
+
+    const int li = lane & 15, kq = lane >> 4;
+    auto retire = [&](int t) {              // frame t has all its temporal taps: write its window rows, clear the accumulator
+        const int slot = t % KT;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const int px = tid + 512 * q;
+            if (px >= NPX) continue;
+            const int hl = px / WI, wi = px - hl * WI, hi = 2 * h0 - 1 + hl;
+            f32x4 v = al[slot * NPX + px];
+            al[slot * NPX + px] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)hi >= (unsigned)g.Hi) continue;
+            float* o = p.x + x_batch_off(g, n) + ((long long)(t * g.Hi + hi) * WI + wi) * 4;
+            if (hl < 2 || hl >= 2 * R) { atomicAdd(o, v[0]); atomicAdd(o + 1, v[1]); atomicAdd(o + 2, v[2]); }   // shared with the neighbour block
+            else { v[3] = 0.f; *reinterpret_cast<f32x4*>(o) = v; }
+        }
+    };
+
+    for (int to = 0; to < g.To; ++to) {
+        __syncthreads();                                          // previous step's readers of yl / accumulators are done
+#pragma unroll
+        for (int j = 0; j < PIX * 16 / 512; ++j) {
+            const int s = tid + 512 * j;
+            *reinterpret_cast<f32x4*>(yl + (s >> 4) * YLD + (s & 15) * 4) = ystage[j];
+        }
+        __syncthreads();
+        if (to + 1 < g.To) {
+#pragma unroll
+            for (int j = 0; j < PIX * 16 / 512; ++j) ystage[j] = bload(yr, yoff[j] + (u32)(to + 1) * yframe);
+        }
+        // A fragments of this wave's 16 pixels (all of K = 64): element m of read gq is co = 16 gq + 4 kq + m
+        f32x4 af[4];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) af[gq] = *reinterpret_cast<const f32x4*>(yl + (wave * 16 + li) * YLD + gq * 16 + kq * 4);
+#pragma unroll
+        for (int a = 0; a < KT; ++a) {
+            f32x4 zc[3];
+#pragma unroll
+            for (int cb = 0; cb < 3; ++cb) {
+                zc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const f32x4 bf = *reinterpret_cast<const f32x4*>(wl + (a * 48 + cb * 16 + li) * WLD + gq * 16 + kq * 4);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) zc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[gq][m], bf[m], zc[cb], 0, 0, 0);
+                }
+            }
+            if (a > 0) __syncthreads();                           // the previous tap's gather has read zl
+            // D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + reg
+#pragma unroll
+            for (int cb = 0; cb < 3; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) zl[(wave * 16 + kq * 4 + r) * ZLD + cb * 16 + li] = zc[cb][r];
+            __syncthreads();
+            const int slot = (to + a) % KT;
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) {
+                const int px = tid + 512 * q;
+                if (px >= NPX) continue;
+                f32x4 v = al[slot * NPX + px];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (gz[q][k] >= 0) { const float* z = zl + gz[q][k]; v[0] += z[0]; v[1] += z[1]; v[2] += z[2]; }
+                al[slot * NPX + px] = v;
+            }
+        }
+        __syncthreads();                                          // all gathers of this step are in the accumulators
+        retire(to);
+    }
+    __syncthreads();
+    for (int t = g.To; t < g.Ti; ++t) retire(t);                  // the last kt - 1 frames
+}
+
+// ------------------------------------------------------------------------------------------
 // dgrad for Ci == 4, Co == 64 (the 3-channel clip padded to 4: D's first layer backward and G's
 // last layer forward).  N = 4 output columns would waste 15/16 of a 64-wide MFMA tile, so this case
 // runs on the VALU with fully coalesced loads.  A wave works on a run of 16 consecutive HALF-resolution
@@ -1203,6 +1342,29 @@ int launch_fprop_c4(const Geom& g, const float* x, const float* w, const float* 
     if (e.mode & EPI_ACT) { if (g.cv <= 3) MCG_C4_LAUNCH(3, 3, 0); else MCG_C4_LAUNCH(3, 4, 1); }
     else { if (g.cv <= 3) MCG_C4_LAUNCH(1, 3, 2); else MCG_C4_LAUNCH(1, 4, 3); }
 #undef MCG_C4_LAUNCH
+    return MCG_OK;
+}
+
+// the MFMA col2im input-gradient kernel of the Ci = 4 layers: what it covers
+bool c4_dgrad_mfma_ok(const Geom& g, const Epi& e, const float* bias, int act, int accumulate) {
+    const long long frame = (long long)g.Ti * g.Hi * g.Wi * g.Ci;
+    return g.Ci == 4 && g.cv <= 3 && g.Co == 64 && (g.Wo == 32 || g.Wo == 16) && g.Ho % (128 / g.Wo) == 0 && !g.perm_n && g.xs0 == frame &&
+           !e.mode && !bias && act == MCG_ACT_NONE && !accumulate;
+}
+
+template <int KT, int WO>
+int launch_dgrad_c4_mfma(const Geom& g, const float* y, const float* w, float* x, hipStream_t s) {
+    C4DgradP p;
+    p.g = g; p.y = y; p.w = w; p.x = x;
+    constexpr int R = 128 / WO, NPX = (2 * R + 2) * 2 * WO;
+    const size_t lds = (size_t)(128 * 68 + KT * 48 * 68 + 128 * 52) * 4 + (size_t)KT * NPX * 16;
+    static std::once_flag once;
+    hipError_t attr = hipSuccess;
+    std::call_once(once, [&] { attr = hipFuncSetAttribute((const void*)dgrad_c4_mfma_kernel<KT, WO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+    if (attr != hipSuccess) return MCG_ERR_LAUNCH;
+    // the rows two neighbouring blocks share are ADDED (two addends, order-independent): x starts from zero
+    if (hipMemsetAsync(x, 0, (size_t)g.N * g.Ti * g.Hi * g.Wi * 4 * sizeof(float), s) != hipSuccess) return MCG_ERR_LAUNCH;
+    hipLaunchKernelGGL((dgrad_c4_mfma_kernel<KT, WO>), dim3(g.N * (g.Ho / R)), dim3(512), lds, s, p);
     return MCG_OK;
 }
 
@@ -1497,6 +1659,12 @@ int conv_dgrad_impl(const mcg_conv_geom* c, const float* y, const float* w, cons
     long long M = (long long)g.N * g.Ti * g.Ho * g.Wo;
     int t = g.tile;
     const int bk = g.bk;
+    if ((t == 0 || t == 6) && g.prec == MCG_PREC_F32 && c4_dgrad_mfma_ok(g, e, bias, act, accumulate)) {
+        if (g.kt == 4) st = g.Wo == 32 ? launch_dgrad_c4_mfma<4, 32>(g, y, w, x, s) : launch_dgrad_c4_mfma<4, 16>(g, y, w, x, s);
+        else st = g.Wo == 32 ? launch_dgrad_c4_mfma<1, 32>(g, y, w, x, s) : launch_dgrad_c4_mfma<1, 16>(g, y, w, x, s);
+        return finish(st);
+    }
+    if (t == 6) t = 0;                                           // elsewhere the first-layer code means "the kernel written for it"
     if (!t && !e.mode && g.Ci == 4 && g.Co == 64 && (g.Wo & 15) == 0) {      // VALU kernel for the padded 3-channel clip
         const int runs = (int)(M / 16);                          // M = N*Ti*Ho*Wo half-resolution positions
         const int per_block = (NTHREADS / 64) * C4_RUNS_PER_WAVE;

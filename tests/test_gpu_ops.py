@@ -304,7 +304,7 @@ def test_philox_noise_matches_oracle_stream(hl):
     out = torch.empty(n, device="cuda")
     hl.randn(out, 0.2, 0x1234567887654321, 42)
     ref = philox.randn(n, 0.2, 0x1234567887654321, 42)
-    assert np.abs(out.cpu().numpy() - ref).max() < 2e-6
+    assert np.abs(out.cpu().numpy() - ref).max() < 4e-6            # sigma = 0.2: 2e-5 per unit normal (hardware log2 / sin / cos)
     # the fused paths draw the SAME stream: lrelu(y) + sigma*randn, padded channel masked
     M, C = 1000, 4
     y = torch.randn(M, C, device="cuda")
@@ -313,7 +313,7 @@ def test_philox_noise_matches_oracle_stream(hl):
     z = philox.randn(M * C, 0.2, 7, 3).reshape(M, C)
     z[:, 3] = 0
     yl = torch.where(y >= 0, y, 0.2 * y).cpu().numpy()
-    assert np.abs(o.cpu().numpy() - (yl + z)).max() < 3e-6
+    assert np.abs(o.cpu().numpy() - (yl + z)).max() < 5e-6
 
 
 def test_pack_unpack_and_tanh_bwd_to_frames(hl):
@@ -484,7 +484,7 @@ def test_fprop_epilogue_statistics_and_first_layer(hl, case, tile):
             assert np.abs(got[gi * mg:(gi + 1) * mg] - z).max() < 2e-5, (groups, gi)
             zd = torch.empty((mg, Co), device="cuda")
             hl.randn_rowquad(zd, Co, 0.2, 77, [5, 9][gi])
-            assert np.abs(zd.cpu().double().numpy() - z).max() < 2e-6
+            assert np.abs(zd.cpu().double().numpy() - z).max() < 4e-6
 
 
 @pytest.mark.parametrize("case", EPI_CASES[:3])
@@ -634,6 +634,23 @@ def test_weight_stationary_first_layer_kernels(hl, case):
             got = ad.reshape(M, Co).cpu().double().numpy() - np.where(pre >= 0, pre, 0.2 * pre)
             for gi in range(groups):
                 assert np.abs(got[gi * mg:(gi + 1) * mg] - philox.randn_rowquad(mg, Co, 0.2, 5, [11, 12][gi])).max() < 2e-5
+    # input gradient: the MFMA col2im kernel (ci_valid = 3, tile 0 / 6) against the oracle; the accumulating call and
+    # ci_valid = 0 take the VALU kernel
+    gy = rng.randn(*y_ref.shape)
+    gx_ref, _, _ = F.conv3d_bwd(x, W, gy, (1, 2, 2), (0, 1, 1))
+    gyd = lay.act_to_dev(dev(gy))
+    for tile, cv in ((6, 3), (0, 3), (0, 0)):
+        g = hl.make_geom(N, Ti, H, H, 4, Co, kt, ci_valid=cv)
+        g.tile = tile
+        gxd = torch.full_like(xd, 7.0)
+        hl.conv_dgrad(g, gyd, wd, None, gxd)
+        assert rel_l2(lay.act_from_dev(gxd, Ci), gx_ref) < BWD_TOL, (tile, cv)
+        assert float(gxd[..., 3].abs().max()) == 0.0
+        again = torch.full_like(xd, -3.0)
+        hl.conv_dgrad(g, gyd, wd, None, again)
+        assert torch.equal(again, gxd), "the shared rows are added by two blocks: the sum must not depend on their order"
+        hl.conv_dgrad(g, gyd, wd, None, gxd, accumulate=True)
+        assert rel_l2(lay.act_from_dev(gxd, Ci), 2 * gx_ref) < BWD_TOL, (tile, cv)
     g = hl.make_geom(2, 5, 16, 16, 8, 64, 4)                  # not a first-layer geometry: the code is refused
     g.tile = 6
     z = torch.zeros(1, device="cuda")
