@@ -431,9 +431,16 @@ __global__ __launch_bounds__(GRU_S * GRU_U) void gru_fwd_kernel(int N, int T, in
                                                                 const int32_t* __restrict__ labels, const float* __restrict__ zc,
                                                                 float* __restrict__ z, float* __restrict__ saved) {
     __shared__ float P[GRU_MAXP];
-    __shared__ float xs[GRU_S][GRU_MAXIN], hs[GRU_S][GRU_U], rhs[GRU_S][GRU_U];
+    __shared__ float xs[GRU_S][GRU_MAXIN + 1], hs[GRU_S][GRU_U + 1], rhs[GRU_S][GRU_U + 1];     // (+1: the 4 samples of a wave on 4 banks)
     const GruOff o = gru_offsets(dz, dl);
-    for (int i = threadIdx.x; i < o.total; i += blockDim.x) P[i] = params[i];
+    // weights are kept TRANSPOSED in LDS ([input][unit]): the 16 lanes of a sample read 16 consecutive words per input
+    // instead of 16 words a row apart (an 8-way bank conflict on every one of the ~60 reads of a step)
+    for (int i = threadIdx.x; i < o.total; i += blockDim.x) {
+        int k = 5;
+        while (k > 0 && i < o.w[k]) --k;                       // which link
+        const int r = i - o.w[k], wsz = dz * o.in[k];
+        P[r < wsz ? o.w[k] + (r % o.in[k]) * dz + r / o.in[k] : i] = params[i];        // biases keep their place
+    }
     const int s = threadIdx.x / GRU_U, j = threadIdx.x % GRU_U;
     const int n = blockIdx.x * GRU_S + s;
     const bool live = n < N && j < dz;
@@ -453,21 +460,21 @@ __global__ __launch_bounds__(GRU_S * GRU_U) void gru_fwd_kernel(int N, int T, in
             hb = P[o.b[4] + j] + P[o.b[5] + j];
             for (int c = 0; c < in; ++c) {
                 float xv = xs[s][c];
-                ar = fmaf(P[o.w[0] + j * in + c], xv, ar);
-                az = fmaf(P[o.w[2] + j * in + c], xv, az);
-                hb = fmaf(P[o.w[4] + j * in + c], xv, hb);
+                ar = fmaf(P[o.w[0] + c * dz + j], xv, ar);
+                az = fmaf(P[o.w[2] + c * dz + j], xv, az);
+                hb = fmaf(P[o.w[4] + c * dz + j], xv, hb);
             }
             for (int c = 0; c < dz; ++c) {
                 float hv = hs[s][c];
-                ar = fmaf(P[o.w[1] + j * dz + c], hv, ar);
-                az = fmaf(P[o.w[3] + j * dz + c], hv, az);
+                ar = fmaf(P[o.w[1] + c * dz + j], hv, ar);
+                az = fmaf(P[o.w[3] + c * dz + j], hv, az);
             }
             r = sigmoidf_(ar); zz = sigmoidf_(az); h = hs[s][j];
             rhs[s][j] = r * h;
         }
         __syncthreads();
         if (live) {
-            for (int c = 0; c < dz; ++c) hb = fmaf(P[o.w[5] + j * dz + c], rhs[s][c], hb);
+            for (int c = 0; c < dz; ++c) hb = fmaf(P[o.w[5] + c * dz + j], rhs[s][c], hb);
             hb = tanhf(hb);
             float hn = (1.f - zz) * h + zz * hb;
             float* sv = saved + ((long long)t * N + n) * 4 * dz;
@@ -484,8 +491,8 @@ __global__ __launch_bounds__(GRU_S * GRU_U) void gru_bwd_kernel(int N, int T, in
                                                                 const float* __restrict__ saved, const float* __restrict__ gz,
                                                                 float* __restrict__ dparams) {
     __shared__ float P[GRU_MAXP], DP[GRU_MAXP];
-    __shared__ float xs[GRU_S][GRU_MAXIN], ga_s[GRU_S][GRU_U], gaz_s[GRU_S][GRU_U], gar_s[GRU_S][GRU_U];
-    __shared__ float h_s[GRU_S][GRU_U], rh_s[GRU_S][GRU_U];
+    __shared__ float xs[GRU_S][GRU_MAXIN + 1], ga_s[GRU_S][GRU_U + 1], gaz_s[GRU_S][GRU_U + 1], gar_s[GRU_S][GRU_U + 1];
+    __shared__ float h_s[GRU_S][GRU_U + 1], rh_s[GRU_S][GRU_U + 1];
     const GruOff o = gru_offsets(dz, dl);
     for (int i = threadIdx.x; i < o.total; i += blockDim.x) { P[i] = params[i]; DP[i] = 0.f; }
     const int s = threadIdx.x / GRU_U, j = threadIdx.x % GRU_U;
