@@ -104,7 +104,7 @@ int main() {
     CK(hipMemcpy(dgamma, gamma.data(), Co * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dbeta, beta.data(), Co * 4, hipMemcpyHostToDevice));
     MCG(mcg_conv_fprop(&g, dx, dw, db, dy, s));
     MCG(mcg_bn_stats(M, Co, dy, dgamma, dbeta, dstats, nullptr, nullptr, 2e-5f, 0.9f, ws, s));
-    MCG(mcg_bn_act_fwd(M, Co, Co, dy, 0, 0, dstats + 2 * Co, MCG_ACT_LRELU, nullptr, 0.f, 0, 0, dout, s));
+    MCG(mcg_bn_act_fwd(M, Co, Co, dy, 0, 0, dstats + 2 * Co, MCG_ACT_LRELU, nullptr, 0.f, 0, 0, dout, 0, s));
     CK(hipStreamSynchronize(s));
     std::vector<float> out(ny);
     CK(hipMemcpy(out.data(), dout, ny * 4, hipMemcpyDeviceToHost));
@@ -126,7 +126,7 @@ int main() {
     CK(hipMemsetAsync(dm, 0, nw * 4, s)); CK(hipMemsetAsync(dv, 0, nw * 4, s));
     const double alpha = 2e-4, b1 = 5e-5, b2 = 0.999, eps = 1e-8, wd = 1e-5;
     const double lr_t = alpha * std::sqrt(1 - b2) / (1 - b1);
-    MCG(mcg_adam_wd((int64_t)nw, dw, dgw, dm, dv, lr_t, b1, b2, eps, wd, 1.0, s));
+    MCG(mcg_adam_wd((int64_t)nw, dw, dgw, dm, dv, lr_t, b1, b2, eps, wd, 1.0, nullptr, s));
     CK(hipStreamSynchronize(s));
     std::vector<float> w2(nw);
     CK(hipMemcpy(w2.data(), dw, nw * 4, hipMemcpyDeviceToHost));

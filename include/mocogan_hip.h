@@ -48,7 +48,11 @@ enum { MCG_ACT_NONE = 0, MCG_ACT_RELU = 1, MCG_ACT_LRELU = 2, MCG_ACT_TANH = 3 }
 /* MFMA operand type of the convolution GEMMs.  Tensors are fp32 in memory either way and products are
  * accumulated in fp32; MCG_PREC_BF16 rounds both operands to bf16 (round-to-nearest-even) inside the
  * kernel and multiplies them on v_mfma_f32_32x32x16_bf16 (BASELINE config "bf16 MFMA tiles"). */
-enum { MCG_PREC_F32 = 0, MCG_PREC_BF16 = 1 };
+enum { MCG_PREC_F32 = 0, MCG_PREC_BF16 = 1,
+       /* as MCG_PREC_BF16, with the INPUT operands of the call (x and w for fprop, y and w for dgrad, x and y for wgrad)
+        * already bf16 in memory (uint16_t, round-to-nearest-even of the fp32 values): they are loaded and staged as they
+        * are -- half the operand traffic, no conversion in the K loop.  Outputs stay fp32.  Ci, Co multiples of 8. */
+       MCG_PREC_BF16_STORE = 2 };
 
 /* Geometry of one 4x4(x4) stride-(1,2,2) pad-(0,1,1) convolution, i.e. every strided layer of
  * the reference: L.ConvolutionND / L.Convolution2D dc1..dc4 (model/net.py:133-136,174-177) and,
@@ -137,6 +141,8 @@ typedef struct mcg_conv_epilogue {
                                  * m & 3 of counter (m >> 2) * C + c (mcg_randn_rowquad draws the same stream) */
     uint64_t seed, stream_id[2];
     uint32_t* mask_out;         /* [rows][(C+31)/32] words, bit c & 31 of word c >> 5 set <=> pre-activation >= 0; or NULL */
+    int32_t out_bf16;           /* with act: y is a bf16 tensor (uint16_t) -- the operand of the next layer of a
+                                 * MCG_PREC_BF16_STORE network -- instead of fp32 */
     /* dgrad only: v *= (mask bit ? 1 : 0.2) -- leaky_relu's backward from the bits the forward pass stored */
     const uint32_t* mask_in;
     /* out (host side, valid after the call): */
@@ -183,7 +189,9 @@ int mcg_bn_stats(int64_t M, int C, const float* y, const float* gamma, const flo
 int mcg_bn_act_fwd(int64_t M, int C, int c_valid, const float* y, int64_t y_rows_per_item,
                    int64_t y_item_stride, const float* scale_shift, int act,
                    const float* addend, float sigma, uint64_t seed, uint64_t stream_id,
-                   float* out, void* stream);
+                   void* out, int out_bf16, void* stream);
+/* (out_bf16 != 0: `out` is a bf16 tensor (uint16_t, round-to-nearest-even) -- the activations of a
+ * MCG_PREC_BF16_STORE network are only ever read as GEMM operands; likewise gx_bf16 of the backward passes below) */
 
 /* Backward of the line above + BN.  g_out: gradient w.r.t. `out`.  Computes
  * g_bn = g_out * act'(y*scale+shift) (the mask is recomputed from the SAVED scale/shift, i.e.
@@ -193,7 +201,7 @@ int mcg_bn_act_fwd(int64_t M, int C, int c_valid, const float* y, int64_t y_rows
  * stats == NULL means "no BN": gx = g_out * act'(y).  act == MCG_ACT_TANH uses y as the saved
  * tanh OUTPUT.  in-place (gx == g_out) is allowed.  workspace: mcg_bn_workspace_bytes(M, C). */
 int mcg_bn_act_bwd(int64_t M, int C, const float* g_out, const float* y, const float* stats,
-                   const float* gamma, int act, float* gx, float* dgamma, float* dbeta,
+                   const float* gamma, int act, void* gx, int gx_bf16, float* dgamma, float* dbeta,
                    void* workspace, void* stream);
 
 /* ---- synchronised BatchNorm (opt-in under data parallelism; the reference is single-device) ---------------
@@ -225,8 +233,8 @@ int mcg_bn_stats_from_partials(int64_t M, int C, const float* part, int n_slots,
                                const float* beta, float* stats, float* avg_mean, float* avg_var, float eps, float decay,
                                void* workspace, void* stream);
 int mcg_bn_act_bwd_from_partials(int64_t M, int C, const float* g_out, const float* y, const float* stats,
-                                 const float* gamma, int act, const float* part, int n_slots, int slot_stride, float* gx,
-                                 float* dgamma, float* dbeta, void* workspace, void* stream);
+                                 const float* gamma, int act, const float* part, int n_slots, int slot_stride, void* gx,
+                                 int gx_bf16, float* dgamma, float* dbeta, void* workspace, void* stream);
 int mcg_colsum_from_partials(int C, const float* part, int n_slots, int slot_stride, float* db, void* workspace,
                              void* stream);
 
@@ -278,7 +286,8 @@ int mcg_loss_gen(int N, int C, const float* y_fake_i, const float* y_fake_v, con
  * (the reference) and 1/world under data parallelism, where g holds the all-reduced SUM of the ranks' gradients:
  * the mean is formed here instead of in a separate pass over the gradient. */
 int mcg_adam_wd(int64_t n, float* p, const float* g, float* m, float* v, double lr_t, double beta1,
-                double beta2, double eps, double wd, double grad_scale, void* stream);
+                double beta2, double eps, double wd, double grad_scale, uint16_t* p_bf16, void* stream);
+/* (p_bf16, may be NULL: a bf16 copy of the updated parameters, the weight operand of MCG_PREC_BF16_STORE launches) */
 
 /* out[i] = sigma * N(0,1), the same Philox stream mcg_bn_act_fwd / mcg_pack_clip draw from. */
 int mcg_randn(int64_t n, float sigma, uint64_t seed, uint64_t stream_id, float* out, void* stream);

@@ -73,6 +73,7 @@ struct Epi {
     const float* bn_y; const float* bn_stats[2]; int bn_act;
     const float* addend[2]; float sigma; u64 seed; u64 stream[2];
     u32* mask_out; const u32* mask_in; int mask_cb;
+    int out16;                  // EPI_ACT: the output tensor is bf16 (the next layer's operand in MCG_PREC_BF16_STORE networks)
 };
 struct RowInfo { long long base; long long pix; int grp; bool ok; };   // base: element offset of the row's column 0 in the output
 
@@ -109,12 +110,16 @@ __device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t r, u32 byte_off) {
 // owns slots q = tid + 256*j, row = q / (C/4), c4 = q % (C/4).
 // ------------------------------------------------------------------------------------------
 
+// E (all policies): elements per 16-byte operand slot -- 4: the operands are fp32 in memory (both MFMA types);
+// 8: they are bf16 in memory (MCG_PREC_BF16_STORE), a slot is loaded and written to LDS as it is.  Outputs are fp32.
+
 // ---------------- fprop ----------------
-template <int BM, int BN, int BK>
+template <int BM, int BN, int BK, int E_ = 4>
 struct FpropP {
     static constexpr bool A_KC = true, B_KC = true;
     static constexpr int ORDER = 0;
-    static constexpr int NA = BM * BK / 4 / NTHREADS, NB = BN * BK / 4 / NTHREADS;
+    static constexpr int E = E_, ESZ = 16 / E_;
+    static constexpr int NA = BM * BK / E / NTHREADS, NB = BN * BK / E / NTHREADS;
     static constexpr bool HAS_EPI = true;
     Geom g;
     Epi e;
@@ -136,10 +141,10 @@ struct FpropP {
                         // for the quarter of a tile's run time that otherwise separates the four uses).
 
     __device__ void init(int m0, int n0, int tid, int z) {
-        constexpr int KC4 = BK / 4, RSTEP = NTHREADS / KC4;        // float4 slots per tile row, rows per pass
+        constexpr int KC4 = BK / E, RSTEP = NTHREADS / KC4;        // 16-byte slots per tile row, rows per pass
         xr = make_srd(x, g.x_bytes); wr = make_srd(w, g.w_bytes);
         zz = z;
-        ak = (tid % KC4) * 4;
+        ak = (tid % KC4) * E;
         krot = 0;
 #ifndef MCG_NO_KROT          // (timing A/B only)
         if (g.kt == 4) {
@@ -156,7 +161,7 @@ struct FpropP {
             int wo = mm & (g.Wo - 1), ho = (mm >> g.lgWo) & (g.Ho - 1), q = mm >> (g.lgWo + g.lgHo);
             int n = div_To(g, q), to = q - n * g.To;
             int hi0 = 2 * ho - 1, wi0 = 2 * wo - 1;
-            abase[j] = ((int)x_batch_off(g, n) + ((to * g.Hi + hi0) * g.Wi + wi0) * g.Ci) * 4;
+            abase[j] = ((int)x_batch_off(g, n) + ((to * g.Hi + hi0) * g.Wi + wi0) * g.Ci) * ESZ;
             u32 mk = 0;
 #pragma unroll
             for (int kh = 0; kh < 4; ++kh)
@@ -168,7 +173,7 @@ struct FpropP {
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             int co = n0 + tid / KC4 + RSTEP * j;
-            bbase[j] = co < g.Co ? (u32)(co * K + ak) * 4u : OOB;
+            bbase[j] = co < g.Co ? (u32)(co * K + ak) * (u32)ESZ : OOB;
         }
     }
     __device__ int k_begin(int z) const { return z * kchunk; }
@@ -180,12 +185,12 @@ struct FpropP {
         int tap, ci;
         divmod_c(k, g.Ci, g.lgCi, tap, ci);
         int sp = tap & 15;
-        int off = ((((tap >> 4) * g.Hi + (sp >> 2)) * g.Wi + (sp & 3)) * g.Ci + ci) * 4;
+        int off = ((((tap >> 4) * g.Hi + (sp >> 2)) * g.Wi + (sp & 3)) * g.Ci + ci) * ESZ;
 #pragma unroll
         for (int j = 0; j < NA; ++j) r[j] = bload(xr, (amask[j] >> sp) & 1u ? (u32)(abase[j] + off) : OOB);
     }
     __device__ void load_b(int k0, f32x4 (&r)[NB]) const {
-        const u32 kb = (u32)rotated(k0) * 4u;
+        const u32 kb = (u32)rotated(k0) * (u32)ESZ;
 #pragma unroll
         for (int j = 0; j < NB; ++j) r[j] = bload(wr, bbase[j] + kb);
     }
@@ -207,11 +212,12 @@ struct FpropP {
 };
 
 // ---------------- dgrad (one output-parity class per blockIdx.z) ----------------
-template <int BM, int BN, int BK>
+template <int BM, int BN, int BK, int E_ = 4>
 struct DgradP {
     static constexpr bool A_KC = true, B_KC = false;
     static constexpr int ORDER = 1;
-    static constexpr int NA = BM * BK / 4 / NTHREADS, NB = BN * BK / 4 / NTHREADS;
+    static constexpr int E = E_, ESZ = 16 / E_;
+    static constexpr int NA = BM * BK / E / NTHREADS, NB = BN * BK / E / NTHREADS;
     static constexpr bool HAS_EPI = true;
     Geom g;
     Epi e;
@@ -234,10 +240,10 @@ struct DgradP {
     // t: a temporal tap `a` whose source frame t - a falls outside [0, To) is then invalid for the whole
     // block and its K-steps are skipped (no loads, no MFMAs).  For D_V this removes 19..43 % of the work.
     __device__ void init(int m0, int n0, int tid, int z) {
-        constexpr int KC4 = BK / 4, RSTEP = NTHREADS / KC4;
+        constexpr int KC4 = BK / E, RSTEP = NTHREADS / KC4;
         yr = make_srd(y, g.y_bytes); wr = make_srd(w, g.w_bytes);
         ph = (z >> 1) & 1; pw = z & 1; zsplit = z >> 2;
-        ak = (tid % KC4) * 4;
+        ak = (tid % KC4) * E;
         {
             int mlast = m0 + BM - 1 < M ? m0 + BM - 1 : M - 1;
             tmin = div_N(g, m0 >> (g.lgWo + g.lgHo));
@@ -255,7 +261,7 @@ struct DgradP {
             int w2 = mm & (g.Wo - 1), h2 = (mm >> g.lgWo) & (g.Ho - 1), q = mm >> (g.lgWo + g.lgHo);
             int t = div_N(g, q), n = q - t * g.N;
             int hh = h2 + ph, ww = w2 + pw;
-            abase[j] = ((((n * g.To + t) * g.Ho + hh) * g.Wo + ww) * g.Co) * 4;
+            abase[j] = ((((n * g.To + t) * g.Ho + hh) * g.Wo + ww) * g.Co) * ESZ;
             u32 mk = 0;
             for (int a = 0; a < g.kt; ++a)
 #pragma unroll
@@ -265,13 +271,13 @@ struct DgradP {
             amask[j] = mk;
         }
         // B tile: rows = k (BK), cols = ci (BN); BN/4 float4 per row
-        constexpr int C4 = BN / 4;
-        bci = n0 + (tid % C4) * 4;
+        constexpr int C4 = BN / E;                                  // 16-byte slots per row
+        bci = n0 + (tid % C4) * E;
         bok = bci < g.Ci;
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             bkrow[j] = tid / C4 + (NTHREADS / C4) * j;
-            bfast[j] = bok ? (u32)(bkrow[j] * g.taps * g.Ci + bci) * 4u : OOB;
+            bfast[j] = bok ? (u32)(bkrow[j] * g.taps * g.Ci + bci) * (u32)ESZ : OOB;
         }
     }
     __device__ int k_begin(int z) const { return (z >> 2) * kchunk; }
@@ -299,7 +305,7 @@ struct DgradP {
         int k = rotated(k0) + ak;
         int ts, co;
         divmod_c(k, g.Co, g.lgCo, ts, co);
-        int off = (co - (((ts >> 2) * g.Ho + ((ts >> 1) & 1)) * g.Wo + (ts & 1)) * g.Co) * 4;
+        int off = (co - (((ts >> 2) * g.Ho + ((ts >> 1) & 1)) * g.Wo + (ts & 1)) * g.Co) * ESZ;
 #pragma unroll
         for (int j = 0; j < NA; ++j) r[j] = bload(yr, (amask[j] >> ts) & 1u ? (u32)(abase[j] + off) : OOB);
     }
@@ -309,7 +315,7 @@ struct DgradP {
             // every k of this K-step shares one sub-filter tap: the tap part of the address is wave-uniform
             int ts = k0 >> g.lgCo, co0 = k0 & (g.Co - 1);
             int tap = (ts >> 2) * 16 + ((1 - ph) + (ts & 2)) * 4 + (1 - pw) + 2 * (ts & 1);
-            u32 base = (u32)((co0 * g.taps + tap) * g.Ci) * 4u;
+            u32 base = (u32)((co0 * g.taps + tap) * g.Ci) * (u32)ESZ;
 #pragma unroll
             for (int j = 0; j < NB; ++j) r[j] = bload(wr, bfast[j] + base);
             return;
@@ -320,7 +326,7 @@ struct DgradP {
             int ts, co;
             divmod_c(k, g.Co, g.lgCo, ts, co);
             int tap = (ts >> 2) * 16 + ((1 - ph) + (ts & 2)) * 4 + (1 - pw) + 2 * (ts & 1);
-            u32 vo = (u32)((co * g.taps + tap) * g.Ci + bci) * 4u;
+            u32 vo = (u32)((co * g.taps + tap) * g.Ci + bci) * (u32)ESZ;
             r[j] = bload(wr, bok ? vo : OOB);
         }
     }
@@ -356,12 +362,13 @@ struct DgradP {
 };
 
 // ---------------- wgrad (blockIdx.z = pixel split) ----------------
-template <int BM, int BN, int BK>
+template <int BM, int BN, int BK, int E_ = 4>
 struct WgradP {
     static constexpr bool HAS_EPI = false;
     static constexpr bool A_KC = false, B_KC = false;
     static constexpr int ORDER = 2;
-    static constexpr int NA = BM * BK / 4 / NTHREADS, NB = BN * BK / 4 / NTHREADS;
+    static constexpr int E = E_, ESZ = 16 / E_;
+    static constexpr int NA = BM * BK / E / NTHREADS, NB = BN * BK / E / NTHREADS;
     Geom g;
     const float* x; const float* y; float* dw;
     int Mpix, Kf, chunk;          // Kf = taps*Ci ; chunk = pixels per split (multiple of BK)
@@ -370,13 +377,13 @@ struct WgradP {
     bool bok; int bt, bkh, bkw, bci; int bkrow[NB];
 
     __device__ void init(int m0, int n0, int tid, int /*z*/) {
-        constexpr int AC4 = BM / 4, BC4 = BN / 4;
+        constexpr int AC4 = BM / E, BC4 = BN / E;
         xr = make_srd(x, g.x_bytes); yr = make_srd(y, g.y_bytes);
-        int aco = m0 + (tid % AC4) * 4;
-        aoff = aco < g.Co ? (u32)aco * 4u : OOB;
+        int aco = m0 + (tid % AC4) * E;
+        aoff = aco < g.Co ? (u32)aco * (u32)ESZ : OOB;
 #pragma unroll
         for (int j = 0; j < NA; ++j) akrow[j] = tid / AC4 + (NTHREADS / AC4) * j;
-        int bkf = n0 + (tid % BC4) * 4;
+        int bkf = n0 + (tid % BC4) * E;
         bok = bkf < Kf;
         int kk = bok ? bkf : 0, tap;
         divmod_c(kk, g.Ci, g.lgCi, tap, bci);
@@ -390,7 +397,7 @@ struct WgradP {
     __device__ void load_a(int k0, f32x4 (&r)[NA]) const {
         // rows beyond Mpix fall outside the buffer: the range check returns zeros
 #pragma unroll
-        for (int j = 0; j < NA; ++j) r[j] = bload(yr, aoff + (u32)((k0 + akrow[j]) * g.Co) * 4u);
+        for (int j = 0; j < NA; ++j) r[j] = bload(yr, aoff + (u32)((k0 + akrow[j]) * g.Co) * (u32)ESZ);
     }
     // (An incremental per-slot pixel decode -- wo/ho/q advanced by BK with carries -- was measured 3-8 %
     // slower than re-decoding with shifts and the multiply-high division: it costs 12 VGPRs.)
@@ -404,7 +411,7 @@ struct WgradP {
             int hi = 2 * ho - 1 + bkh, wi = 2 * wo - 1 + bkw;
             ok = ok && (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)g.Wi;
             int base = g.perm_n ? (int)x_batch_off(g, n) : n * (int)g.xs0;
-            u32 vo = (u32)(base + (((to + bt) * g.Hi + hi) * g.Wi + wi) * g.Ci + bci) * 4u;
+            u32 vo = (u32)(base + (((to + bt) * g.Hi + hi) * g.Wi + wi) * g.Ci + bci) * (u32)ESZ;
             r[j] = bload(xr, ok ? vo : OOB);
         }
     }
@@ -419,6 +426,7 @@ struct WgradP {
 template <int BM, int BN, int BK>
 struct FcFpropP {
     static constexpr bool HAS_EPI = false;
+    static constexpr int E = 4;
     static constexpr bool A_KC = true, B_KC = true;
     static constexpr int ORDER = 0;
     static constexpr int NA = BM * BK / 4 / NTHREADS, NB = BN * BK / 4 / NTHREADS;
@@ -461,6 +469,7 @@ struct FcFpropP {
 template <int BM, int BN, int BK>
 struct FcWgradP {
     static constexpr bool HAS_EPI = false;
+    static constexpr int E = 4;
     static constexpr bool A_KC = false, B_KC = false;
     static constexpr int ORDER = 2;
     static constexpr int NA = BM * BK / 4 / NTHREADS, NB = BN * BK / 4 / NTHREADS;
@@ -578,7 +587,10 @@ __device__ __forceinline__ void fused_epilogue(const P& p, f32x16 (&acc)[TM][TN]
                         const u32 wd = ok ? e.mask_in[ri.pix * e.mask_cb + (col >> 5)] : 0xffffffffu;
                         v = ((wd >> (col & 31)) & 1u) ? v : v * EPI_LRELU_SLOPE;
                     }
-                    if (ok) out[o] = v;
+                    if (ok) {
+                        if ((mode & EPI_ACT) && e.out16) reinterpret_cast<__bf16*>(out)[o] = (__bf16)v;
+                        else out[o] = v;
+                    }
                     if (mode & EPI_SUMS) {
                         float t0 = v, t1 = v * v;
                         if (mode & EPI_BNBWD) {
@@ -879,18 +891,23 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(P p) {
     int k0 = p.next_valid(p.k_begin(z));
     if (k0 < kend) { p.load_a(k0, ra); p.load_b(k0, rb); }
 
-    constexpr int A_C4 = A_C / 4, B_C4 = B_C / 4;
+    constexpr int E = P::E;                               // 4: fp32 operands, rounded to bf16 here; 8: bf16 operands, stored as loaded
+    constexpr int A_C4 = A_C / E, B_C4 = B_C / E;
     while (k0 < kend) {
-        // registers -> bf16 -> LDS
+        // registers (-> bf16) -> LDS
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             int q = tid + NTHREADS * j;
-            *reinterpret_cast<bf16x4*>(&As[(q / A_C4) * A_LD + (q % A_C4) * 4]) = __builtin_convertvector(ra[j], bf16x4);
+            u16* d = &As[(q / A_C4) * A_LD + (q % A_C4) * E];
+            if constexpr (E == 4) *reinterpret_cast<bf16x4*>(d) = __builtin_convertvector(ra[j], bf16x4);
+            else *reinterpret_cast<f32x4*>(d) = ra[j];
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             int q = tid + NTHREADS * j;
-            *reinterpret_cast<bf16x4*>(&Bs[(q / B_C4) * B_LD + (q % B_C4) * 4]) = __builtin_convertvector(rb[j], bf16x4);
+            u16* d = &Bs[(q / B_C4) * B_LD + (q % B_C4) * E];
+            if constexpr (E == 4) *reinterpret_cast<bf16x4*>(d) = __builtin_convertvector(rb[j], bf16x4);
+            else *reinterpret_cast<f32x4*>(d) = rb[j];
         }
         __syncthreads();
         const int kn = p.next_valid(k0 + BK);
@@ -1387,7 +1404,7 @@ int make_geom(const mcg_conv_geom* c, Geom& g) {
     g.prec = c->precision;
     if (c->ci_valid < 0 || c->ci_valid > c->Ci) return MCG_ERR_BAD_ARG;
     g.cv = c->ci_valid ? c->ci_valid : c->Ci;
-    if (g.prec != MCG_PREC_F32 && g.prec != MCG_PREC_BF16) return MCG_ERR_BAD_ARG;
+    if (g.prec != MCG_PREC_F32 && g.prec != MCG_PREC_BF16 && g.prec != MCG_PREC_BF16_STORE) return MCG_ERR_BAD_ARG;
     if (c->tile < 0 || c->tile % 100 > 6 || (c->tile / 100) % 10 > 2 || c->tile / 1000 > 2) return MCG_ERR_BAD_ARG;
     g.tile = c->tile % 100; g.bk = ((c->tile / 100) % 10) * 32; g.ksplit = 1 << (c->tile / 1000);
     g.lgHo = ilog2_exact(g.Ho); g.lgWo = ilog2_exact(g.Wo);
@@ -1406,7 +1423,10 @@ int make_geom(const mcg_conv_geom* c, Geom& g) {
     const long long y_elems = (long long)g.N * g.To * g.Ho * g.Wo * g.Co;
     const long long w_elems = (long long)g.Co * g.taps * g.Ci;
     if (x_elems * 4 >= (1ll << 31) || y_elems * 4 >= (1ll << 31) || w_elems * 4 >= (1ll << 31)) return MCG_ERR_UNSUPPORTED;
-    g.x_bytes = (u32)(x_elems * 4); g.y_bytes = (u32)(y_elems * 4); g.w_bytes = (u32)(w_elems * 4);
+    // (buffer extents of the INPUT operands of a pass: 2-byte elements when they are bf16 in memory)
+    const int esz = g.prec == MCG_PREC_BF16_STORE ? 2 : 4;
+    if (esz == 2 && ((g.Ci & 7) || (g.Co & 7))) return MCG_ERR_UNSUPPORTED;       // a 16-byte slot = 8 channels
+    g.x_bytes = (u32)(x_elems * esz); g.y_bytes = (u32)(y_elems * esz); g.w_bytes = (u32)(w_elems * esz);
     g.magic_To = (u32)((1ull << 32) / (unsigned)g.To) + 1u;
     g.magic_N = (u32)((1ull << 32) / (unsigned)g.N) + 1u;
     return MCG_OK;
@@ -1414,9 +1434,12 @@ int make_geom(const mcg_conv_geom* c, Geom& g) {
 
 int launch_status() { return hipGetLastError() == hipSuccess ? MCG_OK : MCG_ERR_LAUNCH; }
 
-template <int BM, int BN, int BK, bool BF = false>
+// PM (precision mode of a launch): 0 = fp32 MFMA; 1 = bf16 MFMA, operands fp32 in memory (rounded in the kernel);
+// 2 = bf16 MFMA, operands bf16 in memory (MCG_PREC_BF16_STORE).  The fused-epilogue classes 2 / 3 exist for PM 0 / 1.
+template <int BM, int BN, int BK, int PM = 0>
 int launch_fprop(const Geom& g, const float* x, const float* w, const float* bias, float* y, const Epi& e, mcg_conv_epilogue* ep, hipStream_t s) {
-    FpropP<BM, BN, BK> p;
+    using Pol = FpropP<BM, BN, BK, PM == 2 ? 8 : 4>;
+    Pol p;
     p.g = g; p.e = e; p.x = x; p.w = w; p.bias = bias; p.y = y;
     p.M = g.N * g.To * g.Ho * g.Wo; p.K = g.taps * g.Ci;
     if (ep) { ep->n_slots = (p.M + BM - 1) / BM; ep->slot_stride = e.slot_stride; }
@@ -1429,20 +1452,28 @@ int launch_fprop(const Geom& g, const float* x, const float* w, const float* bia
     if (splits == 1) p.kchunk = p.K > 0 ? ((p.K + BK - 1) / BK) * BK : BK;
     else if (hipMemsetAsync(y, 0, (size_t)p.M * g.Co * sizeof(float), s) != hipSuccess) return MCG_ERR_LAUNCH;   // the atomics need a cleared y
     dim3 grid((p.M + BM - 1) / BM, (g.Co + BN - 1) / BN, splits);
-    if (e.mode) {
-        const int cls = epi_class(e.mode);
-#define MCG_EPI_LAUNCH(K_) do { if (BF) hipLaunchKernelGGL((gemm_bf16_kernel<FpropP<BM, BN, BK>, BM, BN, BK, K_>), grid, dim3(NTHREADS), 0, s, p); \
-                                else hipLaunchKernelGGL((gemm_kernel<FpropP<BM, BN, BK>, BM, BN, BK, K_>), grid, dim3(NTHREADS), 0, s, p); } while (0)
-        if (cls == 1) MCG_EPI_LAUNCH(1); else if (cls == 2) MCG_EPI_LAUNCH(2); else MCG_EPI_LAUNCH(3);
-#undef MCG_EPI_LAUNCH
-    } else if (BF) hipLaunchKernelGGL((gemm_bf16_kernel<FpropP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
-    else hipLaunchKernelGGL((gemm_kernel<FpropP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
+    const int cls = e.mode ? epi_class(e.mode) : 0;
+    if (PM == 2 && cls > 1) return MCG_ERR_UNSUPPORTED;
+    if constexpr (PM == 0) {
+        if (cls == 0) hipLaunchKernelGGL((gemm_kernel<Pol, BM, BN, BK, 0>), grid, dim3(NTHREADS), 0, s, p);
+        else if (cls == 1) hipLaunchKernelGGL((gemm_kernel<Pol, BM, BN, BK, 1>), grid, dim3(NTHREADS), 0, s, p);
+        else if (cls == 2) hipLaunchKernelGGL((gemm_kernel<Pol, BM, BN, BK, 2>), grid, dim3(NTHREADS), 0, s, p);
+        else hipLaunchKernelGGL((gemm_kernel<Pol, BM, BN, BK, 3>), grid, dim3(NTHREADS), 0, s, p);
+    } else {
+        if (cls == 0) hipLaunchKernelGGL((gemm_bf16_kernel<Pol, BM, BN, BK, 0>), grid, dim3(NTHREADS), 0, s, p);
+        else if (cls == 1) hipLaunchKernelGGL((gemm_bf16_kernel<Pol, BM, BN, BK, 1>), grid, dim3(NTHREADS), 0, s, p);
+        else if constexpr (PM == 1) {
+            if (cls == 2) hipLaunchKernelGGL((gemm_bf16_kernel<Pol, BM, BN, BK, 2>), grid, dim3(NTHREADS), 0, s, p);
+            else hipLaunchKernelGGL((gemm_bf16_kernel<Pol, BM, BN, BK, 3>), grid, dim3(NTHREADS), 0, s, p);
+        }
+    }
     return MCG_OK;
 }
 
-template <int BM, int BN, int BK, bool BF = false>
+template <int BM, int BN, int BK, int PM = 0>
 int launch_dgrad(const Geom& g, const float* y, const float* w, const float* bias, float* x, int act, int acc, const Epi& e, mcg_conv_epilogue* ep, hipStream_t s) {
-    DgradP<BM, BN, BK> p;
+    using Pol = DgradP<BM, BN, BK, PM == 2 ? 8 : 4>;
+    Pol p;
     p.g = g; p.e = e; p.y = y; p.w = w; p.bias = bias; p.x = x; p.act = act; p.accumulate = acc;
     p.M = g.N * g.Ti * g.Ho * g.Wo; p.K = g.kt * 4 * g.Co;
     if (ep) { ep->n_slots = 4 * ((p.M + BM - 1) / BM); ep->slot_stride = e.slot_stride; }
@@ -1461,20 +1492,24 @@ int launch_dgrad(const Geom& g, const float* y, const float* w, const float* bia
 #else
     dim3 grid(p.gxm, p.gyn, 4 * splits);
 #endif
-    if (e.mode) {
-        const int cls = epi_class(e.mode);
-#define MCG_EPI_LAUNCH(K_) do { if (BF) hipLaunchKernelGGL((gemm_bf16_kernel<DgradP<BM, BN, BK>, BM, BN, BK, K_>), grid, dim3(NTHREADS), 0, s, p); \
-                                else hipLaunchKernelGGL((gemm_kernel<DgradP<BM, BN, BK>, BM, BN, BK, K_>), grid, dim3(NTHREADS), 0, s, p); } while (0)
-        if (cls == 1) MCG_EPI_LAUNCH(1); else MCG_EPI_LAUNCH(2);          // (class 3 is fprop only: make_epi)
-#undef MCG_EPI_LAUNCH
-    } else if (BF) hipLaunchKernelGGL((gemm_bf16_kernel<DgradP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
-    else hipLaunchKernelGGL((gemm_kernel<DgradP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
+    const int cls = e.mode ? epi_class(e.mode) : 0;                      // (class 3 is fprop only: make_epi)
+    if (PM == 2 && cls > 1) return MCG_ERR_UNSUPPORTED;
+    if constexpr (PM == 0) {
+        if (cls == 0) hipLaunchKernelGGL((gemm_kernel<Pol, BM, BN, BK, 0>), grid, dim3(NTHREADS), 0, s, p);
+        else if (cls == 1) hipLaunchKernelGGL((gemm_kernel<Pol, BM, BN, BK, 1>), grid, dim3(NTHREADS), 0, s, p);
+        else hipLaunchKernelGGL((gemm_kernel<Pol, BM, BN, BK, 2>), grid, dim3(NTHREADS), 0, s, p);
+    } else {
+        if (cls == 0) hipLaunchKernelGGL((gemm_bf16_kernel<Pol, BM, BN, BK, 0>), grid, dim3(NTHREADS), 0, s, p);
+        else if (cls == 1) hipLaunchKernelGGL((gemm_bf16_kernel<Pol, BM, BN, BK, 1>), grid, dim3(NTHREADS), 0, s, p);
+        else if constexpr (PM == 1) hipLaunchKernelGGL((gemm_bf16_kernel<Pol, BM, BN, BK, 2>), grid, dim3(NTHREADS), 0, s, p);
+    }
     return MCG_OK;
 }
 
-template <int BM, int BN, int BK, bool BF = false>
+template <int BM, int BN, int BK, int PM = 0>
 int launch_wgrad(const Geom& g, const float* x, const float* y, float* dw, hipStream_t s) {
-    WgradP<BM, BN, BK> p;
+    using Pol = WgradP<BM, BN, BK, PM == 2 ? 8 : 4>;
+    Pol p;
     p.g = g; p.x = x; p.y = y; p.dw = dw;
     p.Mpix = g.N * g.To * g.Ho * g.Wo; p.Kf = g.taps * g.Ci;
     int tiles = ((g.Co + BM - 1) / BM) * ((p.Kf + BN - 1) / BN);
@@ -1488,14 +1523,14 @@ int launch_wgrad(const Geom& g, const float* x, const float* y, float* dw, hipSt
     p.chunk = steps_per * BK;
     splits = (p.Mpix + p.chunk - 1) / p.chunk;
     dim3 grid((g.Co + BM - 1) / BM, (p.Kf + BN - 1) / BN, splits);
-    if (BF) hipLaunchKernelGGL((gemm_bf16_kernel<WgradP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
-    else hipLaunchKernelGGL((gemm_kernel<WgradP<BM, BN, BK>, BM, BN, BK>), grid, dim3(NTHREADS), 0, s, p);
+    if constexpr (PM == 0) hipLaunchKernelGGL((gemm_kernel<Pol, BM, BN, BK, 0>), grid, dim3(NTHREADS), 0, s, p);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<Pol, BM, BN, BK, 0>), grid, dim3(NTHREADS), 0, s, p);
     return MCG_OK;
 }
 
 // tile / K-depth / MFMA-type dispatch of the launch_* templates
 #ifdef MCG_FAST_BUILD       // compile-time experiments: one tile, one K depth, fp32 only
-#define MCG_TILES(fn, t, BK, BF, ...) do { st = fn<128, 128, 32, false>(__VA_ARGS__); } while (0)
+#define MCG_TILES(fn, t, BK, BF, ...) do { st = fn<128, 128, 32, 0>(__VA_ARGS__); } while (0)
 #else
 #define MCG_TILES(fn, t, BK, BF, ...)                                   \
     do {                                                                \
@@ -1506,10 +1541,11 @@ int launch_wgrad(const Geom& g, const float* x, const float* y, float* dw, hipSt
         else st = fn<64, 64, BK, BF>(__VA_ARGS__);                      \
     } while (0)
 #endif
-#define MCG_DISPATCH(fn, t, bk64, bf, ...)                              \
+#define MCG_DISPATCH(fn, t, bk64, pm, ...)                              \
     do {                                                                \
-        if (bf) { if (bk64) MCG_TILES(fn, t, 64, true, __VA_ARGS__); else MCG_TILES(fn, t, 32, true, __VA_ARGS__); }      \
-        else    { if (bk64) MCG_TILES(fn, t, 64, false, __VA_ARGS__); else MCG_TILES(fn, t, 32, false, __VA_ARGS__); }    \
+        if ((pm) == 2)      { if (bk64) MCG_TILES(fn, t, 64, 2, __VA_ARGS__); else MCG_TILES(fn, t, 32, 2, __VA_ARGS__); }      \
+        else if ((pm) == 1) { if (bk64) MCG_TILES(fn, t, 64, 1, __VA_ARGS__); else MCG_TILES(fn, t, 32, 1, __VA_ARGS__); }      \
+        else                { if (bk64) MCG_TILES(fn, t, 64, 0, __VA_ARGS__); else MCG_TILES(fn, t, 32, 0, __VA_ARGS__); }      \
     } while (0)
 
 // a launch status that also reports a failed clear of a split-K output (st) -- the atomics would otherwise add onto stale data
@@ -1558,7 +1594,8 @@ int make_epi(const mcg_conv_epilogue* ep, const Geom& g, int pass, Epi& e) {
         e.addend[0] = ep->addend[0]; e.addend[1] = ep->addend[1];
         e.sigma = ep->sigma; e.seed = ep->seed; e.stream[0] = ep->stream_id[0]; e.stream[1] = ep->stream_id[1];
         e.mask_out = ep->mask_out;
-    } else if (ep->mask_out) return MCG_ERR_BAD_ARG;
+        e.out16 = ep->out_bf16 ? 1 : 0;
+    } else if (ep->mask_out || ep->out_bf16) return MCG_ERR_BAD_ARG;
     if (ep->mask_in) {
         if (pass != 1) return MCG_ERR_UNSUPPORTED;
         e.mode |= EPI_MASKMUL; e.mask_in = ep->mask_in;
@@ -1599,8 +1636,8 @@ int conv_fprop_impl(const mcg_conv_geom* c, const float* x, const float* w, cons
     // 64-deep K-steps halve the per-step overhead (barriers, LDS refill, address math) and pay off when the
     // grid is small (few resident waves to hide it: measured on dc4); big grids prefer the higher occupancy of 32.
     const long long nblk = ((M + (t == 3 ? 63 : 127)) / (t == 3 ? 64 : 128)) * ((g.Co + (t == 1 ? 127 : 63)) / (t == 1 ? 128 : 64));
-    const bool bk64 = (g.taps * g.Ci) % 64 == 0 && (bk ? bk == 64 : (nblk < 1024 || g.prec == MCG_PREC_BF16));
-    MCG_DISPATCH(launch_fprop, t, bk64, g.prec == MCG_PREC_BF16, g, x, w, bias, y, e, ep, s);
+    const bool bk64 = (g.taps * g.Ci) % 64 == 0 && (bk ? bk == 64 : (nblk < 1024 || g.prec != MCG_PREC_F32));
+    MCG_DISPATCH(launch_fprop, t, bk64, g.prec, g, x, w, bias, y, e, ep, s);
     return finish(st);
 }
 #endif
@@ -1659,7 +1696,7 @@ int conv_dgrad_impl(const mcg_conv_geom* c, const float* y, const float* w, cons
     long long M = (long long)g.N * g.Ti * g.Ho * g.Wo;
     int t = g.tile;
     const int bk = g.bk;
-    if ((t == 0 || t == 6) && g.prec == MCG_PREC_F32 && c4_dgrad_mfma_ok(g, e, bias, act, accumulate)) {
+    if ((t == 0 || t == 6) && g.prec != MCG_PREC_BF16_STORE && c4_dgrad_mfma_ok(g, e, bias, act, accumulate)) {      // (computes in fp32)
         if (g.kt == 4) st = g.Wo == 32 ? launch_dgrad_c4_mfma<4, 32>(g, y, w, x, s) : launch_dgrad_c4_mfma<4, 16>(g, y, w, x, s);
         else st = g.Wo == 32 ? launch_dgrad_c4_mfma<1, 32>(g, y, w, x, s) : launch_dgrad_c4_mfma<1, 16>(g, y, w, x, s);
         return finish(st);
@@ -1686,8 +1723,8 @@ int conv_dgrad_impl(const mcg_conv_geom* c, const float* y, const float* w, cons
         else t = g.Ci <= 64 ? 2 : (4 * mt * ((g.Ci + 127) / 128) >= 1024 ? 1 : 2);
     }
     const long long nblk = 4 * ((M + (t == 3 ? 63 : 127)) / (t == 3 ? 64 : 128)) * ((g.Ci + (t == 1 ? 127 : 63)) / (t == 1 ? 128 : 64));
-    const bool bk64 = (g.kt * 4 * g.Co) % 64 == 0 && (bk ? bk == 64 : (nblk < 1024 || g.prec == MCG_PREC_BF16));
-    MCG_DISPATCH(launch_dgrad, t, bk64, g.prec == MCG_PREC_BF16, g, y, w, bias, x, act, accumulate, e, ep, s);
+    const bool bk64 = (g.kt * 4 * g.Co) % 64 == 0 && (bk ? bk == 64 : (nblk < 1024 || g.prec != MCG_PREC_F32));
+    MCG_DISPATCH(launch_dgrad, t, bk64, g.prec, g, y, w, bias, x, act, accumulate, e, ep, s);
     return finish(st);
 }
 
@@ -1705,8 +1742,8 @@ extern "C" int mcg_conv_wgrad(const mcg_conv_geom* c, const float* x, const floa
     int t = g.tile;
     const int bk = g.bk;
     if (!t) t = (g.Co <= 64 || Kf <= 64) ? 3 : 1;
-    const bool bk64 = bk ? bk == 64 : g.prec == MCG_PREC_BF16;
-    MCG_DISPATCH(launch_wgrad, t, bk64, g.prec == MCG_PREC_BF16, g, x, y, dw, s);
+    const bool bk64 = bk ? bk == 64 : g.prec != MCG_PREC_F32;
+    MCG_DISPATCH(launch_wgrad, t, bk64, g.prec, g, x, y, dw, s);
     return finish(st);
 }
 

@@ -18,6 +18,14 @@ int launch_status() { return hipGetLastError() == hipSuccess ? MCG_OK : MCG_ERR_
 
 using mcg::randn4;
 
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+// element i4 (a group of 4) of a tensor that is fp32 or (out16) bf16 in memory: MCG_PREC_BF16_STORE networks keep the
+// GEMM operands -- activations and output gradients -- in bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32)
+__device__ __forceinline__ void store4(float* out, long long i4, f32x4 v, int out16) {
+    if (out16) reinterpret_cast<bf16x4_t*>(out)[i4] = __builtin_convertvector(v, bf16x4_t);
+    else reinterpret_cast<f32x4*>(out)[i4] = v;
+}
+
 __device__ __forceinline__ float act_fwd(float v, int act) {
     if (act == MCG_ACT_RELU) return fmaxf(v, 0.f);
     if (act == MCG_ACT_LRELU) return v >= 0.f ? v : v * LRELU_SLOPE;
@@ -230,7 +238,7 @@ __global__ __launch_bounds__(NT) void bn_act_fwd_kernel(long long n4, int C, int
                                                         long long item4, long long item_stride,
                                                         const float* __restrict__ ss, int act,
                                                         const float* __restrict__ addend, float sigma,
-                                                        uint64_t seed, uint64_t stream_id, float* __restrict__ out) {
+                                                        uint64_t seed, uint64_t stream_id, float* __restrict__ out, int out16) {
     const int C4 = C >> 2;
     for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long long)gridDim.x * NT) {
         int c4 = (int)(i % C4);
@@ -252,14 +260,14 @@ __global__ __launch_bounds__(NT) void bn_act_fwd_kernel(long long n4, int C, int
 #pragma unroll
             for (int k = 0; k < 4; ++k) if (c4 * 4 + k < c_valid) v[k] = fmaf(sigma, z[k], v[k]);
         }
-        *reinterpret_cast<f32x4*>(out + i * 4) = v;
+        store4(out, i, v, out16);
     }
 }
 
 // gx = coef0 * (g*mask - x_hat*coef1 - coef2)    (BN)   or   gx = g*mask(y) / g*(1-y^2)  (no BN)
 __global__ __launch_bounds__(NT) void bn_act_bwd_apply_kernel(long long n4, int C, const float* __restrict__ g,
                                                               const float* __restrict__ y, const float* __restrict__ stats,
-                                                              const float* __restrict__ coef, int act, float* __restrict__ gx) {
+                                                              const float* __restrict__ coef, int act, float* __restrict__ gx, int out16) {
     const int C4 = C >> 2;
     for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long long)gridDim.x * NT) {
         int c4 = (int)(i % C4);
@@ -285,7 +293,7 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_apply_kernel(long long n4, int 
             for (int k = 0; k < 4; ++k)
                 o[k] = act == MCG_ACT_TANH ? gv[k] * (1.f - yv[k] * yv[k]) : gv[k] * act_mask(yv[k], act);
         }
-        *reinterpret_cast<f32x4*>(gx + i * 4) = o;
+        store4(gx, i, o, out16);
     }
 }
 
@@ -652,7 +660,7 @@ __global__ __launch_bounds__(NT) void loss_gen_kernel(int N, int C, const float*
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void adam_wd_kernel(long long n, float* __restrict__ p, const float* __restrict__ g,
                                                      float* __restrict__ m, float* __restrict__ v, float lr, float b1c,
-                                                     float b2c, float eps, float wd, float gscale) {
+                                                     float b2c, float eps, float wd, float gscale, __bf16* __restrict__ p16) {
     for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n; i += (long long)gridDim.x * NT) {
         float pv = p[i];
         float gg = g[i] * gscale + wd * pv;      // gscale = 1 / world: the all-reduced SUM becomes the mean here (x 1.0f is exact)
@@ -660,7 +668,9 @@ __global__ __launch_bounds__(NT) void adam_wd_kernel(long long n, float* __restr
         mv += b1c * (gg - mv);
         vv += b2c * (gg * gg - vv);
         m[i] = mv; v[i] = vv;
-        p[i] = pv - lr * mv / (sqrtf(vv) + eps);
+        pv -= lr * mv / (sqrtf(vv) + eps);
+        p[i] = pv;
+        if (p16) p16[i] = (__bf16)pv;             // the GEMMs' bf16 copy of the master weights (MCG_PREC_BF16_STORE)
     }
 }
 
@@ -739,19 +749,20 @@ extern "C" int mcg_bn_stats_from_partials(int64_t M, int C, const float* part, i
 
 extern "C" int mcg_bn_act_fwd(int64_t M, int C, int c_valid, const float* y, int64_t y_rows_per_item, int64_t y_item_stride,
                               const float* scale_shift, int act, const float* addend,
-                              float sigma, uint64_t seed, uint64_t stream_id, float* out, void* stream) {
+                              float sigma, uint64_t seed, uint64_t stream_id, void* out, int out_bf16, void* stream) {
     if (!y || !out || M <= 0 || C <= 0 || (C & 3)) return MCG_ERR_BAD_ARG;
     if (y_rows_per_item < 0 || (y_rows_per_item > 0 && (M % y_rows_per_item || (y_item_stride & 3)))) return MCG_ERR_BAD_ARG;
     long long n4 = (long long)M * (C >> 2);
     hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(n4)), dim3(NT), 0, (hipStream_t)stream, n4, C, c_valid, y,
                        (long long)y_rows_per_item * (C >> 2), (long long)y_item_stride, scale_shift, act,
-                       addend, sigma, seed, stream_id, out);
+                       addend, sigma, seed, stream_id, (float*)out, out_bf16);
     return launch_status();
 }
 
 extern "C" int mcg_bn_act_bwd(int64_t M, int C, const float* g_out, const float* y, const float* stats, const float* gamma, int act,
-                              float* gx, float* dgamma, float* dbeta, void* workspace, void* stream) {
+                              void* gx, int gx_bf16, float* dgamma, float* dbeta, void* workspace, void* stream) {
     if (!g_out || !y || !gx || M <= 0 || C <= 0 || (C & 3)) return MCG_ERR_BAD_ARG;
+    if (gx_bf16 && gx == (const void*)g_out) return MCG_ERR_BAD_ARG;            // a bf16 result cannot overwrite its fp32 input
     hipStream_t s = (hipStream_t)stream;
     long long n4 = (long long)M * (C >> 2);
     float* coef = nullptr;
@@ -765,21 +776,22 @@ extern "C" int mcg_bn_act_bwd(int64_t M, int C, const float* g_out, const float*
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, pl.blocks, C, 1.0 / (double)M, part, stats, gamma,
                            coef, dgamma, dbeta, 0LL);
     }
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(NT), 0, s, n4, C, g_out, y, stats, coef, act, gx);
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(NT), 0, s, n4, C, g_out, y, stats, coef, act, (float*)gx, gx_bf16);
     return launch_status();
 }
 
 extern "C" int mcg_bn_act_bwd_from_partials(int64_t M, int C, const float* g_out, const float* y, const float* stats, const float* gamma, int act,
-                                            const float* part, int n_slots, int slot_stride, float* gx, float* dgamma, float* dbeta,
+                                            const float* part, int n_slots, int slot_stride, void* gx, int gx_bf16, float* dgamma, float* dbeta,
                                             void* workspace, void* stream) {
     if (!g_out || !y || !gx || !stats || !gamma || !part || !workspace || M <= 0 || bad_c(C) || n_slots <= 0 || slot_stride < 2 * C) return MCG_ERR_BAD_ARG;
+    if (gx_bf16 && gx == (const void*)g_out) return MCG_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     float* coef = (float*)workspace + (long long)MAX_PART * 2 * C;
     const Folded f = fold_slots(part, n_slots, slot_stride, C, (float*)workspace, s);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, f.n, C, 1.0 / (double)M, f.part, stats, gamma,
                        coef, dgamma, dbeta, f.stride);
     long long n4 = (long long)M * (C >> 2);
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(NT), 0, s, n4, C, g_out, y, stats, coef, act, gx);
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(NT), 0, s, n4, C, g_out, y, stats, coef, act, (float*)gx, gx_bf16);
     return launch_status();
 }
 
@@ -832,7 +844,7 @@ extern "C" int mcg_bn_act_bwd_from_sums(int64_t M, int64_t M_total, int C, const
     hipLaunchKernelGGL(bn_bwd_from_sums_kernel, dim3((C + 63) / 64), dim3(64), 0, s, C, 1.0 / (double)M_total, local_sums, global_sums, stats, gamma,
                        coef, dgamma, dbeta);
     long long n4 = (long long)M * (C >> 2);
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(NT), 0, s, n4, C, g_out, y, stats, coef, act, gx);
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(NT), 0, s, n4, C, g_out, y, stats, coef, act, gx, 0);
     return launch_status();
 }
 
@@ -938,11 +950,11 @@ extern "C" int mcg_loss_gen(int N, int C, const float* y_fake_i, const float* y_
 }
 
 extern "C" int mcg_adam_wd(int64_t n, float* p, const float* g, float* m, float* v, double lr_t, double beta1, double beta2, double eps,
-                           double wd, double grad_scale, void* stream) {
+                           double wd, double grad_scale, uint16_t* p_bf16, void* stream) {
     if (!p || !g || !m || !v || n <= 0) return MCG_ERR_BAD_ARG;
     // hyper-parameters arrive as doubles so that (1 - beta) is rounded to fp32 once, like Chainer's python-float arithmetic
     hipLaunchKernelGGL(adam_wd_kernel, dim3(ew_grid(n)), dim3(NT), 0, (hipStream_t)stream, (long long)n, p, g, m, v, (float)lr_t,
-                       (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)wd, (float)grad_scale);
+                       (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)wd, (float)grad_scale, (__bf16*)p_bf16);
     return launch_status();
 }
 

@@ -39,7 +39,8 @@ class ConvEpilogue(C.Structure):
     _fields_ = [("sums", C.c_int32), ("groups", C.c_int32), ("part", C.c_void_p), ("bn_y", C.c_void_p),
                 ("bn_stats", C.c_void_p * 2), ("bn_act", C.c_int32), ("act", C.c_int32), ("addend", C.c_void_p * 2),
                 ("sigma", C.c_float), ("seed", C.c_uint64), ("stream_id", C.c_uint64 * 2),
-                ("mask_out", C.c_void_p), ("mask_in", C.c_void_p), ("n_slots", C.c_int32), ("slot_stride", C.c_int32)]
+                ("mask_out", C.c_void_p), ("out_bf16", C.c_int32), ("mask_in", C.c_void_p), ("n_slots", C.c_int32),
+                ("slot_stride", C.c_int32)]
 
 
 _P, _I, _I64, _U64, _F, _D = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double
@@ -56,7 +57,7 @@ SIGNATURES = {
     "mcg_conv_dgrad_ex": (_I, [_GP, _P, _P, _P, _P, _EP, _P]),
     "mcg_conv_epilogue_part_bytes": (_I64, [_GP, _I, _I]),
     "mcg_bn_stats_from_partials": (_I, [_I64, _I, _P, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P]),
-    "mcg_bn_act_bwd_from_partials": (_I, [_I64, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "mcg_bn_act_bwd_from_partials": (_I, [_I64, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P, _I, _P, _P, _P, _P]),
     "mcg_colsum_from_partials": (_I, [_I, _P, _I, _I, _P, _P, _P]),
     "mcg_randn_rowquad": (_I, [_I64, _I, _F, _U64, _U64, _P, _P]),
     "mcg_fc_fprop": (_I, [_I, _I, _I, _P, _P, _P, _P, _P]),
@@ -64,8 +65,8 @@ SIGNATURES = {
     "mcg_fc_wgrad": (_I, [_I, _I, _I, _P, _P, _P, _P, _P]),
     "mcg_bn_workspace_bytes": (_I64, [_I64, _I]),
     "mcg_bn_stats": (_I, [_I64, _I, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P]),
-    "mcg_bn_act_fwd": (_I, [_I64, _I, _I, _P, _I64, _I64, _P, _I, _P, _F, _U64, _U64, _P, _P]),
-    "mcg_bn_act_bwd": (_I, [_I64, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
+    "mcg_bn_act_fwd": (_I, [_I64, _I, _I, _P, _I64, _I64, _P, _I, _P, _F, _U64, _U64, _P, _I, _P]),
+    "mcg_bn_act_bwd": (_I, [_I64, _I, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P]),
     "mcg_bn_sums": (_I, [_I64, _I, _P, _P, _P, _P]),
     "mcg_bn_stats_from_sums": (_I, [_I64, _I, _P, _P, _P, _P, _P, _P, _F, _F, _P]),
     "mcg_bn_bwd_sums": (_I, [_I64, _I, _P, _P, _P, _I, _P, _P, _P]),
@@ -78,7 +79,7 @@ SIGNATURES = {
     "mcg_gru_seq_bwd": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "mcg_loss_dis": (_I, [_I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
     "mcg_loss_gen": (_I, [_I, _I, _P, _P, _P, _I, _P, _P, _P, _P]),
-    "mcg_adam_wd": (_I, [_I64, _P, _P, _P, _P, _D, _D, _D, _D, _D, _D, _P]),
+    "mcg_adam_wd": (_I, [_I64, _P, _P, _P, _P, _D, _D, _D, _D, _D, _D, _P, _P]),
     "mcg_randn": (_I, [_I64, _F, _U64, _U64, _P, _P]),
 }
 
@@ -152,8 +153,22 @@ def _dense(t):
     return t
 
 
-PREC_F32, PREC_BF16 = 0, 1
-PRECISIONS = {"f32": PREC_F32, "fp32": PREC_F32, "bf16": PREC_BF16, PREC_F32: PREC_F32, PREC_BF16: PREC_BF16}
+PREC_F32, PREC_BF16, PREC_BF16_STORE = 0, 1, 2
+# 'bf16': bf16 MFMA on fp32 tensors (rounded in the kernel); 'bf16s': bf16 MFMA on operands that are bf16 in memory
+PRECISIONS = {"f32": PREC_F32, "fp32": PREC_F32, "bf16": PREC_BF16, "bf16s": PREC_BF16_STORE,
+              PREC_F32: PREC_F32, PREC_BF16: PREC_BF16, PREC_BF16_STORE: PREC_BF16_STORE}
+
+
+def _pin(g, t):
+    """device pointer of an INPUT operand of a conv launch: bf16 tensors for MCG_PREC_BF16_STORE geometries"""
+    return _p(t, torch.bfloat16 if g.precision == PREC_BF16_STORE else torch.float32)
+
+
+def _pany(t):
+    """device pointer of a tensor that may be fp32 or bf16 (outputs of the element-wise passes) -> (pointer, is_bf16)"""
+    if t.dtype == torch.bfloat16:
+        return _p(t, torch.bfloat16), 1
+    return _p(t), 0
 
 
 def make_geom(N, Ti, Hi, Wi, Ci, Co, kt, x_stride0=None, x_perm_n=0, x_stride1=0, precision=PREC_F32, ci_valid=0):
@@ -331,18 +346,18 @@ def _scratch_like(g, which):
 # ------------------------------------------------------------------------------------------
 def _fprop(g, x, w, bias, y):
     g = _with_override(g)
-    _check(load().mcg_conv_fprop(C.byref(g), _p(x), _p(_dense(w)), _p(bias), _p(_dense(y)), _stream()), "mcg_conv_fprop")
+    _check(load().mcg_conv_fprop(C.byref(g), _pin(g, x), _pin(g, _dense(w)), _p(bias), _p(_dense(y)), _stream()), "mcg_conv_fprop")
 
 
 def _dgrad(g, y, w, bias, x, act, accumulate):
     g = _with_override(g)
-    _check(load().mcg_conv_dgrad(C.byref(g), _p(_dense(y)), _p(_dense(w)), _p(bias), _p(x), act, int(accumulate), _stream()),
+    _check(load().mcg_conv_dgrad(C.byref(g), _pin(g, _dense(y)), _pin(g, _dense(w)), _p(bias), _p(x), act, int(accumulate), _stream()),
            "mcg_conv_dgrad")
 
 
 def _wgrad(g, x, y, dw):
     g = _with_override(g)
-    _check(load().mcg_conv_wgrad(C.byref(g), _p(x), _p(_dense(y)), _p(_dense(dw)), _stream()), "mcg_conv_wgrad")
+    _check(load().mcg_conv_wgrad(C.byref(g), _pin(g, x), _pin(g, _dense(y)), _p(_dense(dw)), _stream()), "mcg_conv_wgrad")
 
 
 # ---- fused epilogues (mcg_conv_epilogue) ---------------------------------------------------------
@@ -353,7 +368,7 @@ def _vp(t, dtype=torch.float32):
 
 
 def epilogue(sums=SUMS_NONE, groups=1, part=None, bn_y=None, bn_stats=(None, None), bn_act=ACT_NONE, act=ACT_NONE,
-             addend=(None, None), sigma=0.0, seed=0, stream_id=(0, 0), mask_out=None, mask_in=None):
+             addend=(None, None), sigma=0.0, seed=0, stream_id=(0, 0), mask_out=None, mask_in=None, out_bf16=False):
     """Builds a ConvEpilogue; the tensors must stay alive until the launch has been queued (they are the caller's)."""
     ep = ConvEpilogue()
     ep.sums, ep.groups, ep.part, ep.bn_y = sums, groups, _vp(part), _vp(_dense(bn_y))
@@ -363,6 +378,7 @@ def epilogue(sums=SUMS_NONE, groups=1, part=None, bn_y=None, bn_stats=(None, Non
     ep.sigma, ep.seed = float(sigma), int(seed)
     ep.stream_id[0], ep.stream_id[1] = int(stream_id[0]), int(stream_id[1] if len(stream_id) > 1 else 0)
     ep.mask_out, ep.mask_in = _vp(_dense(mask_out), torch.int32), _vp(_dense(mask_in), torch.int32)
+    ep.out_bf16 = int(bool(out_bf16))
     return ep
 
 
@@ -382,12 +398,13 @@ def _no_split(g):
 
 def _fprop_ex(g, x, w, bias, y, ep):
     g = _no_split(_with_override(g))
-    _check(load().mcg_conv_fprop_ex(C.byref(g), _p(x), _p(_dense(w)), _p(bias), _p(_dense(y)), C.byref(ep), _stream()), "mcg_conv_fprop_ex")
+    yp = _p(_dense(y), torch.bfloat16) if ep.out_bf16 else _p(_dense(y))
+    _check(load().mcg_conv_fprop_ex(C.byref(g), _pin(g, x), _pin(g, _dense(w)), _p(bias), yp, C.byref(ep), _stream()), "mcg_conv_fprop_ex")
 
 
 def _dgrad_ex(g, y, w, bias, x, ep):
     g = _no_split(_with_override(g))
-    _check(load().mcg_conv_dgrad_ex(C.byref(g), _p(_dense(y)), _p(_dense(w)), _p(bias), _p(_dense(x)), C.byref(ep), _stream()),
+    _check(load().mcg_conv_dgrad_ex(C.byref(g), _pin(g, _dense(y)), _pin(g, _dense(w)), _p(bias), _p(_dense(x)), C.byref(ep), _stream()),
            "mcg_conv_dgrad_ex")
 
 
@@ -457,13 +474,15 @@ def bn_act_fwd(M, Cn, y, scale_shift, act, out, addend=None, sigma=0.0, seed=0, 
     """y dense [M][Cn], or (rows_per_item > 0) a view whose items are item_stride elements apart."""
     if rows_per_item == 0:
         _dense(y)
+    op, o16 = _pany(_dense(out))
     _check(load().mcg_bn_act_fwd(M, Cn, Cn if c_valid is None else c_valid, _p(y), rows_per_item, item_stride, _p(scale_shift), act,
-                                 _p(_dense(addend)), sigma, seed, stream_id, _p(_dense(out)), _stream()), "mcg_bn_act_fwd")
+                                 _p(_dense(addend)), sigma, seed, stream_id, op, o16, _stream()), "mcg_bn_act_fwd")
 
 
 def bn_act_bwd(M, Cn, g_out, y, stats, gamma, act, gx, dgamma, dbeta, ws, sync=None):
     if sync is None or sync.world == 1 or stats is None:
-        _check(load().mcg_bn_act_bwd(M, Cn, _p(_dense(g_out)), _p(_dense(y)), _p(stats), _p(gamma), act, _p(_dense(gx)),
+        gp, g16 = _pany(_dense(gx))
+        _check(load().mcg_bn_act_bwd(M, Cn, _p(_dense(g_out)), _p(_dense(y)), _p(stats), _p(gamma), act, gp, g16,
                                      _p(dgamma), _p(dbeta), _p(ws), _stream()), "mcg_bn_act_bwd")
         return
     local = torch.empty(2 * Cn, dtype=torch.float64, device=y.device)
@@ -483,8 +502,9 @@ def bn_stats_from_partials(M, Cn, part, n_slots, slot_stride, gamma, beta, stats
 
 
 def bn_act_bwd_from_partials(M, Cn, g_out, y, stats, gamma, act, part, n_slots, slot_stride, gx, dgamma, dbeta, ws):
+    gp, g16 = _pany(_dense(gx))
     _check(load().mcg_bn_act_bwd_from_partials(M, Cn, _p(_dense(g_out)), _p(_dense(y)), _p(stats), _p(gamma), act, _p(part), n_slots,
-                                               slot_stride, _p(_dense(gx)), _p(dgamma), _p(dbeta), _p(ws), _stream()),
+                                               slot_stride, gp, g16, _p(dgamma), _p(dbeta), _p(ws), _stream()),
            "mcg_bn_act_bwd_from_partials")
 
 
@@ -538,9 +558,10 @@ def loss_gen(N, Cn, y_i, y_v, t_fake, with_ce, loss_out, g_i, g_v):
                                _p(_dense(g_i)), _p(_dense(g_v)), _stream()), "mcg_loss_gen")
 
 
-def adam_wd(p, g, m, v, lr_t, beta1, beta2, eps, wd, grad_scale=1.0):
+def adam_wd(p, g, m, v, lr_t, beta1, beta2, eps, wd, grad_scale=1.0, p16=None):
+    """p16: optional bf16 buffer of p's size that receives a copy of the updated parameters"""
     _check(load().mcg_adam_wd(p.numel(), _p(_dense(p)), _p(_dense(g)), _p(_dense(m)), _p(_dense(v)), lr_t, beta1, beta2, eps, wd,
-                              grad_scale, _stream()), "mcg_adam_wd")
+                              grad_scale, _p(_dense(p16), torch.bfloat16), _stream()), "mcg_adam_wd")
 
 
 def randn(out, sigma, seed, stream_id):

@@ -57,6 +57,7 @@ class FlatParams:
         self.g = torch.zeros_like(self.p)
         self.m = torch.zeros_like(self.p)
         self.v = torch.zeros_like(self.p)
+        self.p16 = None                 # bf16 copy of p (same offsets): the weight operand of the bf16-storage GEMMs
 
     def _view(self, buf, name):
         o, s = self.offsets[name], self.shapes[name]
@@ -64,6 +65,15 @@ class FlatParams:
 
     def param(self, name):
         return self._view(self.p, name)
+
+    def param16(self, name):
+        return self._view(self.p16, name)
+
+    def refresh16(self):
+        """(re)build the bf16 copy from the fp32 master parameters; afterwards the Adam kernel keeps it current"""
+        if self.p16 is None:
+            self.p16 = torch.empty(self.size, dtype=torch.bfloat16, device=self.p.device)
+        self.p16.copy_(self.p)
 
     def grad(self, name):
         return self._view(self.g, name)
@@ -87,10 +97,27 @@ class _Net:
     # backward passes below leave that gradient at its exact value 0 instead of reducing gx again.
     BIAS_NOTE = "pre-BatchNorm bias gradients are exactly zero"
 
-    # MFMA operand type of this network's convolution GEMMs: 'f32' (default, the parity configuration) or
-    # 'bf16' (operands rounded to bf16 in-kernel, fp32 accumulation; parameters, activations, BN statistics
-    # and Adam stay fp32).  BASELINE.json configs[2].
+    # MFMA operand type of this network's convolution GEMMs: 'f32' (default, the parity configuration) or 'bf16'
+    # (BASELINE.json configs[2]): bf16 MFMA with fp32 accumulation; master parameters, BatchNorm statistics, Adam and
+    # every GEMM OUTPUT stay fp32, while the tensors that are only ever read as GEMM operands -- the activations behind
+    # BatchNorm / the activation function, the gradients behind their backward, and a copy of the weights -- are
+    # STORED in bf16 (hl 'bf16s' launches: half the operand traffic, no conversion in the K loop).  Rounding a value
+    # when it is stored or when it is loaded gives the same bf16 number, so this equals rounding in the kernel.
+    # Layers whose channel counts are not multiples of 8 (the 4-channel clip side) keep fp32 tensors ('bf16' launches).
     precision = 'f32'
+
+    def set_precision(self, precision):
+        assert precision in ('f32', 'bf16')
+        self.precision = precision
+        if precision == 'bf16':
+            self.fp.refresh16()
+
+    def _stored16(self, ci, co):
+        """does a layer with these channel counts run on bf16-stored operands?"""
+        return self.precision == 'bf16' and ci % 8 == 0 and co % 8 == 0 and ci > 4
+
+    def _w(self, name, stored16):
+        return self.fp.param16(name) if stored16 else self.fp.param(name)
 
     # Optional second HIP stream for the weight-gradient GEMMs of the backward pass.  wgrad(l) and dgrad(l)
     # both only read the layer's output gradient, so they may run side by side: the blocks of one fill the
@@ -150,6 +177,8 @@ class _Net:
             v = _np_to(params[key], self.device)
             assert tuple(v.shape) == tuple(self.ref_shapes[key]), (key, v.shape, self.ref_shapes[key])
             self._set_from_ref(key, v)
+        if self.precision == 'bf16':
+            self.fp.refresh16()
 
     def export_reference_params(self):
         out = {}
@@ -187,6 +216,8 @@ class _Net:
         device = torch.device(device)
         for b in ('p', 'g', 'm', 'v'):
             setattr(self.fp, b, getattr(self.fp, b).to(device))
+        if self.fp.p16 is not None:
+            self.fp.p16 = self.fp.p16.to(device)
         self.running = {k: v.to(device) for k, v in self.running.items()}
         self.ws = self.ws.to(device)
         self._part = None
@@ -272,10 +303,14 @@ class DisNet(_Net):
         """(T, H) of the INPUT of layer l (1..5)."""
         return self.T0 - (self.kt - 1) * (l - 1), IMG >> (l - 1)
 
+    def _s16(self, l):
+        """layer l (1..4) runs on bf16-stored operands"""
+        return 1 <= l <= 4 and self._stored16(lay.pad4(self.chans[l - 1]), self.chans[l])
+
     def _geom(self, l, n, x_stride0=None):
         t, h = self._extents(l)
         return hl.make_geom(n, t, h, h, lay.pad4(self.chans[l - 1]), self.chans[l], self.kt, x_stride0=x_stride0,
-                            precision=self.precision, ci_valid=self.chans[l - 1])
+                            precision='bf16s' if self._s16(l) else self.precision, ci_valid=self.chans[l - 1])
 
     # ---- forward ---------------------------------------------------------------------------
     def forward(self, n, first_input, noise=None, rng=None, update_stats=True):
@@ -320,12 +355,13 @@ class DisNet(_Net):
         for l in (1, 2, 3, 4):
             g = self._geom(l, N)
             co = self.chans[l]
-            w, b = self.fp.param('dc%d/W' % l), self.fp.param('dc%d/b' % l)
+            w, b = self._w('dc%d/W' % l, self._s16(l)), self.fp.param('dc%d/b' % l)
             m = n * g.To * g.Ho * g.Wo                       # rows of ONE group
+            adt = torch.bfloat16 if self._s16(l + 1) else torch.float32      # what the NEXT layer's GEMMs read
             if l == 1 and fuse_dc1:
                 # dc1 has no BatchNorm: leaky_relu + add_noise run in its epilogue (model/net.py:148-149,189-190); what
                 # backward needs of the pre-activation -- its sign -- is kept as one bit per element
-                a = torch.empty((N, g.To, g.Ho, g.Wo, co), device=dev)
+                a = torch.empty((N, g.To, g.Ho, g.Wo, co), device=dev, dtype=adt)
                 mask = torch.empty((G * m, (co + 31) // 32), dtype=torch.int32, device=dev)
                 na = [noise_args(grp, 2) for grp in groups]
                 kw = {}
@@ -336,7 +372,8 @@ class DisNet(_Net):
                     else:
                         assert all(x['seed'] == na[0]['seed'] for x in na)
                         kw = dict(sigma=na[0]['sigma'], seed=na[0]['seed'], stream_id=[x['stream_id'] for x in na])
-                hl.conv_fprop(g, saved['a'][1], w, b, a, ep=hl.epilogue(act=hl.ACT_LRELU, groups=G, mask_out=mask, **kw), must_fuse=True)
+                hl.conv_fprop(g, saved['a'][1], w, b, a, must_fuse=True,
+                              ep=hl.epilogue(act=hl.ACT_LRELU, groups=G, mask_out=mask, out_bf16=adt == torch.bfloat16, **kw))
                 saved['y'][1], saved['mask1'], saved['a'][2] = None, mask, a
                 continue
             y = torch.empty((N, g.To, g.Ho, g.Wo, co), device=dev)
@@ -349,7 +386,7 @@ class DisNet(_Net):
             else:
                 hl.conv_fprop(g, a, w, b, y)
             saved['y'][l] = y
-            a = torch.empty_like(y)
+            a = torch.empty_like(y, dtype=adt)
             if l >= 2:
                 saved['stats'][l] = []
             for gi, grp in enumerate(groups):
@@ -433,19 +470,22 @@ class DisNet(_Net):
             co = self.chans[l]
             y = saved['y'][l]
             m = n * geom.To * geom.Ho * geom.Wo                  # rows of ONE group
+            s16 = self._s16(l)
             if l >= 2:
                 name = 'bn%d' % l
+                gy = torch.empty_like(g, dtype=torch.bfloat16) if s16 else g       # bf16-stored operand of wgrad / dgrad, else in place
                 for gi in range(G):
-                    gg, yg = g[gi * n:(gi + 1) * n], y[gi * n:(gi + 1) * n]
+                    gg, yg, go = g[gi * n:(gi + 1) * n], y[gi * n:(gi + 1) * n], gy[gi * n:(gi + 1) * n]
                     dg = fp.grad(name + '/gamma') if param_grads else None
                     db = fp.grad(name + '/beta') if param_grads else None
                     if pending is not None:
                         ep, part = pending
                         hl.bn_act_bwd_from_partials(m, co, gg, yg, saved['stats'][l][gi], fp.param(name + '/gamma'), hl.ACT_LRELU,
-                                                    part[gi * 2 * co:], ep.n_slots, ep.slot_stride, gg, dg, db, self.ws)
+                                                    part[gi * 2 * co:], ep.n_slots, ep.slot_stride, go, dg, db, self.ws)
                     else:
-                        hl.bn_act_bwd(m, co, gg, yg, saved['stats'][l][gi], fp.param(name + '/gamma'), hl.ACT_LRELU, gg, dg, db, self.ws,
+                        hl.bn_act_bwd(m, co, gg, yg, saved['stats'][l][gi], fp.param(name + '/gamma'), hl.ACT_LRELU, go, dg, db, self.ws,
                                       sync=self.sync_bn)
+                g = gy
             elif mask1 is None:
                 for gi in range(G):
                     gg, yg = g[gi * n:(gi + 1) * n], y[gi * n:(gi + 1) * n]
@@ -463,14 +503,14 @@ class DisNet(_Net):
                     self._after_wgrads(on_late_bucket)
             pending = None
             if l > 1:
-                ga = torch.empty_like(saved['a'][l])
-                w = fp.param('dc%d/W' % l)
+                ga = torch.empty_like(saved['a'][l], dtype=torch.float32)
+                w = self._w('dc%d/W' % l, s16)
                 if l == 2 and mask1 is not None:
                     part = self._part_buf(geom, 'dgrad', 1) if param_grads else None
                     ep = hl.epilogue(mask_in=mask1, sums=hl.SUMS_COL if param_grads else hl.SUMS_NONE, groups=1, part=part)
                     hl.conv_dgrad(geom, g, w, None, ga, ep=ep, must_fuse=True)
                     pending = (ep, part) if param_grads else None
-                elif l > 2 and fuse_bwd:
+                elif l > 2 and fuse_bwd and not s16:
                     part = self._part_buf(geom, 'dgrad', G)
                     ep = hl.epilogue(sums=hl.SUMS_BN_BWD, groups=G, part=part, bn_y=saved['y'][l - 1], bn_stats=saved['stats'][l - 1],
                                      bn_act=hl.ACT_LRELU)
@@ -574,11 +614,16 @@ class GenNet(_Net):
         clip n, time t): the (T,N)->(N,T) transpose of model/updater.py:102 costs nothing."""
         h = 4 << (l - 1)
         ci = lay.pad4(self.chans[l])
+        prec = 'bf16s' if self._s16(l) else self.precision
         if clip_order_n:
             T = frames // clip_order_n
             return hl.make_geom(frames, 1, h, h, ci, self.chans[l - 1], 1, x_stride0=T * h * h * ci,
-                                x_perm_n=clip_order_n, x_stride1=h * h * ci, precision=self.precision, ci_valid=self.chans[l])
-        return hl.make_geom(frames, 1, h, h, ci, self.chans[l - 1], 1, precision=self.precision, ci_valid=self.chans[l])
+                                x_perm_n=clip_order_n, x_stride1=h * h * ci, precision=prec, ci_valid=self.chans[l])
+        return hl.make_geom(frames, 1, h, h, ci, self.chans[l - 1], 1, precision=prec, ci_valid=self.chans[l])
+
+    def _s16(self, l):
+        """deconvolution layer l (2..5) runs on bf16-stored operands (conv form: Ci = its output channels, Co = its input's)"""
+        return 2 <= l <= 5 and self._stored16(lay.pad4(self.chans[l]), self.chans[l - 1])
 
     # ---- latent draws (model/net.py:55-56,66,71,92,102) ------------------------------------------
     def draw(self, n, rng):
@@ -643,7 +688,7 @@ class GenNet(_Net):
                 scale = fp.param(name + '/gamma') * inv
                 ss = torch.cat((scale, fp.param(name + '/beta') - self.running[name + '/avg_mean'] * scale))
             saved['y'][l] = y
-            a = torch.empty_like(y)
+            a = torch.empty_like(y, dtype=torch.bfloat16 if self._s16(l + 1) else torch.float32)   # the operand of layer l + 1's GEMMs
             hl.bn_act_fwd(m, co, y, ss, hl.ACT_RELU, a)
             saved['a'][l + 1] = a
             h = 4 << l
@@ -651,7 +696,7 @@ class GenNet(_Net):
             if l < 4:
                 y = torch.empty((frames, h, h, self.chans[l + 1]), device=dev)
                 geom = self._geom(l + 1, frames)
-                w, b = fp.param('dc%d/W' % (l + 1)), fp.param('dc%d/b' % (l + 1))
+                w, b = self._w('dc%d/W' % (l + 1), self._s16(l + 1)), fp.param('dc%d/b' % (l + 1))
                 if fuse_stats:
                     part = self._part_buf(geom, 'dgrad', 1)
                     ep = hl.epilogue(sums=hl.SUMS_STATS, groups=1, part=part)
@@ -688,30 +733,34 @@ class GenNet(_Net):
             geom = self._geom(l, frames)
             ci = lay.pad4(self.chans[l])
             m = g.numel() // ci
+            s16 = self._s16(l)
             if l < 5:
                 name = 'bn%d' % l
+                gy = torch.empty_like(g, dtype=torch.bfloat16) if s16 else g      # bf16-stored operand of wgrad / fprop, else in place
                 if pending is not None:
                     ep, part = pending
                     hl.bn_act_bwd_from_partials(m, ci, g, saved['y'][l], saved['stats'][l], fp.param(name + '/gamma'), hl.ACT_RELU, part,
-                                                ep.n_slots, ep.slot_stride, g, fp.grad(name + '/gamma'), fp.grad(name + '/beta'), self.ws)
+                                                ep.n_slots, ep.slot_stride, gy, fp.grad(name + '/gamma'), fp.grad(name + '/beta'), self.ws)
                 else:
-                    hl.bn_act_bwd(m, ci, g, saved['y'][l], saved['stats'][l], fp.param(name + '/gamma'), hl.ACT_RELU, g,
+                    hl.bn_act_bwd(m, ci, g, saved['y'][l], saved['stats'][l], fp.param(name + '/gamma'), hl.ACT_RELU, gy,
                                   fp.grad(name + '/gamma'), fp.grad(name + '/beta'), self.ws, sync=self.sync_bn)
+                g = gy
             if l == 5:
                 hl.colsum_acc(m, ci, g, fp.grad('dc5/b'), self.ws)         # dc1..dc4 feed BatchNorm: exact zero
             self._wgrad(geom, g, saved['a'][l], fp.grad('dc%d/W' % l))
             if l == 2 and on_late_bucket is not None:
                 self._after_wgrads(on_late_bucket)
-            ga = torch.empty_like(saved['a'][l])
+            ga = torch.empty_like(saved['a'][l], dtype=torch.float32)
             pending = None
-            if fuse_bwd:             # ga is the gradient w.r.t. relu(bn_{l-1}(y_{l-1})): the sums of that BatchNorm's backward
+            wl = self._w('dc%d/W' % l, s16)
+            if fuse_bwd and not s16:     # ga is the gradient w.r.t. relu(bn_{l-1}(y_{l-1})): the sums of that BatchNorm's backward
                 part = self._part_buf(geom, 'fprop', 1)
                 ep = hl.epilogue(sums=hl.SUMS_BN_BWD, groups=1, part=part, bn_y=saved['y'][l - 1], bn_stats=[saved['stats'][l - 1]],
                                  bn_act=hl.ACT_RELU)
-                if hl.conv_fprop(geom, g, fp.param('dc%d/W' % l), None, ga, ep=ep):
+                if hl.conv_fprop(geom, g, wl, None, ga, ep=ep):
                     pending = (ep, part)
             else:
-                hl.conv_fprop(geom, g, fp.param('dc%d/W' % l), None, ga)
+                hl.conv_fprop(geom, g, wl, None, ga)
             g = ga
         c1 = self.chans[1]
         k1 = 16 * c1

@@ -34,7 +34,8 @@ def adam_update(net, hyper, grad_scale=1.0):
     grad_scale: 1 / world under data parallelism (the flat gradient then holds the SUM over the ranks)."""
     net.t += 1
     fp = net.fp
-    hl.adam_wd(fp.p, fp.g, fp.m, fp.v, hyper.lr(net.t), hyper.beta1, hyper.beta2, hyper.eps, hyper.weight_decay, grad_scale)
+    hl.adam_wd(fp.p, fp.g, fp.m, fp.v, hyper.lr(net.t), hyper.beta1, hyper.beta2, hyper.eps, hyper.weight_decay, grad_scale,
+               p16=fp.p16 if net.precision == 'bf16' else None)
 
 
 class GradExchange:
@@ -87,7 +88,7 @@ class TrainStep:
         if precision is not None:                                 # 'f32' | 'bf16': MFMA operand type of every conv GEMM
             assert precision in ('f32', 'bf16')
             for net in (gen, dis_i, dis_v):
-                net.precision = precision
+                net.set_precision(precision)
         self.hyper = hyper or {'image_gen': AdamHyper(), 'image_dis': AdamHyper(), 'video_dis': AdamHyper()}
         self.exchange = exchange
         # sync_bn (opt-in): BatchNorm statistics and their backward sums are all-reduced over the ranks, i.e.

@@ -57,7 +57,7 @@ def test_argument_validation_happens_on_the_host(hl):
     assert lib.mcg_conv_fprop(ctypes.byref(g), None, None, None, None, None) == -1
     assert lib.mcg_fc_fprop(4, 30, 1, None, None, None, None, None) == -1
     assert lib.mcg_gru_seq_fwd(4, 16, 64, 0, 50, None, None, None, None, None, None, None, None) == -1
-    assert lib.mcg_adam_wd(0, None, None, None, None, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, None) == -1
+    assert lib.mcg_adam_wd(0, None, None, None, None, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, None, None) == -1
     assert int(lib.mcg_bn_workspace_bytes(0, 512)) == (512 * 2 * 512 + 3 * 512) * 4
 
 

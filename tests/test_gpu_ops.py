@@ -657,3 +657,79 @@ def test_weight_stationary_first_layer_kernels(hl, case):
     with pytest.raises(hl.McgError):
         hl.conv_fprop(g, torch.zeros((2, 5, 16, 16, 8), device="cuda"), torch.zeros((64, 4, 4, 4, 8), device="cuda"), None,
                       torch.zeros((2, 2, 8, 8, 64), device="cuda"))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# MCG_PREC_BF16_STORE ('bf16s'): operands that are bf16 IN MEMORY (BASELINE configs[2] networks keep the tensors that are
+# only read by GEMMs -- activations, output gradients, a weight copy -- in bf16)
+# ------------------------------------------------------------------------------------------------------------------
+BF16S_CASES = [(2, 7, 16, 8, 64, 4), (3, 1, 16, 16, 32, 1), (2, 4, 8, 64, 160, 4), (2, 9, 8, 16, 24, 4)]
+
+
+@pytest.mark.parametrize("case", BF16S_CASES)
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 101, 203])
+def test_bf16_stored_operands_equal_rounding_in_the_kernel(hl, case, tile):
+    """Rounding an operand to bf16 when it is stored or when it is loaded yields the same number, so a 'bf16s' launch on
+    bf16 tensors must reproduce the 'bf16' launch on the fp32 tensors holding the same (bf16-representable) values: bit
+    for bit for fprop / dgrad (same MFMA sequence), to summation order for wgrad (atomics); and both match the oracle."""
+    N, Ti, H, Ci, Co, kt = case
+    rng = np.random.RandomState(hash(case) % 2**31 + 5)
+    lay = L()
+    x, W = _bf16_round(rng.uniform(-1, 1, (N, Ci, Ti, H, H))), _bf16_round(rng.randn(Co, Ci, kt, 4, 4) * 0.1)
+    b = rng.randn(Co)
+    gy = _bf16_round(rng.randn(N, Co, Ti - kt + 1, H // 2, H // 2))
+    y_ref = F.conv3d_fwd(x, W, b, (1, 2, 2), (0, 1, 1))
+    gx_ref, gW_ref, _ = F.conv3d_bwd(x, W, gy, (1, 2, 2), (0, 1, 1))
+    xd, wd, bd, gyd = lay.act_to_dev(dev(x)), lay.conv_w_to_dev(dev(W)), dev(b), lay.act_to_dev(dev(gy))
+    x16, w16, gy16 = xd.to(torch.bfloat16), wd.to(torch.bfloat16), gyd.to(torch.bfloat16)
+    assert torch.equal(x16.float(), xd) and torch.equal(w16.float(), wd)
+    res = {}
+    for prec, (xa, wa, ga) in (('bf16', (xd, wd, gyd)), ('bf16s', (x16, w16, gy16))):
+        g = hl.make_geom(N, Ti, H, H, Ci, Co, kt, precision=prec)
+        g.tile = tile
+        yd = torch.empty((N, g.To, g.Ho, g.Wo, Co), device="cuda")
+        hl.conv_fprop(g, xa, wa, bd, yd)
+        gxd = torch.full((N, Ti, H, H, Ci), 7.0, device="cuda")
+        hl.conv_dgrad(g, ga, wa, None, gxd)
+        dwd = torch.zeros_like(wd)
+        hl.conv_wgrad(g, xa, ga, dwd)
+        res[prec] = (yd, gxd, dwd)
+    assert rel_l2(lay.act_from_dev(res['bf16s'][0], Co), y_ref) < FWD_TOL
+    assert rel_l2(lay.act_from_dev(res['bf16s'][1], Ci), gx_ref) < BWD_TOL
+    assert rel_l2(lay.conv_w_from_dev(res['bf16s'][2], Ci, 3), gW_ref) < BWD_TOL
+    assert torch.equal(res['bf16'][0], res['bf16s'][0]) and torch.equal(res['bf16'][1], res['bf16s'][1])
+    assert rel_l2(res['bf16s'][2], res['bf16'][2].cpu().double().numpy()) < 1e-5
+    # a stats epilogue rides on a 'bf16s' launch too; host tensors / wrong dtypes are refused
+    g = hl.make_geom(N, Ti, H, H, Ci, Co, kt, precision='bf16s')
+    g.tile = tile
+    part = torch.empty(hl.epilogue_part_floats(g, "fprop", 1), device="cuda")
+    ep = hl.epilogue(sums=hl.SUMS_STATS, groups=1, part=part)
+    y2 = torch.empty_like(res['bf16s'][0])
+    assert hl.conv_fprop(g, x16, w16, bd, y2, ep=ep) and torch.equal(y2, res['bf16s'][0])
+    with pytest.raises(hl.McgError):
+        hl.conv_fprop(g, xd, w16, bd, y2)                     # fp32 tensor where the geometry promises bf16
+
+
+def test_elementwise_passes_write_bf16_operands(hl):
+    """bn_act_fwd / bn_act_bwd with a bf16 output tensor store round-to-nearest-even of what they store in fp32, and Adam's
+    bf16 weight copy is the rounded master parameter."""
+    rng = np.random.RandomState(12)
+    M, C = 3000, 64
+    y, gamma, beta = dev(rng.randn(M, C) * 1.5), dev(1 + 0.1 * rng.randn(C)), dev(0.1 * rng.randn(C))
+    ws = torch.empty(hl.bn_workspace_floats(C), device="cuda")
+    stats = torch.empty(4 * C, device="cuda")
+    hl.bn_stats(M, C, y, gamma, beta, stats, None, None, ws)
+    o32, o16 = torch.empty((M, C), device="cuda"), torch.empty((M, C), device="cuda", dtype=torch.bfloat16)
+    hl.bn_act_fwd(M, C, y, stats[2 * C:], hl.ACT_LRELU, o32, sigma=0.2, seed=3, stream_id=9)
+    hl.bn_act_fwd(M, C, y, stats[2 * C:], hl.ACT_LRELU, o16, sigma=0.2, seed=3, stream_id=9)
+    assert torch.equal(o16, o32.to(torch.bfloat16))
+    g = dev(rng.randn(M, C))
+    g32, g16 = torch.empty((M, C), device="cuda"), torch.empty((M, C), device="cuda", dtype=torch.bfloat16)
+    hl.bn_act_bwd(M, C, g, y, stats, gamma, hl.ACT_LRELU, g32, None, None, ws)
+    hl.bn_act_bwd(M, C, g, y, stats, gamma, hl.ACT_LRELU, g16, None, None, ws)
+    assert torch.equal(g16, g32.to(torch.bfloat16))
+    n = 5001
+    p, gr, m, v = dev(rng.randn(n)), dev(rng.randn(n) * 1e-2), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    p16 = torch.zeros(n, device="cuda", dtype=torch.bfloat16)
+    hl.adam_wd(p, gr, m, v, 2e-4, 5e-5, 0.999, 1e-8, 1e-5, p16=p16)
+    assert torch.equal(p16, p.to(torch.bfloat16))
