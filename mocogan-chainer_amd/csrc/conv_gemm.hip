@@ -1365,7 +1365,10 @@ int launch_fprop_c4(const Geom& g, const float* x, const float* w, const float* 
 // the MFMA col2im input-gradient kernel of the Ci = 4 layers: what it covers
 bool c4_dgrad_mfma_ok(const Geom& g, const Epi& e, const float* bias, int act, int accumulate) {
     const long long frame = (long long)g.Ti * g.Hi * g.Wi * g.Ci;
-    return g.Ci == 4 && g.cv <= 3 && g.Co == 64 && (g.Wo == 32 || g.Wo == 16) && g.Ho % (128 / g.Wo) == 0 && !g.perm_n && g.xs0 == frame &&
+    // x must be ONE dense buffer of N frames (it is cleared as a whole): plain batch order, or the generator's
+    // (T,N) -> (N,T) frame permutation, which maps the N frames one-to-one onto it
+    const bool whole = g.perm_n ? (g.xs1 == frame && g.xs0 == (long long)(g.N / g.perm_n) * frame) : g.xs0 == frame;
+    return g.Ci == 4 && g.cv <= 3 && g.Co == 64 && (g.Wo == 32 || g.Wo == 16) && g.Ho % (128 / g.Wo) == 0 && whole &&
            !e.mode && !bias && act == MCG_ACT_NONE && !accumulate;
 }
 

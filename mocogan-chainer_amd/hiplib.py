@@ -408,6 +408,15 @@ def _dgrad_ex(g, y, w, bias, x, ep):
            "mcg_conv_dgrad_ex")
 
 
+def dgrad_c4_mfma_covers(g):
+    """True when conv_dgrad(g, ..., bias=None, act=ACT_NONE) runs the MFMA col2im kernel of the Ci = 4 layers (the library's
+    own condition, restated for callers that split bias + tanh off into an element-wise pass to reach that kernel)."""
+    frame = g.Ti * g.Hi * g.Wi * g.Ci
+    whole = (g.x_stride1 == frame and g.x_stride0 == (g.N // g.x_perm_n) * frame) if g.x_perm_n else g.x_stride0 == frame
+    return (g.Ci == 4 and 0 < g.ci_valid <= 3 and g.Co == 64 and g.Wo in (16, 32) and g.Ho % (128 // g.Wo) == 0 and whole
+            and g.precision != PREC_BF16_STORE and _with_override(g).tile in (0, 6))
+
+
 def conv_fprop(g, x, w, bias, y, ep=None, must_fuse=False):
     """ep: a ConvEpilogue to fuse into the launch.  Returns True when it was fused; False when the tile tuned for this
     geometry splits K (partial tiles cannot carry an epilogue) and must_fuse is off: then the PLAIN convolution ran and

@@ -705,8 +705,17 @@ class GenNet(_Net):
                 else:
                     hl.conv_dgrad(geom, a, w, b, y)
         x = torch.empty((n, T, IMG, IMG, self.cp_out), device=dev)
-        hl.conv_dgrad(self._geom(5, frames, clip_order_n=n), saved['a'][5], fp.param('dc5/W'), fp.param('dc5/b'), x,
-                      act=hl.ACT_TANH)
+        g5 = self._geom(5, frames, clip_order_n=n)
+        if hl.dgrad_c4_mfma_covers(g5):
+            # the last deconvolution (64 -> 3 channels) on the matrix pipe; bias + tanh (model/net.py:114) follow as an
+            # element-wise pass over the 4-channel clip (x = tanh(1 * x + b)), which the MFMA kernel cannot carry
+            if getattr(self, '_one_bias', None) is None or self._one_bias.device != dev:
+                self._one_bias = torch.ones(2 * self.cp_out, device=dev)
+            self._one_bias[self.cp_out:].copy_(fp.param('dc5/b'))
+            hl.conv_dgrad(g5, saved['a'][5], fp.param('dc5/W'), None, x)
+            hl.bn_act_fwd(x.numel() // self.cp_out, self.cp_out, x, self._one_bias, hl.ACT_TANH, x)
+        else:
+            hl.conv_dgrad(g5, saved['a'][5], fp.param('dc5/W'), fp.param('dc5/b'), x, act=hl.ACT_TANH)
         saved['x'] = x
         return x, saved
 

@@ -48,7 +48,7 @@ def main():
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--tile', type=int, default=0)
     ap.add_argument('--only', default='')
-    ap.add_argument('--precision', default='f32', choices=['f32', 'bf16'])
+    ap.add_argument('--precision', default='f32', choices=['f32', 'bf16', 'bf16s'])
     ap.add_argument('--net', default='', help='restrict to layers whose name starts with this (e.g. D_V)')
     ap.add_argument('--layer', default='', help='restrict to layers whose name contains this (e.g. dc1)')
     ap.add_argument('--autotune', action='store_true', help='time the tile candidates per geometry first')
@@ -73,9 +73,15 @@ def main():
         w = torch.randn((Co, kt, 4, 4, Ci), device='cuda') * 0.05
         dw = torch.zeros_like(w)
         flops = 2.0 * N * g.To * g.Ho * g.Wo * kt * 16 * ci_real * Co
-        for p, fn in (('fprop', lambda: hl.conv_fprop(g, x, w, None, y)),
-                      ('dgrad', lambda: hl.conv_dgrad(g, y, w, None, x)),
-                      ('wgrad', lambda: hl.conv_wgrad(g, x, y, dw))):
+        if args.precision == 'bf16s':                       # operands bf16 in memory, outputs fp32
+            if Ci % 8 or Co % 8:
+                continue
+            xi, yi, wi = x.to(torch.bfloat16), y.to(torch.bfloat16), w.to(torch.bfloat16)
+        else:
+            xi, yi, wi = x, y, w
+        for p, fn in (('fprop', lambda: hl.conv_fprop(g, xi, wi, None, y)),
+                      ('dgrad', lambda: hl.conv_dgrad(g, yi, wi, None, x)),
+                      ('wgrad', lambda: hl.conv_wgrad(g, xi, yi, dw))):
             if args.only and p != args.only:
                 continue
             ms = timeit(fn)
