@@ -21,6 +21,7 @@
 // validity bit-masks over the 16 taps precomputed once per block.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <mutex>
 #include "mocogan_hip.h"
 #include "mcg_common.h"
@@ -125,6 +126,8 @@ struct FpropP {
     Epi e;
     const float* x; const float* w; const float* bias; float* y;
     int M, K;
+    int mfast;          // tile order inside an XCD: 1 = M tile fastest (one filter panel resident in L2), 0 = N tile fastest
+    __device__ bool m_fastest() const { return mfast != 0; }
     int kchunk;         // K range of one blockIdx.z (multiple of BK; == K without split-K)
     int zz;             // this block's K split; with more than one split the partial tiles are added atomically
                         // onto a zeroed y (mcg_conv_fprop clears it) and split 0 contributes the bias
@@ -427,6 +430,7 @@ template <int BM, int BN, int BK>
 struct FcFpropP {
     static constexpr bool HAS_EPI = false;
     static constexpr int E = 4;
+    __device__ bool m_fastest() const { return false; }
     static constexpr bool A_KC = true, B_KC = true;
     static constexpr int ORDER = 0;
     static constexpr int NA = BM * BK / 4 / NTHREADS, NB = BN * BK / 4 / NTHREADS;
@@ -662,8 +666,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(P p) {
         const int L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
         const int xcd = L & 7, q = nwg >> 3, r = nwg & 7;
         const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
-        if (P::ORDER == 0) {            // fprop: N tile fastest, then M tile (same activations, next filters), then K split
-            by = t % gy; bx = (t / gy) % gx; bz = t / (gy * gx);
+        if constexpr (P::ORDER == 0) {  // fprop: N tile fastest, then M tile (same activations, next filters), then K split;
+            // or (m_fastest) each XCD keeps ONE filter panel in its L2 and sweeps the M tiles: layers whose filter is
+            // larger than an L2 would otherwise stream the whole filter from the fabric once per M tile
+            if (p.m_fastest()) { bx = t % gx; by = (t / gx) % gy; bz = t / (gy * gx); }
+            else { by = t % gy; bx = (t / gy) % gx; bz = t / (gy * gx); }
         } else if constexpr (P::ORDER == 1) {
             // dgrad: (M tile, N tile) pairs are dealt round-robin over the XCDs in dispatch order -- rows are time-major
             // and blocks near the temporal boundary skip most K-steps, so a contiguous range per XCD would give the
@@ -735,6 +742,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(P p) {
         { const int kl = kn < kend ? kn : kend - BK; p.load_a(kl, ra); p.load_b(kl, rb); }
 #endif
         MCG_T(ts2);
+#ifdef MCG_SETPRIO          // (experiment: the wave's MFMA phase at raised issue priority)
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int gk = 0; gk < BK / 8; ++gk) {
             float fa[TM][4], fb[TN][4];
@@ -767,6 +777,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(P p) {
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
         }
         MCG_T(ts3);
+#ifdef MCG_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
 #ifndef MCG_PROBE_NOBAR2
         __syncthreads();
 #endif
@@ -852,8 +865,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(P p) {
         const int L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
         const int xcd = L & 7, q = nwg >> 3, r = nwg & 7;
         const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
-        if (P::ORDER == 0) { by = t % gy; bx = (t / gy) % gx; bz = t / (gy * gx); }
-        else if constexpr (P::ORDER == 1) {
+        if constexpr (P::ORDER == 0) {
+            if (p.m_fastest()) { bx = t % gx; by = (t / gx) % gy; bz = t / (gy * gx); }
+            else { by = t % gy; bx = (t / gy) % gx; bz = t / (gy * gx); }
+        } else if constexpr (P::ORDER == 1) {
 #ifndef MCG_NO_CLASS_ADJ
             const int Lb = blockIdx.x, xq = Lb & 7, qq = Lb >> 3;
             const int cls = qq & 3, rr = qq >> 2;
@@ -1084,6 +1099,99 @@ __global__ __launch_bounds__(512) void fprop_c4_kernel(C4FpropP p) {
     }
 }
 
+// The same kernel on the bf16 MFMA (v_mfma_f32_32x32x16_bf16) for networks in bf16 mode: x and w (fp32 in memory: the
+// first layer's tensors stay fp32) are rounded to bf16 on their way into LDS.  One MFMA covers the 4 kw x 4 channels
+// of a (frame, kh) filter row: lane half h reads the two adjacent pixels kw = 2h, 2h + 1 of its output pixel as one
+// 16-byte LDS read -- patch rows are plain pixel order with one pixel of left padding, so that read is 16-byte aligned
+// and the 32 lanes of an accumulator row read 32 consecutive 16-byte slots.
+template <int KT, int WO, int EPI>
+__global__ __launch_bounds__(512) void fprop_c4_bf16_kernel(C4FpropP p) {
+    constexpr int BM = 256, BN = 64, K = KT * 64;
+    constexpr int R = BM / WO, PR = 2 * R + 2, WI = 2 * WO;
+    constexpr int ENT = WI + 4, ROW = ENT * 8, SLAB = PR * ROW;                          // bytes (a pixel = 4 bf16)
+    constexpr int WROW = (K + 8) * 2;                                                      // bytes
+    constexpr int NLD = (PR * ENT + 511) / 512;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* wl = smem;                                  // 64 * WROW
+    unsigned char* pl = smem + 64 * WROW;                      // KT * SLAB
+    float* red = reinterpret_cast<float*>(pl + KT * SLAB);
+    const Geom& g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int hblocks = g.Ho / R;
+    const int n = blockIdx.x / hblocks, ho0 = (blockIdx.x - n * hblocks) * R;
+    const __amdgpu_buffer_rsrc_t xr = make_srd(p.x, g.x_bytes);
+
+    for (int i = tid; i < 64 * K / 4; i += 512) {
+        const int co = i / (K / 4), k4 = i - co * (K / 4);
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(p.w + (long long)co * K + k4 * 4);
+        *reinterpret_cast<bf16x4*>(wl + co * WROW + k4 * 8) = __builtin_convertvector(wv, bf16x4);
+    }
+    // patch position `en` of a row holds input pixel wi = en - 1 (positions 0 and > WI: zeros)
+    u32 goff[NLD]; int loff[NLD];
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int idx = tid + 512 * j, pr = idx / ENT, en = idx - pr * ENT;
+        const int hi = 2 * ho0 - 1 + pr, wi = en - 1;
+        const bool ok = pr < PR && (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)WI;
+        goff[j] = ok ? (u32)(((long long)n * g.Ti * g.Hi + hi) * WI + wi) * 16u : OOB;
+        loff[j] = pr < PR ? pr * ROW + en * 8 : -1;
+    }
+    const u32 fbytes = (u32)g.Hi * WI * 16u;
+    f32x4 stage[NLD];
+    auto slab_load = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) stage[j] = bload(xr, goff[j] == OOB ? OOB : goff[j] + (u32)t * fbytes);
+    };
+    auto slab_store = [&](int slot) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j)
+            if (loff[j] >= 0) *reinterpret_cast<bf16x4*>(pl + slot * SLAB + loff[j]) = __builtin_convertvector(stage[j], bf16x4);
+    };
+#pragma unroll
+    for (int t = 0; t < KT; ++t) { slab_load(t); slab_store(t); }
+    __syncthreads();
+
+    const int wm = wave >> 1, wn = wave & 1;
+    int abase[2];
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx) {
+        const int r = wm * 64 + sidx * 32 + li, hol = r / WO, wo = r - hol * WO;
+        abase[sidx] = (2 * hol) * ROW + (2 * wo + 2 * lh) * 8;
+    }
+    const int bbase = (wn * 32 + li) * WROW + lh * 16;
+
+    for (int to = 0; to < g.To; ++to) {
+        const bool more = KT > 1 && to + KT < g.Ti;
+        if (more) slab_load(to + KT);
+        f32x16 acc[2][1];
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[sidx][0][r] = 0.f;
+#pragma unroll
+        for (int a = 0; a < KT; ++a) {
+            const int sb = ((to + a) % KT) * SLAB;
+#pragma unroll
+            for (int kh = 0; kh < 4; ++kh) {
+                const bf16x8 bv = *reinterpret_cast<const bf16x8*>(wl + bbase + (a * 4 + kh) * 32);
+#pragma unroll
+                for (int sidx = 0; sidx < 2; ++sidx) {
+                    const bf16x8 av = *reinterpret_cast<const bf16x8*>(pl + sb + abase[sidx] + kh * ROW);
+                    acc[sidx][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[sidx][0], 0, 0, 0);
+                }
+            }
+        }
+        const int m0 = ((n * g.To + to) * g.Ho + ho0) * WO;
+        fused_epilogue<C4FpropP, BM, BN, 4, 2, 2, 1, EPI>(p, acc, m0, 0, m0 / BM, 0, tid, red);
+        if (KT > 1) {
+            __syncthreads();
+            if (more) slab_store(to % KT);
+            __syncthreads();
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // dgrad for Ci == 4 (<= 3 data channels), Co == 64 on the MATRIX pipe -- the input gradient of D's first layer.
 // With 3..4 output columns the parity-class GEMM of DgradP leaves the MFMA tile empty, and the VALU kernel below runs
@@ -1103,10 +1211,12 @@ struct C4DgradP {
     const float* y; const float* w; float* x;
 };
 
-template <int KT, int WO>
+// BF: the two GEMM operands are rounded to bf16 on their way into LDS and multiplied on v_mfma_f32_16x16x32_bf16
+// (networks in bf16 mode; y and w are fp32 in memory either way, Z and the accumulators stay fp32)
+template <int KT, int WO, bool BF>
 __global__ __launch_bounds__(512) void dgrad_c4_mfma_kernel(C4DgradP p) {
     constexpr int PIX = 128, R = PIX / WO, WI = 2 * WO, XR = 2 * R + 2;       // y pixels per step; input rows of the window
-    constexpr int YLD = 68, WLD = 68, ZLD = 52;                              // LDS row strides (floats)
+    constexpr int YLD = BF ? 36 : 68, WLD = YLD, ZLD = 52;                   // LDS row strides in floats (bf16 rows: 64 + 8 elements)
     constexpr int NPX = XR * WI, PPT = (NPX + 511) / 512;                    // input pixels of the window; per thread
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* yl = sm;                                  // [PIX][YLD]
@@ -1122,7 +1232,9 @@ __global__ __launch_bounds__(512) void dgrad_c4_mfma_kernel(C4DgradP p) {
     // ---- weights -> LDS, transposed to [column][co]
     for (int i = tid; i < KT * 48 * 64; i += 512) {
         const int co = i & 63, col = i >> 6, ci = col % 3, tap = col / 3;    // tap = a * 16 + kh * 4 + kw
-        wl[col * WLD + co] = p.w[((long long)co * g.taps + tap) * 4 + ci];
+        const float wv = p.w[((long long)co * g.taps + tap) * 4 + ci];
+        if constexpr (BF) reinterpret_cast<__bf16*>(wl)[col * (2 * WLD) + co] = (__bf16)wv;
+        else wl[col * WLD + co] = wv;
     }
     for (int i = tid; i < KT * NPX; i += 512) al[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -1173,28 +1285,44 @@ __global__ __launch_bounds__(512) void dgrad_c4_mfma_kernel(C4DgradP p) {
 #pragma unroll
         for (int j = 0; j < PIX * 16 / 512; ++j) {
             const int s = tid + 512 * j;
-            *reinterpret_cast<f32x4*>(yl + (s >> 4) * YLD + (s & 15) * 4) = ystage[j];
+            if constexpr (BF) *reinterpret_cast<bf16x4*>(reinterpret_cast<u16*>(yl) + (s >> 4) * (2 * YLD) + (s & 15) * 4) = __builtin_convertvector(ystage[j], bf16x4);
+            else *reinterpret_cast<f32x4*>(yl + (s >> 4) * YLD + (s & 15) * 4) = ystage[j];
         }
         __syncthreads();
         if (to + 1 < g.To) {
 #pragma unroll
             for (int j = 0; j < PIX * 16 / 512; ++j) ystage[j] = bload(yr, yoff[j] + (u32)(to + 1) * yframe);
         }
-        // A fragments of this wave's 16 pixels (all of K = 64): element m of read gq is co = 16 gq + 4 kq + m
+        // A fragments of this wave's 16 pixels (all of K = 64).  fp32: element m of read gq is co = 16 gq + 4 kq + m (one
+        // 16x16x4 MFMA per element); bf16: read s holds co = 32 s + 8 kq .. + 7 (one 16x16x32 MFMA per read)
         f32x4 af[4];
+        bf16x8 ah[2];
+        if constexpr (BF) {
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) af[gq] = *reinterpret_cast<const f32x4*>(yl + (wave * 16 + li) * YLD + gq * 16 + kq * 4);
+            for (int sq = 0; sq < 2; ++sq) ah[sq] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const u16*>(yl) + (wave * 16 + li) * (2 * YLD) + sq * 32 + kq * 8);
+        } else {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) af[gq] = *reinterpret_cast<const f32x4*>(yl + (wave * 16 + li) * YLD + gq * 16 + kq * 4);
+        }
 #pragma unroll
         for (int a = 0; a < KT; ++a) {
             f32x4 zc[3];
 #pragma unroll
             for (int cb = 0; cb < 3; ++cb) {
                 zc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (BF) {
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const f32x4 bf = *reinterpret_cast<const f32x4*>(wl + (a * 48 + cb * 16 + li) * WLD + gq * 16 + kq * 4);
+                    for (int sq = 0; sq < 2; ++sq) {
+                        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const u16*>(wl) + (a * 48 + cb * 16 + li) * (2 * WLD) + sq * 32 + kq * 8);
+                        zc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[sq], bh, zc[cb], 0, 0, 0);
+                    }
+                } else {
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) zc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[gq][m], bf[m], zc[cb], 0, 0, 0);
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const f32x4 bf = *reinterpret_cast<const f32x4*>(wl + (a * 48 + cb * 16 + li) * WLD + gq * 16 + kq * 4);
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) zc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[gq][m], bf[m], zc[cb], 0, 0, 0);
+                    }
                 }
             }
             if (a > 0) __syncthreads();                           // the previous tap's gather has read zl
@@ -1339,7 +1467,7 @@ __global__ __launch_bounds__(NTHREADS) void dgrad_c4_kernel(Geom g, const float*
 bool c4_fprop_ok(const Geom& g, const Epi& e) {
     const long long frame = (long long)g.Ti * g.Hi * g.Wi * g.Ci;
     return g.Ci == 4 && g.Co == 64 && (g.Wo == 32 || g.Wo == 16) && g.Ho % (256 / g.Wo) == 0 && !g.perm_n && g.xs0 == frame &&
-           g.prec == MCG_PREC_F32 && (e.mode == 0 || e.mode == EPI_ACT);
+           g.prec != MCG_PREC_BF16_STORE && (e.mode == 0 || e.mode == EPI_ACT);          // (this layer's tensors are fp32 in memory)
 }
 
 template <int KT, int WO>
@@ -1372,19 +1500,41 @@ bool c4_dgrad_mfma_ok(const Geom& g, const Epi& e, const float* bias, int act, i
            !e.mode && !bias && act == MCG_ACT_NONE && !accumulate;
 }
 
-template <int KT, int WO>
+template <int KT, int WO, bool BF>
 int launch_dgrad_c4_mfma(const Geom& g, const float* y, const float* w, float* x, hipStream_t s) {
     C4DgradP p;
     p.g = g; p.y = y; p.w = w; p.x = x;
-    constexpr int R = 128 / WO, NPX = (2 * R + 2) * 2 * WO;
-    const size_t lds = (size_t)(128 * 68 + KT * 48 * 68 + 128 * 52) * 4 + (size_t)KT * NPX * 16;
+    constexpr int R = 128 / WO, NPX = (2 * R + 2) * 2 * WO, LD = BF ? 36 : 68;
+    const size_t lds = (size_t)(128 * LD + KT * 48 * LD + 128 * 52) * 4 + (size_t)KT * NPX * 16;
     static std::once_flag once;
     hipError_t attr = hipSuccess;
-    std::call_once(once, [&] { attr = hipFuncSetAttribute((const void*)dgrad_c4_mfma_kernel<KT, WO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+    std::call_once(once, [&] { attr = hipFuncSetAttribute((const void*)dgrad_c4_mfma_kernel<KT, WO, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
     if (attr != hipSuccess) return MCG_ERR_LAUNCH;
     // the rows two neighbouring blocks share are ADDED (two addends, order-independent): x starts from zero
     if (hipMemsetAsync(x, 0, (size_t)g.N * g.Ti * g.Hi * g.Wi * 4 * sizeof(float), s) != hipSuccess) return MCG_ERR_LAUNCH;
-    hipLaunchKernelGGL((dgrad_c4_mfma_kernel<KT, WO>), dim3(g.N * (g.Ho / R)), dim3(512), lds, s, p);
+    hipLaunchKernelGGL((dgrad_c4_mfma_kernel<KT, WO, BF>), dim3(g.N * (g.Ho / R)), dim3(512), lds, s, p);
+    return MCG_OK;
+}
+
+template <int KT, int WO>
+int launch_fprop_c4_bf16(const Geom& g, const float* x, const float* w, const float* bias, float* y, const Epi& e, hipStream_t s) {
+    C4FpropP p;
+    p.g = g; p.e = e; p.x = x; p.w = w; p.bias = bias; p.y = y;
+    p.M = g.N * g.To * g.Ho * g.Wo;
+    constexpr int R = 256 / WO, K = KT * 64;
+    const size_t lds = (size_t)64 * (K + 8) * 2 + (size_t)KT * (2 * R + 2) * (2 * WO + 4) * 8 + 4096;
+    static std::once_flag once[2];
+    hipError_t attr = hipSuccess;
+    const dim3 grid(g.N * (g.Ho / R));
+    if (e.mode & EPI_ACT) {
+        std::call_once(once[0], [&] { attr = hipFuncSetAttribute((const void*)fprop_c4_bf16_kernel<KT, WO, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+        if (attr != hipSuccess) return MCG_ERR_LAUNCH;
+        hipLaunchKernelGGL((fprop_c4_bf16_kernel<KT, WO, 3>), grid, dim3(512), lds, s, p);
+    } else {
+        std::call_once(once[1], [&] { attr = hipFuncSetAttribute((const void*)fprop_c4_bf16_kernel<KT, WO, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+        if (attr != hipSuccess) return MCG_ERR_LAUNCH;
+        hipLaunchKernelGGL((fprop_c4_bf16_kernel<KT, WO, 1>), grid, dim3(512), lds, s, p);
+    }
     return MCG_OK;
 }
 
@@ -1455,6 +1605,12 @@ int launch_fprop(const Geom& g, const float* x, const float* w, const float* bia
     if (splits == 1) p.kchunk = p.K > 0 ? ((p.K + BK - 1) / BK) * BK : BK;
     else if (hipMemsetAsync(y, 0, (size_t)p.M * g.Co * sizeof(float), s) != hipSuccess) return MCG_ERR_LAUNCH;   // the atomics need a cleared y
     dim3 grid((p.M + BM - 1) / BM, (g.Co + BN - 1) / BN, splits);
+    // A filter that does not fit an XCD's 4 MiB L2 next to the activations it is multiplied with: sweep M inside one filter
+    // panel per XCD (measured on D_V's dc3, 8.4 MB filter, 224 x 4 tiles: fabric fetch 1.68 GB -> see profiles/).
+    {
+        static const int force = getenv("MCG_FPROP_MFAST") ? atoi(getenv("MCG_FPROP_MFAST")) : -1;      // (A/B timing only)
+        p.mfast = force >= 0 ? force : (grid.y >= 2 && grid.x >= 16 && (long long)g.w_bytes > (3ll << 20));
+    }
     const int cls = e.mode ? epi_class(e.mode) : 0;
     if (PM == 2 && cls > 1) return MCG_ERR_UNSUPPORTED;
     if constexpr (PM == 0) {
@@ -1629,8 +1785,13 @@ int conv_fprop_impl(const mcg_conv_geom* c, const float* x, const float* w, cons
     const int bk = g.bk;
     if ((t == 0 || t == 6) && c4_fprop_ok(g, e)) {                 // the 3-channel clip padded to 4: weight-stationary kernel
         if (ep) { ep->n_slots = 0; ep->slot_stride = e.slot_stride; }
-        if (g.kt == 4) st = g.Wo == 32 ? launch_fprop_c4<4, 32>(g, x, w, bias, y, e, s) : launch_fprop_c4<4, 16>(g, x, w, bias, y, e, s);
-        else st = g.Wo == 32 ? launch_fprop_c4<1, 32>(g, x, w, bias, y, e, s) : launch_fprop_c4<1, 16>(g, x, w, bias, y, e, s);
+        if (g.prec == MCG_PREC_BF16) {
+            if (g.kt == 4) st = g.Wo == 32 ? launch_fprop_c4_bf16<4, 32>(g, x, w, bias, y, e, s) : launch_fprop_c4_bf16<4, 16>(g, x, w, bias, y, e, s);
+            else st = g.Wo == 32 ? launch_fprop_c4_bf16<1, 32>(g, x, w, bias, y, e, s) : launch_fprop_c4_bf16<1, 16>(g, x, w, bias, y, e, s);
+        } else {
+            if (g.kt == 4) st = g.Wo == 32 ? launch_fprop_c4<4, 32>(g, x, w, bias, y, e, s) : launch_fprop_c4<4, 16>(g, x, w, bias, y, e, s);
+            else st = g.Wo == 32 ? launch_fprop_c4<1, 32>(g, x, w, bias, y, e, s) : launch_fprop_c4<1, 16>(g, x, w, bias, y, e, s);
+        }
         return finish(st);
     }
     if (t == 6) return MCG_ERR_UNSUPPORTED;
@@ -1700,8 +1861,13 @@ int conv_dgrad_impl(const mcg_conv_geom* c, const float* y, const float* w, cons
     int t = g.tile;
     const int bk = g.bk;
     if ((t == 0 || t == 6) && g.prec != MCG_PREC_BF16_STORE && c4_dgrad_mfma_ok(g, e, bias, act, accumulate)) {      // (computes in fp32)
-        if (g.kt == 4) st = g.Wo == 32 ? launch_dgrad_c4_mfma<4, 32>(g, y, w, x, s) : launch_dgrad_c4_mfma<4, 16>(g, y, w, x, s);
-        else st = g.Wo == 32 ? launch_dgrad_c4_mfma<1, 32>(g, y, w, x, s) : launch_dgrad_c4_mfma<1, 16>(g, y, w, x, s);
+        if (g.prec == MCG_PREC_BF16) {                           // bf16 networks: the same kernel on the bf16 MFMA
+            if (g.kt == 4) st = g.Wo == 32 ? launch_dgrad_c4_mfma<4, 32, true>(g, y, w, x, s) : launch_dgrad_c4_mfma<4, 16, true>(g, y, w, x, s);
+            else st = g.Wo == 32 ? launch_dgrad_c4_mfma<1, 32, true>(g, y, w, x, s) : launch_dgrad_c4_mfma<1, 16, true>(g, y, w, x, s);
+        } else {
+            if (g.kt == 4) st = g.Wo == 32 ? launch_dgrad_c4_mfma<4, 32, false>(g, y, w, x, s) : launch_dgrad_c4_mfma<4, 16, false>(g, y, w, x, s);
+            else st = g.Wo == 32 ? launch_dgrad_c4_mfma<1, 32, false>(g, y, w, x, s) : launch_dgrad_c4_mfma<1, 16, false>(g, y, w, x, s);
+        }
         return finish(st);
     }
     if (t == 6) t = 0;                                           // elsewhere the first-layer code means "the kernel written for it"

@@ -634,6 +634,24 @@ def test_weight_stationary_first_layer_kernels(hl, case):
             got = ad.reshape(M, Co).cpu().double().numpy() - np.where(pre >= 0, pre, 0.2 * pre)
             for gi in range(groups):
                 assert np.abs(got[gi * mg:(gi + 1) * mg] - philox.randn_rowquad(mg, Co, 0.2, 5, [11, 12][gi])).max() < 2e-5
+    # bf16 networks: the weight-stationary kernel on the bf16 MFMA, plain and with the first-layer epilogue (bf16 output)
+    for exact in (True, False):
+        x2, W2 = (_bf16_round(x), _bf16_round(W)) if exact else (x, W)
+        y2 = F.conv3d_fwd(x2, W2, b, (1, 2, 2), (0, 1, 1))
+        g = hl.make_geom(N, Ti, H, H, 4, Co, kt, ci_valid=3, precision='bf16')
+        g.tile = 6
+        yd = torch.full((N, g.To, g.Ho, g.Wo, Co), 5.0, device="cuda")
+        hl.conv_fprop(g, lay.act_to_dev(dev(x2)), lay.conv_w_to_dev(dev(W2)), bd, yd)
+        assert rel_l2(lay.act_from_dev(yd, Co), y2) < (FWD_TOL if exact else BF16_TOL), exact
+        if exact:
+            M = N * g.To * g.Ho * g.Wo
+            mask = torch.zeros((M, 2), dtype=torch.int32, device="cuda")
+            a16 = torch.empty((N, g.To, g.Ho, g.Wo, Co), device="cuda", dtype=torch.bfloat16)
+            hl.conv_fprop(g, lay.act_to_dev(dev(x2)), lay.conv_w_to_dev(dev(W2)), bd, a16, must_fuse=True,
+                          ep=hl.epilogue(act=hl.ACT_LRELU, groups=1, mask_out=mask, out_bf16=True))
+            want = torch.tensor(F.leaky_relu_fwd(y2), dtype=torch.float32).to(torch.bfloat16).double().numpy()
+            got = lay.act_from_dev(a16.float(), Co).cpu().double().numpy()
+            assert np.abs(got - want).max() <= 2.0 ** -7 * np.abs(want).max()      # one bf16 ulp at most (fp32 sums rounded once)
     # input gradient: the MFMA col2im kernel (ci_valid = 3, tile 0 / 6) against the oracle; the accumulating call and
     # ci_valid = 0 take the VALU kernel
     gy = rng.randn(*y_ref.shape)
@@ -651,6 +669,17 @@ def test_weight_stationary_first_layer_kernels(hl, case):
         assert torch.equal(again, gxd), "the shared rows are added by two blocks: the sum must not depend on their order"
         hl.conv_dgrad(g, gyd, wd, None, gxd, accumulate=True)
         assert rel_l2(lay.act_from_dev(gxd, Ci), 2 * gx_ref) < BWD_TOL, (tile, cv)
+    # bf16 networks: the same col2im kernel on the bf16 MFMA (y and w rounded on their way into LDS): digit-exact on
+    # bf16-representable operands, within the bf16 tolerance otherwise
+    for exact in (True, False):
+        gy2 = _bf16_round(gy) if exact else gy
+        W2 = _bf16_round(W) if exact else W
+        ref2, _, _ = F.conv3d_bwd(x, W2, gy2, (1, 2, 2), (0, 1, 1))
+        g = hl.make_geom(N, Ti, H, H, 4, Co, kt, ci_valid=3, precision='bf16')
+        gxd = torch.full_like(xd, 7.0)
+        hl.conv_dgrad(g, lay.act_to_dev(dev(gy2)), lay.conv_w_to_dev(dev(W2)), None, gxd)
+        assert rel_l2(lay.act_from_dev(gxd, Ci), ref2) < (BWD_TOL if exact else BF16_TOL), exact
+        assert float(gxd[..., 3].abs().max()) == 0.0
     g = hl.make_geom(2, 5, 16, 16, 8, 64, 4)                  # not a first-layer geometry: the code is refused
     g.tile = 6
     z = torch.zeros(1, device="cuda")
