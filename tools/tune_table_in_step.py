@@ -76,6 +76,8 @@ def main():
             cands = list(hl.TILE_CANDIDATES)
             if k[0] in ('fprop', 'dgrad') and k[5] > 4:
                 cands += list(hl.FPROP_SPLIT_CANDIDATES)
+            if (k[0] == 'dgrad' and 4 < k[5] <= 64) or (k[0] == 'fprop' and k[6] <= 64 and k[5] > 4):
+                cands += [4]                                 # 256 x 64: the widest tile a 64-column output admits
             if k[0] == 'wgrad':                             # more / fewer pixel splits around the current tile
                 cands += [1000 + c for c in hl.TILE_CANDIDATES if c] + [2000 + c for c in hl.TILE_CANDIDATES if c]
             cur = cache[k]
