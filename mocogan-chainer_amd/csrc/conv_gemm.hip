@@ -1516,6 +1516,218 @@ int launch_dgrad_c4_mfma(const Geom& g, const float* y, const float* w, float* x
     return MCG_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// wgrad for Ci == 4 (<= 3 data channels), Co == 64: dw[co][a][kh][kw][ci] += sum_pix y[pix][co] * x[pix @ tap][ci].
+// In the generic kernel this layer is a 64 x 256 output with a K of millions of pixels whose B operand is a 16-byte
+// gather per (pixel, tap); here the INPUT PATCH sits in LDS exactly as in fprop_c4_kernel (a ring of kt frame slabs, each
+// input pixel crosses the fabric about once), the padded channel's columns are dropped (kt * 48 instead of kt * 64) and the
+// 64 x (kt * 48) result stays in registers for the whole block: a block owns R = 256 / Wo output rows, walks frames (and
+// batch items), and its 8 waves split the PIXELS (the K axis) four ways and the columns two ways -- so y needs no LDS at
+// all: the MFMA A operand (co = 2 li + q of pixel 2 i + lh) is one 8-byte global load per lane and pixel pair, fetched
+// eight pairs ahead.  B operand: lane (li, lh) reads column nb * 32 + li = (tap, ci) of pixel 2 i + lh from the patch --
+// lane base + immediate.  At the end the four partial results are added in LDS (ds_add_f32) and the block adds its
+// 64 x (kt * 48) sums onto dw with float atomics, as WgradP does.
+// ------------------------------------------------------------------------------------------
+// compiler-only fence (no instruction): memory operations stay on their side of it
+#define MCG_WFENCE() asm volatile("" ::: "memory")
+struct C4WgradP {
+    Geom g;
+    const float* x; const float* y; float* dw;
+    int nsplit, tsplit;          // gridDim.x = hblocks * nsplit * tsplit: batch items n0, n0 + nsplit, ..; frames [t0, t1) of each
+};
+
+template <int KT, int WO>
+__global__ __launch_bounds__(512) void wgrad_c4_kernel(C4WgradP p) {
+    constexpr int BM = 256, K = KT * 64;
+    constexpr int R = BM / WO, PR = 2 * R + 2, WI = 2 * WO;
+    constexpr int PLANE = (WO + 2) * 16, ROW = 2 * PLANE, SLAB = PR * ROW;             // bytes (layout of fprop_c4_kernel)
+    constexpr int ENT = 2 * (WO + 2), NLD = (PR * ENT + 511) / 512;
+    constexpr int RING = KT + 1;                 // one slab more than a step reads: the next frame is written while this step runs
+    constexpr int NCOL = KT * 48, NB = (NCOL + 31) / 32, NC = NB * 32;                  // data columns; 32-column MFMA blocks
+    static_assert(64 * NC * 4 <= RING * SLAB, "the reduction buffer reuses the patch ring");
+    static_assert(NLD <= 4, "one slab chunk per quarter step");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* pl = smem;                                  // RING * SLAB
+    float* red = reinterpret_cast<float*>(smem);               // [64][NC] after the last step
+    const Geom& g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int hblocks = g.Ho / R;
+    const int hb = blockIdx.x % hblocks, rest = blockIdx.x / hblocks;
+    const int n0 = rest % p.nsplit, ts = rest / p.nsplit, ho0 = hb * R;
+    const int tper = (g.To + p.tsplit - 1) / p.tsplit, t0 = ts * tper, t1 = t0 + tper < g.To ? t0 + tper : g.To;
+    const __amdgpu_buffer_rsrc_t xr = make_srd(p.x, g.x_bytes);
+    const u32 fbytes = (u32)g.Hi * WI * 16u;
+
+    // ---- patch slabs (layout of fprop_c4_kernel): chunk j = entries tid + 512 j; addresses are recomputed per use so that
+    // nothing but the 16 bytes in flight stays in registers across the MFMAs
+    // (entries beyond the patch are clamped to its last entry: the same value written twice instead of a branch)
+    auto chunk_load = [&](int j, int n, int t, bool live) -> f32x4 {
+        int tq = tid;
+        asm volatile("" : "+v"(tq));                           // (keeps the address arithmetic where it is used)
+        int idx = tq + 512 * j;
+        idx = idx < PR * ENT ? idx : PR * ENT - 1;
+        const int pr = idx / ENT, en = idx - pr * ENT;
+        const int hi = 2 * ho0 - 1 + pr, wi = en - 1;
+        const bool ok = live && (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)WI;
+        return bload(xr, ok ? (u32)(hi * WI + wi) * 16u + (u32)(n * g.Ti + t) * fbytes : OOB);
+    };
+    auto chunk_store = [&](int j, int slot, const f32x4& v) {
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
+        int idx = tq + 512 * j;
+        idx = idx < PR * ENT ? idx : PR * ENT - 1;
+        const int pr = idx / ENT, en = idx - pr * ENT;
+        *reinterpret_cast<f32x4*>(pl + slot * SLAB + pr * ROW + (en & 1) * PLANE + (en >> 1) * 16) = v;
+    };
+
+    // ---- work split: wave pair gq = wave >> 1 takes pixels 64 gq .. 64 gq + 63 of every step (32 pairs of the MFMA's
+    // K = 2); within the pair, wave & 1 takes one half of the column blocks -- 2 x NBW accumulators per lane
+    constexpr int NBW = NB / 2, NP = 32;
+    static_assert(NB % 2 == 0, "column blocks split over two waves");
+    const int gq = wave >> 1, nb0 = (wave & 1) * NBW;
+    // lane constants of the B reads: column (nb0 + k) * 32 + li -> (a, kh, kw, ci); pixel pair i -> immediate
+    int bl[NBW], ta[NBW];
+#pragma unroll
+    for (int k = 0; k < NBW; ++k) {
+        const int col = (nb0 + k) * 32 + li, ok = col < NCOL;
+        const int tap = ok ? col / 3 : 0, ci = ok ? col - tap * 3 : 0;
+        const int kh = (tap >> 2) & 3, kw = tap & 3;
+        ta[k] = tap >> 4;
+        bl[k] = kh * ROW + (kw & 1) * PLANE + (kw >> 1) * 16 + ci * 4 + lh * 16 +
+                (WO == 32 ? 4 * gq * ROW : 8 * gq * ROW);                // the wave pair's first output row
+    }
+    auto pixoff = [](int i) { return WO == 32 ? (i >> 4) * 2 * ROW + (i & 15) * 32 : (i >> 3) * 2 * ROW + (i & 7) * 32; };
+
+    f32x16 acc[2][NBW];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int k = 0; k < NBW; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][k][r] = 0.f;
+
+    // y of a step: pixel pair i of this wave pair = rows m0 + 64 gq + 2 i + lh, channels 2 li, 2 li + 1.  PF pairs are in
+    // flight: pair i's registers are refilled with pair i + PF (of this step, or of the next one) right after its MFMAs.
+    constexpr int PF = 8;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2* ylane = reinterpret_cast<const f32x2*>(p.y) + ((gq * 64 + lh) * 64 + 2 * li) / 2;
+    auto y_pair = [&](int n, int to, int i) -> f32x2 {
+        const long long m0 = ((long long)(n * g.To + to) * g.Ho + ho0) * WO;
+        return ylane[m0 * 32 + i * 64];
+    };
+    f32x2 yq[PF];
+    int sb[NBW];
+    if (n0 < g.N && t0 < t1) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) yq[i] = y_pair(n0, t0, i);
+    }
+    int item = 0;                                              // 2-D layers: item i of this block lives in slot i % 2
+    for (int n = n0; n < g.N; n += p.nsplit, ++item) {
+        // frames t0 .. t0 + kt - 1 of this batch item (2-D: only the block's first item; the others arrive during the previous step)
+        if (KT > 1 || item == 0) {
+            if (KT > 1) __syncthreads();                       // the previous item's last step may still read the ring
+#pragma unroll
+            for (int a = 0; a < KT; ++a) {
+                f32x4 fr[NLD];
+#pragma unroll
+                for (int j = 0; j < NLD; ++j) fr[j] = chunk_load(j, n, t0 + a, true);
+#pragma unroll
+                for (int j = 0; j < NLD; ++j) chunk_store(j, KT > 1 ? (t0 + a) % RING : 0, fr[j]);
+            }
+            __syncthreads();
+        }
+        for (int to = t0; to < t1; ++to) {
+            // the slab this step adds: frame to + kt of this item, or (2-D) the next item's frame
+            const bool more = KT > 1 ? to + KT < g.Ti && to + 1 < t1 : n + p.nsplit < g.N;
+            const int nslot = KT > 1 ? (to + KT) % RING : (item + 1) & 1;
+            const int ln = KT > 1 ? n : n + p.nsplit, lt = KT > 1 ? to + KT : 0;
+            const int s0 = KT > 1 ? to % RING : item & 1;
+#pragma unroll
+            for (int k = 0; k < NBW; ++k) {
+                int sl = s0 + (KT > 1 ? ta[k] : 0);
+                sl = sl >= RING ? sl - RING : sl;
+                sb[k] = sl * SLAB + bl[k];
+            }
+            // the step after this one (its first PF pixel pairs are fetched during this step's last PF); past the end the
+            // loads repeat this step's -- no branch anywhere in the step
+            const bool last_t = to + 1 >= t1;
+            const bool nxt = last_t ? n + p.nsplit < g.N : true;
+            const int nn = nxt ? (last_t ? n + p.nsplit : n) : n, nto = nxt ? (last_t ? t0 : to + 1) : to;
+            // without a slab to add (`more` false) the loads return zeros and the stores fill the ring's free slot with them
+            f32x4 st;
+            float bv[2][NBW];
+#pragma unroll
+            for (int k = 0; k < NBW; ++k) bv[0][k] = *reinterpret_cast<const float*>(pl + sb[k] + pixoff(0));
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                // (fences around the global loads: left alone the compiler sinks each of them to just above its first use
+                // and the wave waits out the memory latency there.  Between two fences: the B reads of pair i + 1, then
+                // the MFMAs of pair i.)
+                if (i % 10 == 0 && i / 10 < NLD) { st = chunk_load(i / 10, ln, lt, more); MCG_WFENCE(); }
+                if (i + 1 < NP) {
+#pragma unroll
+                    for (int k = 0; k < NBW; ++k) bv[(i + 1) & 1][k] = *reinterpret_cast<const float*>(pl + sb[k] + pixoff(i + 1));
+                }
+#pragma unroll
+                for (int k = 0; k < NBW; ++k) {
+                    acc[0][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(yq[i % PF][0], bv[i & 1][k], acc[0][k], 0, 0, 0);
+                    acc[1][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(yq[i % PF][1], bv[i & 1][k], acc[1][k], 0, 0, 0);
+                }
+                MCG_WFENCE();
+                yq[i % PF] = i + PF < NP ? y_pair(n, to, i + PF) : y_pair(nn, nto, i + PF - NP);
+                MCG_WFENCE();
+                if (i % 10 == 9 && i / 10 < NLD) { chunk_store(i / 10, nslot, st); MCG_WFENCE(); }
+            }
+            __syncthreads();                                   // the new slab is complete; every wave is done with frame `to`
+        }
+    }
+
+    // ---- partial results of the four pixel groups -> LDS -> dw
+    for (int i = tid; i < 64 * NC; i += 512) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int k = 0; k < NBW; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;                 // C/D layout: row = MFMA A index = li of the y load
+                __hip_atomic_fetch_add(&red[(2 * row + q) * NC + (nb0 + k) * 32 + li], acc[q][k][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+    __syncthreads();
+    for (int i = tid; i < 64 * NCOL; i += 512) {
+        const int co = i / NCOL, col = i - co * NCOL, tap = col / 3, ci = col - tap * 3;
+        atomicAdd(p.dw + (long long)co * K + tap * 4 + ci, red[co * NC + col]);
+    }
+}
+
+bool c4_wgrad_ok(const Geom& g) {
+    const long long frame = (long long)g.Ti * g.Hi * g.Wi * g.Ci;
+    return g.Ci == 4 && g.cv <= 3 && g.Co == 64 && (g.Wo == 32 || g.Wo == 16) && g.Ho % (256 / g.Wo) == 0 && !g.perm_n &&
+           g.xs0 == frame && g.prec == MCG_PREC_F32;
+}
+
+template <int KT, int WO>
+int launch_wgrad_c4(const Geom& g, const float* x, const float* y, float* dw, hipStream_t s) {
+    C4WgradP p;
+    p.g = g; p.x = x; p.y = y; p.dw = dw;
+    constexpr int R = 256 / WO;
+    const size_t lds = (size_t)(KT + 1) * (2 * R + 2) * 2 * (WO + 2) * 16;
+    static std::once_flag once;
+    hipError_t attr = hipSuccess;
+    std::call_once(once, [&] { attr = hipFuncSetAttribute((const void*)wgrad_c4_kernel<KT, WO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+    if (attr != hipSuccess) return MCG_ERR_LAUNCH;
+    // one block per CU: (row block, batch item) pairs; with fewer than 256 of them the frames of an item are split as well
+    // (each part re-reads kt - 1 frames), with more a block walks several items (every block ends in 64 x kt * 48 atomics)
+    const int hblocks = g.Ho / R;
+    p.nsplit = g.N; p.tsplit = 1;
+    if (hblocks * p.nsplit > 512) p.nsplit = 512 / hblocks > 0 ? 512 / hblocks : 1;
+    while (hblocks * p.nsplit * p.tsplit < 256 && 2 * p.tsplit * 2 <= g.To) p.tsplit *= 2;        // >= 2 steps per part
+    hipLaunchKernelGGL((wgrad_c4_kernel<KT, WO>), dim3(hblocks * p.nsplit * p.tsplit), dim3(512), lds, s, p);
+    return MCG_OK;
+}
+
 template <int KT, int WO>
 int launch_fprop_c4_bf16(const Geom& g, const float* x, const float* w, const float* bias, float* y, const Epi& e, hipStream_t s) {
     C4FpropP p;
@@ -1910,6 +2122,15 @@ extern "C" int mcg_conv_wgrad(const mcg_conv_geom* c, const float* x, const floa
     int Kf = g.taps * g.Ci;
     int t = g.tile;
     const int bk = g.bk;
+    // the 3-channel clip padded to 4: patch-in-LDS kernel.  Only on request (tile code 6): measured on the MI355X it equals the
+    // generic kernel on D_V's first layer at 64 clips (0.250 ms) and loses below that -- its steps run at the MFMA rate, but all
+    // blocks finish together and their 64 x kt * 48 device-scope atomics each (~80 us) are not hidden behind other blocks' work
+    if (t == 6 && c4_wgrad_ok(g)) {
+        if (g.kt == 4) st = g.Wo == 32 ? launch_wgrad_c4<4, 32>(g, x, y, dw, s) : launch_wgrad_c4<4, 16>(g, x, y, dw, s);
+        else st = g.Wo == 32 ? launch_wgrad_c4<1, 32>(g, x, y, dw, s) : launch_wgrad_c4<1, 16>(g, x, y, dw, s);
+        return finish(st);
+    }
+    if (t == 6) return MCG_ERR_UNSUPPORTED;
     if (!t) t = (g.Co <= 64 || Kf <= 64) ? 3 : 1;
     const bool bk64 = bk ? bk == 64 : g.prec != MCG_PREC_F32;
     MCG_DISPATCH(launch_wgrad, t, bk64, g.prec, g, x, y, dw, s);

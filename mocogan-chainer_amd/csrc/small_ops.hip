@@ -412,6 +412,28 @@ __global__ __launch_bounds__(NT) void fc_dgrad_kernel(int K, int Co, const float
     *reinterpret_cast<f32x4*>(x + (long long)m * K + k) = s;
 }
 
+// the same for R rows per thread: each filter value is loaded once for R outputs (G's dc1: 512 rows x 60 inputs -> 8192)
+template <int R>
+__global__ __launch_bounds__(NT) void fc_dgrad_rows_kernel(int K, int Co, const float* __restrict__ y, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, int bias_period, float* __restrict__ x) {
+    const int m0 = blockIdx.y * R;
+    const int k = (blockIdx.x * NT + threadIdx.x) * 4;
+    if (k >= K) return;
+    f32x4 s[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) s[r] = f32x4{0, 0, 0, 0};
+    const float* yr = y + (long long)m0 * Co;
+    for (int co = 0; co < Co; ++co) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (long long)co * K + k);
+#pragma unroll
+        for (int r = 0; r < R; ++r) s[r] += yr[r * Co + co] * wv;
+    }
+    f32x4 b = {0, 0, 0, 0};
+    if (bias) b = *reinterpret_cast<const f32x4*>(bias + (k % bias_period));
+#pragma unroll
+    for (int r = 0; r < R; ++r) *reinterpret_cast<f32x4*>(x + (long long)(m0 + r) * K + k) = s[r] + b;
+}
+
 __global__ __launch_bounds__(NT) void fc_wgrad_kernel(int M, int K, int Co, const float* __restrict__ x, const float* __restrict__ y,
                                                       float* __restrict__ dw, float* db) {
     const int co = blockIdx.y;
@@ -432,6 +454,7 @@ __global__ __launch_bounds__(NT) void fc_wgrad_kernel(int M, int K, int Co, cons
 // GRU (Chainer StatelessGRU): thread = (sample, hidden unit); 16 samples x 16 units per block
 // ------------------------------------------------------------------------------------------
 constexpr int GRU_S = 16, GRU_U = 16, GRU_MAXIN = 32, GRU_MAXP = 6 * (GRU_U * GRU_MAXIN + GRU_U);
+constexpr int GRU_T = 16;            // steps whose per-step inputs are prefetched into registers (video_len of the reference)
 
 struct GruOff { int w[6]; int b[6]; int in[6]; int total; };
 __host__ __device__ inline GruOff gru_offsets(int dim_zm, int dim_zl) {
@@ -457,10 +480,11 @@ __global__ __launch_bounds__(GRU_S * GRU_U) void gru_fwd_kernel(int N, int T, in
     // weights are kept TRANSPOSED in LDS ([input][unit]): the 16 lanes of a sample read 16 consecutive words per input
     // instead of 16 words a row apart (an 8-way bank conflict on every one of the ~60 reads of a step)
     for (int i = threadIdx.x; i < o.total; i += blockDim.x) {
-        int k = 5;
-        while (k > 0 && i < o.w[k]) --k;                       // which link
-        const int r = i - o.w[k], wsz = dz * o.in[k];
-        P[r < wsz ? o.w[k] + (r % o.in[k]) * dz + r / o.in[k] : i] = params[i];        // biases keep their place
+        int wk = o.w[0], ink = o.in[0];                        // which link (static indices: `o` stays in registers)
+#pragma unroll
+        for (int q = 1; q < 6; ++q) if (i >= o.w[q]) { wk = o.w[q]; ink = o.in[q]; }
+        const int r = i - wk, wsz = dz * ink;
+        P[r < wsz ? wk + (r % ink) * dz + r / ink : i] = params[i];        // biases keep their place
     }
     const int s = threadIdx.x / GRU_U, j = threadIdx.x % GRU_U;
     const int n = blockIdx.x * GRU_S + s;
@@ -471,9 +495,14 @@ __global__ __launch_bounds__(GRU_S * GRU_U) void gru_fwd_kernel(int N, int T, in
         for (int c = j; c < dl; c += GRU_U) xs[s][c] = (c == labels[n]) ? 1.f : 0.f;
         for (int t = 0; t < T; ++t) for (int c = j; c < dc; c += GRU_U) z[((long long)t * N + n) * zw + c] = zc[n * dc + c];
     }
+    // the noise inputs of the first GRU_T steps are fetched up front: a load per step would put a memory round trip
+    // into each link of the 16-step dependency chain
+    float ev[GRU_T];
+#pragma unroll
+    for (int t = 0; t < GRU_T; ++t) ev[t] = (live && t < T) ? e[((long long)t * N + n) * dz + j] : 0.f;
     __syncthreads();
-    for (int t = 0; t < T; ++t) {
-        if (live) xs[s][dl + j] = e[((long long)t * N + n) * dz + j];
+    auto step = [&](int t, float e_t) {
+        if (live) xs[s][dl + j] = e_t;
         __syncthreads();
         float r = 0, zz = 0, hb = 0, h = 0;
         if (live) {
@@ -504,7 +533,10 @@ __global__ __launch_bounds__(GRU_S * GRU_U) void gru_fwd_kernel(int N, int T, in
             hs[s][j] = hn;
         }
         __syncthreads();
-    }
+    };
+#pragma unroll
+    for (int t = 0; t < GRU_T; ++t) if (t < T) step(t, ev[t]);
+    for (int t = GRU_T; t < T; ++t) step(t, live ? e[((long long)t * N + n) * dz + j] : 0.f);
 }
 
 __global__ __launch_bounds__(GRU_S * GRU_U) void gru_bwd_kernel(int N, int T, int dz, int dl, int dc, const float* __restrict__ params,
@@ -527,14 +559,27 @@ __global__ __launch_bounds__(GRU_S * GRU_U) void gru_bwd_kernel(int N, int T, in
     for (int c = 0; c < GRU_MAXIN; ++c) { gW[0][c] = 0.f; gW[1][c] = 0.f; gW[2][c] = 0.f; }
 #pragma unroll
     for (int c = 0; c < GRU_U; ++c) { gU[0][c] = 0.f; gU[1][c] = 0.f; gU[2][c] = 0.f; }
+    struct In { float r, zz, hb, h, e, gz; };
+    auto fetch = [&](int t) {
+        In v = {0, 0, 0, 0, 0, 0};
+        if (live && t < T) {
+            const float* sv = saved + ((long long)t * N + n) * 4 * dz;
+            v.r = sv[j]; v.zz = sv[dz + j]; v.hb = sv[2 * dz + j]; v.h = sv[3 * dz + j];
+            v.e = e[((long long)t * N + n) * dz + j];
+            v.gz = gz[((long long)t * N + n) * zw + dc + j];
+        }
+        return v;
+    };
+    In pre[GRU_T];                                  // as in gru_fwd_kernel: no load inside the dependency chain
+#pragma unroll
+    for (int t = 0; t < GRU_T; ++t) pre[t] = fetch(t);
     __syncthreads();
-    for (int t = T - 1; t >= 0; --t) {
+    auto step = [&](int t, const In& v) {
         float r = 0, zz = 0, hb = 0, h = 0, ga = 0, gaz = 0, ghn = 0;
         if (live) {
-            const float* sv = saved + ((long long)t * N + n) * 4 * dz;
-            r = sv[j]; zz = sv[dz + j]; hb = sv[2 * dz + j]; h = sv[3 * dz + j];
-            xs[s][dl + j] = e[((long long)t * N + n) * dz + j];
-            ghn = gh + gz[((long long)t * N + n) * zw + dc + j];
+            r = v.r; zz = v.zz; hb = v.hb; h = v.h;
+            xs[s][dl + j] = v.e;
+            ghn = gh + v.gz;
             float gzz = ghn * (hb - h), ghb = ghn * zz;
             ga = ghb * (1.f - hb * hb);
             gaz = gzz * zz * (1.f - zz);
@@ -572,7 +617,10 @@ __global__ __launch_bounds__(GRU_S * GRU_U) void gru_bwd_kernel(int N, int T, in
             gb[0] += ga; gb[1] += gaz; gb[2] += gar;
         }
         __syncthreads();
-    }
+    };
+    for (int t = T - 1; t >= GRU_T; --t) step(t, fetch(t));
+#pragma unroll
+    for (int t = GRU_T - 1; t >= 0; --t) if (t < T) step(t, pre[t]);
     if (live) {                                    // one LDS reduction over the block's samples
 #pragma unroll
         for (int c = 0; c < GRU_MAXIN; ++c)
@@ -912,7 +960,10 @@ extern "C" int mcg_fc_fprop(int M, int K, int Co, const float* x, const float* w
 extern "C" int mcg_fc_dgrad(int M, int K, int Co, const float* y, const float* w, const float* bias, int bias_period, float* x, void* stream) {
     if (!x || !w || !y || M <= 0 || K <= 0 || (K & 3) || Co <= 0) return MCG_ERR_BAD_ARG;
     if (bias && (bias_period <= 0 || (bias_period & 3) || K % bias_period)) return MCG_ERR_BAD_ARG;
-    hipLaunchKernelGGL(fc_dgrad_kernel, dim3((K / 4 + NT - 1) / NT, M), dim3(NT), 0, (hipStream_t)stream, K, Co, y, w, bias, bias_period, x);
+    if (Co >= 8 && M % 8 == 0 && M >= 64)
+        hipLaunchKernelGGL(fc_dgrad_rows_kernel<8>, dim3((K / 4 + NT - 1) / NT, M / 8), dim3(NT), 0, (hipStream_t)stream, K, Co, y, w, bias, bias_period, x);
+    else
+        hipLaunchKernelGGL(fc_dgrad_kernel, dim3((K / 4 + NT - 1) / NT, M), dim3(NT), 0, (hipStream_t)stream, K, Co, y, w, bias, bias_period, x);
     return launch_status();
 }
 

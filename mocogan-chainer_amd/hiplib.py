@@ -299,6 +299,8 @@ def _tuned(kind, g, extra, out_side, run_on):
             cands = TILE_CANDIDATES
             if (kind == "dgrad" and 4 < g.Ci <= 64) or (kind == "fprop" and g.Co <= 64 and g.Ci > 4):
                 cands = cands + (4,)                                # 256 x 64: the widest tile a 64-column output admits
+            if kind == "wgrad" and g.Ci == 4:
+                cands = cands + (6,)                                # patch-in-LDS kernel (also what tile 0 selects when it applies)
             out_elems = g.N * g.To * g.Ho * g.Wo * g.Co if kind == "fprop" else g.N * g.Ti * g.Hi * g.Wi * g.Ci
             if kind in ("fprop", "dgrad") and g.Ci > 4 and out_elems <= (1 << (23 if kind == "fprop" else 25)):
                 cands = cands + FPROP_SPLIT_CANDIDATES          # <= 1024 tiles of 64x64: K splits can fill the CUs

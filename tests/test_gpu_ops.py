@@ -593,6 +593,7 @@ C4_CASES = [
     (3, 1, 32, 1),       # 2-D
     (2, 5, 64, 4),       # Wo = 32: four blocks per batch item
     (2, 1, 64, 1),
+    (150, 1, 64, 1),     # more (row block, batch item) pairs than blocks: a block of the weight-gradient kernel walks two items
 ]
 
 
@@ -680,6 +681,22 @@ def test_weight_stationary_first_layer_kernels(hl, case):
         hl.conv_dgrad(g, lay.act_to_dev(dev(gy2)), lay.conv_w_to_dev(dev(W2)), None, gxd)
         assert rel_l2(lay.act_from_dev(gxd, Ci), ref2) < (BWD_TOL if exact else BF16_TOL), exact
         assert float(gxd[..., 3].abs().max()) == 0.0
+    # weight gradient: the patch-in-LDS kernel (ci_valid = 3, tile 6, fp32) accumulates onto dw like the generic one
+    # (tiles 0 and 3; ci_valid = 0); the padded channel's gradient stays exactly zero
+    _, gW_ref, _ = F.conv3d_bwd(x, W, gy, (1, 2, 2), (0, 1, 1))
+    for tile, cv in ((6, 3), (0, 3), (3, 3), (0, 0)):
+        g = hl.make_geom(N, Ti, H, H, 4, Co, kt, ci_valid=cv)
+        g.tile = tile
+        dwd = torch.zeros_like(wd)
+        hl.conv_wgrad(g, xd, gyd, dwd)
+        assert rel_l2(lay.conv_w_from_dev(dwd, Ci, 3), gW_ref) < BWD_TOL, (tile, cv)
+        assert float(dwd[..., 3].abs().max()) == 0.0
+        hl.conv_wgrad(g, xd, gyd, dwd)
+        assert rel_l2(lay.conv_w_from_dev(dwd, Ci, 3), 2 * gW_ref) < BWD_TOL, (tile, cv)
+    g = hl.make_geom(N, Ti, H, H, 4, Co, kt, ci_valid=3, precision='bf16')     # bf16 networks: no such kernel, the code is refused
+    g.tile = 6
+    with pytest.raises(hl.McgError):
+        hl.conv_wgrad(g, xd, gyd, torch.zeros_like(wd))
     g = hl.make_geom(2, 5, 16, 16, 8, 64, 4)                  # not a first-layer geometry: the code is refused
     g.tile = 6
     z = torch.zeros(1, device="cuda")
