@@ -70,7 +70,7 @@ typedef struct mcg_conv_geom {
     int32_t x_perm_n;
     int32_t precision;         /* MCG_PREC_F32 or MCG_PREC_BF16 */
     int32_t tile;              /* GEMM block tile for this call: 0 = library heuristic; 1 = 128x128, 2 = 128x64,
-                                * 3 = 64x64, 4 = 256x64, 5 = 64x256 (the last two always with K-steps of 32);
+                                * 3 = 64x64, 4 = 256x64, 5 = 64x256 (the last two with K-steps of 32 in fp32 mode);
                                 * 6 = the patch-in-LDS kernels of the Ci = 4, Co = 64 layers (refused elsewhere; what
                                 * tile 0 picks for those layers in fprop / dgrad; in wgrad, fp32 only, by request only);
                                 * +100 / +200 also fixes the K-step depth to 32 / 64; +1000 / +2000

@@ -126,8 +126,6 @@ struct FpropP {
     Epi e;
     const float* x; const float* w; const float* bias; float* y;
     int M, K;
-    int mfast;          // tile order inside an XCD: 1 = M tile fastest (one filter panel resident in L2), 0 = N tile fastest
-    __device__ bool m_fastest() const { return mfast != 0; }
     int kchunk;         // K range of one blockIdx.z (multiple of BK; == K without split-K)
     int zz;             // this block's K split; with more than one split the partial tiles are added atomically
                         // onto a zeroed y (mcg_conv_fprop clears it) and split 0 contributes the bias
@@ -430,7 +428,6 @@ template <int BM, int BN, int BK>
 struct FcFpropP {
     static constexpr bool HAS_EPI = false;
     static constexpr int E = 4;
-    __device__ bool m_fastest() const { return false; }
     static constexpr bool A_KC = true, B_KC = true;
     static constexpr int ORDER = 0;
     static constexpr int NA = BM * BK / 4 / NTHREADS, NB = BN * BK / 4 / NTHREADS;
@@ -667,10 +664,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(P p) {
         const int xcd = L & 7, q = nwg >> 3, r = nwg & 7;
         const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
         if constexpr (P::ORDER == 0) {  // fprop: N tile fastest, then M tile (same activations, next filters), then K split;
-            // or (m_fastest) each XCD keeps ONE filter panel in its L2 and sweeps the M tiles: layers whose filter is
-            // larger than an L2 would otherwise stream the whole filter from the fabric once per M tile
-            if (p.m_fastest()) { bx = t % gx; by = (t / gx) % gy; bz = t / (gy * gx); }
-            else { by = t % gy; bx = (t / gy) % gx; bz = t / (gy * gx); }
+            // (the other order -- every XCD sweeping the M tiles of ONE filter panel -- was measured in round 2 on the layers
+            // whose filter exceeds an L2: same time, and MORE fabric traffic, dc3 1.68 -> 2.55 GB, dc4 0.26 -> 0.86 GB)
+            by = t % gy; bx = (t / gy) % gx; bz = t / (gy * gx);
         } else if constexpr (P::ORDER == 1) {
             // dgrad: (M tile, N tile) pairs are dealt round-robin over the XCDs in dispatch order -- rows are time-major
             // and blocks near the temporal boundary skip most K-steps, so a contiguous range per XCD would give the
@@ -866,8 +862,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(P p) {
         const int xcd = L & 7, q = nwg >> 3, r = nwg & 7;
         const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
         if constexpr (P::ORDER == 0) {
-            if (p.m_fastest()) { bx = t % gx; by = (t / gx) % gy; bz = t / (gy * gx); }
-            else { by = t % gy; bx = (t / gy) % gx; bz = t / (gy * gx); }
+            by = t % gy; bx = (t / gy) % gx; bz = t / (gy * gx);
         } else if constexpr (P::ORDER == 1) {
 #ifndef MCG_NO_CLASS_ADJ
             const int Lb = blockIdx.x, xq = Lb & 7, qq = Lb >> 3;
@@ -1817,12 +1812,6 @@ int launch_fprop(const Geom& g, const float* x, const float* w, const float* bia
     if (splits == 1) p.kchunk = p.K > 0 ? ((p.K + BK - 1) / BK) * BK : BK;
     else if (hipMemsetAsync(y, 0, (size_t)p.M * g.Co * sizeof(float), s) != hipSuccess) return MCG_ERR_LAUNCH;   // the atomics need a cleared y
     dim3 grid((p.M + BM - 1) / BM, (g.Co + BN - 1) / BN, splits);
-    // A filter that does not fit an XCD's 4 MiB L2 next to the activations it is multiplied with: sweep M inside one filter
-    // panel per XCD (measured on D_V's dc3, 8.4 MB filter, 224 x 4 tiles: fabric fetch 1.68 GB -> see profiles/).
-    {
-        static const int force = getenv("MCG_FPROP_MFAST") ? atoi(getenv("MCG_FPROP_MFAST")) : -1;      // (A/B timing only)
-        p.mfast = force >= 0 ? force : (grid.y >= 2 && grid.x >= 16 && (long long)g.w_bytes > (3ll << 20));
-    }
     const int cls = e.mode ? epi_class(e.mode) : 0;
     if (PM == 2 && cls > 1) return MCG_ERR_UNSUPPORTED;
     if constexpr (PM == 0) {
@@ -1907,8 +1896,8 @@ int launch_wgrad(const Geom& g, const float* x, const float* y, float* dw, hipSt
     do {                                                                \
         if ((t) == 1) st = fn<128, 128, BK, BF>(__VA_ARGS__);           \
         else if ((t) == 2) st = fn<128, 64, BK, BF>(__VA_ARGS__);       \
-        else if ((t) == 4) st = fn<256, 64, 32, BF>(__VA_ARGS__);       \
-        else if ((t) == 5) st = fn<64, 256, 32, BF>(__VA_ARGS__);       \
+        else if ((t) == 4) st = fn<256, 64, (BF) ? BK : 32, BF>(__VA_ARGS__);   /* fp32: 64-deep K-steps of the long tiles */ \
+        else if ((t) == 5) st = fn<64, 256, (BF) ? BK : 32, BF>(__VA_ARGS__);   /* would not fit the 64 KiB of static LDS     */ \
         else st = fn<64, 64, BK, BF>(__VA_ARGS__);                      \
     } while (0)
 #endif

@@ -423,7 +423,8 @@ __global__ __launch_bounds__(NT) void fc_dgrad_rows_kernel(int K, int Co, const 
 #pragma unroll
     for (int r = 0; r < R; ++r) s[r] = f32x4{0, 0, 0, 0};
     const float* yr = y + (long long)m0 * Co;
-    for (int co = 0; co < Co; ++co) {
+#pragma unroll 4
+    for (int co = 0; co < Co; ++co) {                           // (unrolled: four filter loads in flight)
         const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (long long)co * K + k);
 #pragma unroll
         for (int r = 0; r < R; ++r) s[r] += yr[r * Co + co] * wv;
@@ -454,7 +455,6 @@ __global__ __launch_bounds__(NT) void fc_wgrad_kernel(int M, int K, int Co, cons
 // GRU (Chainer StatelessGRU): thread = (sample, hidden unit); 16 samples x 16 units per block
 // ------------------------------------------------------------------------------------------
 constexpr int GRU_S = 16, GRU_U = 16, GRU_MAXIN = 32, GRU_MAXP = 6 * (GRU_U * GRU_MAXIN + GRU_U);
-constexpr int GRU_T = 16;            // steps whose per-step inputs are prefetched into registers (video_len of the reference)
 
 struct GruOff { int w[6]; int b[6]; int in[6]; int total; };
 __host__ __device__ inline GruOff gru_offsets(int dim_zm, int dim_zl) {
@@ -470,63 +470,77 @@ __host__ __device__ inline GruOff gru_offsets(int dim_zm, int dim_zl) {
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 0.5f * tanhf(0.5f * v) + 0.5f; }
 
+// Both kernels keep the weight rows / columns a thread needs in REGISTERS (zero beyond the real sizes, as are the LDS
+// vectors they multiply: the padded products add +0 and the loops have compile-time bounds) -- with the weights in LDS and
+// run-time loop bounds every step was a chain of ~90 dependent LDS reads (3 us per step, measured).
+template <int IN_MAX>
 __global__ __launch_bounds__(GRU_S * GRU_U) void gru_fwd_kernel(int N, int T, int dz, int dl, int dc, const float* __restrict__ params,
                                                                 const float* __restrict__ h0, const float* __restrict__ e,
                                                                 const int32_t* __restrict__ labels, const float* __restrict__ zc,
                                                                 float* __restrict__ z, float* __restrict__ saved) {
-    __shared__ float P[GRU_MAXP];
-    __shared__ float xs[GRU_S][GRU_MAXIN + 1], hs[GRU_S][GRU_U + 1], rhs[GRU_S][GRU_U + 1];     // (+1: the 4 samples of a wave on 4 banks)
+    __shared__ float xs[GRU_S][IN_MAX + 4], hs[GRU_S][GRU_U + 4], rhs[GRU_S][GRU_U + 4];
     const GruOff o = gru_offsets(dz, dl);
-    // weights are kept TRANSPOSED in LDS ([input][unit]): the 16 lanes of a sample read 16 consecutive words per input
-    // instead of 16 words a row apart (an 8-way bank conflict on every one of the ~60 reads of a step)
-    for (int i = threadIdx.x; i < o.total; i += blockDim.x) {
-        int wk = o.w[0], ink = o.in[0];                        // which link (static indices: `o` stays in registers)
-#pragma unroll
-        for (int q = 1; q < 6; ++q) if (i >= o.w[q]) { wk = o.w[q]; ink = o.in[q]; }
-        const int r = i - wk, wsz = dz * ink;
-        P[r < wsz ? wk + (r % ink) * dz + r / ink : i] = params[i];        // biases keep their place
-    }
     const int s = threadIdx.x / GRU_U, j = threadIdx.x % GRU_U;
     const int n = blockIdx.x * GRU_S + s;
     const bool live = n < N && j < dz;
     const int in = dz + dl, zw = dc + dz;
+    // row j of W_r, W_z, W (x side) and of U_r, U_z, U (h side); biases summed as the reference adds them
+    float Wr[IN_MAX], Wz[IN_MAX], Wh[IN_MAX], Ur[GRU_U], Uz[GRU_U], Uh[GRU_U];
+#pragma unroll
+    for (int c = 0; c < IN_MAX; ++c) {
+        const bool ok = j < dz && c < in;
+        Wr[c] = ok ? params[o.w[0] + j * in + c] : 0.f;
+        Wz[c] = ok ? params[o.w[2] + j * in + c] : 0.f;
+        Wh[c] = ok ? params[o.w[4] + j * in + c] : 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < GRU_U; ++c) {
+        const bool ok = j < dz && c < dz;
+        Ur[c] = ok ? params[o.w[1] + j * dz + c] : 0.f;
+        Uz[c] = ok ? params[o.w[3] + j * dz + c] : 0.f;
+        Uh[c] = ok ? params[o.w[5] + j * dz + c] : 0.f;
+    }
+    const float b_r = j < dz ? params[o.b[0] + j] + params[o.b[1] + j] : 0.f;
+    const float b_z = j < dz ? params[o.b[2] + j] + params[o.b[3] + j] : 0.f;
+    const float b_h = j < dz ? params[o.b[4] + j] + params[o.b[5] + j] : 0.f;
+    for (int c = j; c < IN_MAX + 4; c += GRU_U) xs[s][c] = 0.f;
+    hs[s][j] = 0.f; rhs[s][j] = 0.f;
+    if (j < 4) { hs[s][GRU_U + j] = 0.f; rhs[s][GRU_U + j] = 0.f; }
+    __syncthreads();
     if (live) hs[s][j] = h0[n * dz + j];
     if (n < N) {
         for (int c = j; c < dl; c += GRU_U) xs[s][c] = (c == labels[n]) ? 1.f : 0.f;
         for (int t = 0; t < T; ++t) for (int c = j; c < dc; c += GRU_U) z[((long long)t * N + n) * zw + c] = zc[n * dc + c];
     }
-    // the noise inputs of the first GRU_T steps are fetched up front: a load per step would put a memory round trip
-    // into each link of the 16-step dependency chain
-    float ev[GRU_T];
-#pragma unroll
-    for (int t = 0; t < GRU_T; ++t) ev[t] = (live && t < T) ? e[((long long)t * N + n) * dz + j] : 0.f;
+    // the noise input of step t + 1 is fetched during step t: no memory round trip inside the dependency chain (and the
+    // time loop stays rolled: unrolled, its 16 bodies run at instruction-fetch speed)
+    float e_next = live ? e[(long long)n * dz + j] : 0.f;
     __syncthreads();
     auto step = [&](int t, float e_t) {
         if (live) xs[s][dl + j] = e_t;
         __syncthreads();
-        float r = 0, zz = 0, hb = 0, h = 0;
-        if (live) {
-            float ar = P[o.b[0] + j] + P[o.b[1] + j], az = P[o.b[2] + j] + P[o.b[3] + j];
-            hb = P[o.b[4] + j] + P[o.b[5] + j];
-            for (int c = 0; c < in; ++c) {
-                float xv = xs[s][c];
-                ar = fmaf(P[o.w[0] + c * dz + j], xv, ar);
-                az = fmaf(P[o.w[2] + c * dz + j], xv, az);
-                hb = fmaf(P[o.w[4] + c * dz + j], xv, hb);
-            }
-            for (int c = 0; c < dz; ++c) {
-                float hv = hs[s][c];
-                ar = fmaf(P[o.w[1] + c * dz + j], hv, ar);
-                az = fmaf(P[o.w[3] + c * dz + j], hv, az);
-            }
-            r = sigmoidf_(ar); zz = sigmoidf_(az); h = hs[s][j];
-            rhs[s][j] = r * h;
+        float ar = b_r, az = b_z, hb = b_h;
+#pragma unroll
+        for (int c = 0; c < IN_MAX; ++c) {
+            const float xv = xs[s][c];
+            ar = fmaf(Wr[c], xv, ar);
+            az = fmaf(Wz[c], xv, az);
+            hb = fmaf(Wh[c], xv, hb);
         }
+#pragma unroll
+        for (int c = 0; c < GRU_U; ++c) {
+            const float hv = hs[s][c];
+            ar = fmaf(Ur[c], hv, ar);
+            az = fmaf(Uz[c], hv, az);
+        }
+        const float r = sigmoidf_(ar), zz = sigmoidf_(az), h = hs[s][j];
+        if (live) rhs[s][j] = r * h;
         __syncthreads();
+#pragma unroll
+        for (int c = 0; c < GRU_U; ++c) hb = fmaf(Uh[c], rhs[s][c], hb);
+        hb = tanhf(hb);
+        const float hn = (1.f - zz) * h + zz * hb;
         if (live) {
-            for (int c = 0; c < dz; ++c) hb = fmaf(P[o.w[5] + c * dz + j], rhs[s][c], hb);
-            hb = tanhf(hb);
-            float hn = (1.f - zz) * h + zz * hb;
             float* sv = saved + ((long long)t * N + n) * 4 * dz;
             sv[j] = r; sv[dz + j] = zz; sv[2 * dz + j] = hb; sv[3 * dz + j] = h;
             z[((long long)t * N + n) * zw + dc + j] = hn;
@@ -534,35 +548,51 @@ __global__ __launch_bounds__(GRU_S * GRU_U) void gru_fwd_kernel(int N, int T, in
         }
         __syncthreads();
     };
-#pragma unroll
-    for (int t = 0; t < GRU_T; ++t) if (t < T) step(t, ev[t]);
-    for (int t = GRU_T; t < T; ++t) step(t, live ? e[((long long)t * N + n) * dz + j] : 0.f);
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+        const float e_t = e_next;
+        e_next = (live && t + 1 < T) ? e[((long long)(t + 1) * N + n) * dz + j] : 0.f;
+        step(t, e_t);
+    }
 }
 
+template <int IN_MAX>
 __global__ __launch_bounds__(GRU_S * GRU_U) void gru_bwd_kernel(int N, int T, int dz, int dl, int dc, const float* __restrict__ params,
                                                                 const float* __restrict__ e, const int32_t* __restrict__ labels,
                                                                 const float* __restrict__ saved, const float* __restrict__ gz,
                                                                 float* __restrict__ dparams) {
-    __shared__ float P[GRU_MAXP], DP[GRU_MAXP];
-    __shared__ float xs[GRU_S][GRU_MAXIN + 1], ga_s[GRU_S][GRU_U + 1], gaz_s[GRU_S][GRU_U + 1], gar_s[GRU_S][GRU_U + 1];
-    __shared__ float h_s[GRU_S][GRU_U + 1], rh_s[GRU_S][GRU_U + 1];
+    __shared__ float DP[GRU_MAXP];
+    __shared__ float xs[GRU_S][IN_MAX + 4], ga_s[GRU_S][GRU_U + 4], gaz_s[GRU_S][GRU_U + 4], gar_s[GRU_S][GRU_U + 4];
+    __shared__ float h_s[GRU_S][GRU_U + 4], rh_s[GRU_S][GRU_U + 4];
     const GruOff o = gru_offsets(dz, dl);
-    for (int i = threadIdx.x; i < o.total; i += blockDim.x) { P[i] = params[i]; DP[i] = 0.f; }
+    for (int i = threadIdx.x; i < o.total; i += blockDim.x) DP[i] = 0.f;
     const int s = threadIdx.x / GRU_U, j = threadIdx.x % GRU_U;
     const int n = blockIdx.x * GRU_S + s;
     const bool live = n < N && j < dz;
     const int in = dz + dl, zw = dc + dz;
+    // column j of U, U_z, U_r (the transposed products of the backward pass)
+    float Uhc[GRU_U], Uzc[GRU_U], Urc[GRU_U];
+#pragma unroll
+    for (int i = 0; i < GRU_U; ++i) {
+        const bool ok = j < dz && i < dz;
+        Uhc[i] = ok ? params[o.w[5] + i * dz + j] : 0.f;
+        Uzc[i] = ok ? params[o.w[3] + i * dz + j] : 0.f;
+        Urc[i] = ok ? params[o.w[1] + i * dz + j] : 0.f;
+    }
+    for (int c = j; c < IN_MAX + 4; c += GRU_U) xs[s][c] = 0.f;
+    for (int c = j; c < GRU_U + 4; c += GRU_U) { ga_s[s][c] = 0.f; gaz_s[s][c] = 0.f; gar_s[s][c] = 0.f; h_s[s][c] = 0.f; rh_s[s][c] = 0.f; }
+    __syncthreads();
     if (n < N) for (int c = j; c < dl; c += GRU_U) xs[s][c] = (c == labels[n]) ? 1.f : 0.f;
     float gh = 0.f;
-    float gW[3][GRU_MAXIN], gU[3][GRU_U], gb[3] = {0.f, 0.f, 0.f};       // d(W, W_z, W_r), d(U, U_z, U_r) rows, biases
+    float gW[3][IN_MAX], gU[3][GRU_U], gb[3] = {0.f, 0.f, 0.f};       // d(W, W_z, W_r), d(U, U_z, U_r) rows, biases
 #pragma unroll
-    for (int c = 0; c < GRU_MAXIN; ++c) { gW[0][c] = 0.f; gW[1][c] = 0.f; gW[2][c] = 0.f; }
+    for (int c = 0; c < IN_MAX; ++c) { gW[0][c] = 0.f; gW[1][c] = 0.f; gW[2][c] = 0.f; }
 #pragma unroll
     for (int c = 0; c < GRU_U; ++c) { gU[0][c] = 0.f; gU[1][c] = 0.f; gU[2][c] = 0.f; }
     struct In { float r, zz, hb, h, e, gz; };
     auto fetch = [&](int t) {
         In v = {0, 0, 0, 0, 0, 0};
-        if (live && t < T) {
+        if (live && t >= 0) {
             const float* sv = saved + ((long long)t * N + n) * 4 * dz;
             v.r = sv[j]; v.zz = sv[dz + j]; v.hb = sv[2 * dz + j]; v.h = sv[3 * dz + j];
             v.e = e[((long long)t * N + n) * dz + j];
@@ -570,60 +600,55 @@ __global__ __launch_bounds__(GRU_S * GRU_U) void gru_bwd_kernel(int N, int T, in
         }
         return v;
     };
-    In pre[GRU_T];                                  // as in gru_fwd_kernel: no load inside the dependency chain
-#pragma unroll
-    for (int t = 0; t < GRU_T; ++t) pre[t] = fetch(t);
+    In next = fetch(T - 1);                         // as in gru_fwd_kernel: step t - 1's inputs are fetched during step t
     __syncthreads();
     auto step = [&](int t, const In& v) {
-        float r = 0, zz = 0, hb = 0, h = 0, ga = 0, gaz = 0, ghn = 0;
+        const float r = v.r, zz = v.zz, hb = v.hb, h = v.h;      // (all zero in the padded threads)
+        const float ghn = gh + v.gz;
+        const float gzz = ghn * (hb - h), ghb = ghn * zz;
+        const float ga = ghb * (1.f - hb * hb);
+        const float gaz = gzz * zz * (1.f - zz);
         if (live) {
-            r = v.r; zz = v.zz; hb = v.hb; h = v.h;
             xs[s][dl + j] = v.e;
-            ghn = gh + v.gz;
-            float gzz = ghn * (hb - h), ghb = ghn * zz;
-            ga = ghb * (1.f - hb * hb);
-            gaz = gzz * zz * (1.f - zz);
             ga_s[s][j] = ga; gaz_s[s][j] = gaz; h_s[s][j] = h; rh_s[s][j] = r * h;
         }
         __syncthreads();
-        float gar = 0.f;
-        if (live) {
-            float grh = 0.f;
-            for (int i = 0; i < dz; ++i) grh = fmaf(ga_s[s][i], P[o.w[5] + i * dz + j], grh);
-            gh = ghn * (1.f - zz) + grh * r;
-            float gr = grh * h;
-            gar = gr * r * (1.f - r);
-            gar_s[s][j] = gar;
-        }
+        float grh = 0.f;
+#pragma unroll
+        for (int i = 0; i < GRU_U; ++i) grh = fmaf(ga_s[s][i], Uhc[i], grh);
+        gh = ghn * (1.f - zz) + grh * r;
+        const float gr = grh * h;
+        const float gar = gr * r * (1.f - r);
+        if (live) gar_s[s][j] = gar;
         __syncthreads();
-        if (live) {
-            for (int i = 0; i < dz; ++i) {
-                gh = fmaf(gaz_s[s][i], P[o.w[3] + i * dz + j], gh);
-                gh = fmaf(gar_s[s][i], P[o.w[1] + i * dz + j], gh);
-            }
-            // parameter gradients of row j of each link: accumulated in registers over the 16 steps
 #pragma unroll
-            for (int c = 0; c < GRU_MAXIN; ++c)
-                if (c < in) {
-                    const float xv = xs[s][c];
-                    gW[0][c] = fmaf(ga, xv, gW[0][c]); gW[1][c] = fmaf(gaz, xv, gW[1][c]); gW[2][c] = fmaf(gar, xv, gW[2][c]);
-                }
-#pragma unroll
-            for (int c = 0; c < GRU_U; ++c)
-                if (c < dz) {
-                    gU[0][c] = fmaf(ga, rh_s[s][c], gU[0][c]); gU[1][c] = fmaf(gaz, h_s[s][c], gU[1][c]);
-                    gU[2][c] = fmaf(gar, h_s[s][c], gU[2][c]);
-                }
-            gb[0] += ga; gb[1] += gaz; gb[2] += gar;
+        for (int i = 0; i < GRU_U; ++i) {
+            gh = fmaf(gaz_s[s][i], Uzc[i], gh);
+            gh = fmaf(gar_s[s][i], Urc[i], gh);
         }
+        // parameter gradients of row j of each link: accumulated in registers over the 16 steps
+#pragma unroll
+        for (int c = 0; c < IN_MAX; ++c) {
+            const float xv = xs[s][c];
+            gW[0][c] = fmaf(ga, xv, gW[0][c]); gW[1][c] = fmaf(gaz, xv, gW[1][c]); gW[2][c] = fmaf(gar, xv, gW[2][c]);
+        }
+#pragma unroll
+        for (int c = 0; c < GRU_U; ++c) {
+            gU[0][c] = fmaf(ga, rh_s[s][c], gU[0][c]); gU[1][c] = fmaf(gaz, h_s[s][c], gU[1][c]);
+            gU[2][c] = fmaf(gar, h_s[s][c], gU[2][c]);
+        }
+        gb[0] += ga; gb[1] += gaz; gb[2] += gar;
         __syncthreads();
     };
-    for (int t = T - 1; t >= GRU_T; --t) step(t, fetch(t));
-#pragma unroll
-    for (int t = GRU_T - 1; t >= 0; --t) if (t < T) step(t, pre[t]);
+#pragma unroll 1
+    for (int t = T - 1; t >= 0; --t) {
+        const In cur = next;
+        next = fetch(t - 1);
+        step(t, cur);
+    }
     if (live) {                                    // one LDS reduction over the block's samples
 #pragma unroll
-        for (int c = 0; c < GRU_MAXIN; ++c)
+        for (int c = 0; c < IN_MAX; ++c)
             if (c < in) {
                 atomicAdd(&DP[o.w[4] + j * in + c], gW[0][c]);
                 atomicAdd(&DP[o.w[2] + j * in + c], gW[1][c]);
@@ -982,8 +1007,12 @@ extern "C" int mcg_gru_seq_fwd(int N, int T, int dim_zm, int dim_zl, int dim_zc,
     if (!params || !h0 || !e || !zc || !z || !saved || N <= 0 || T <= 0) return MCG_ERR_BAD_ARG;
     if (dim_zm <= 0 || dim_zm > GRU_U || dim_zl < 0 || dim_zm + dim_zl > GRU_MAXIN || dim_zc < 0) return MCG_ERR_UNSUPPORTED;
     if (dim_zl && !labels) return MCG_ERR_BAD_ARG;
-    hipLaunchKernelGGL(gru_fwd_kernel, dim3((N + GRU_S - 1) / GRU_S), dim3(GRU_S * GRU_U), 0, (hipStream_t)stream, N, T, dim_zm, dim_zl, dim_zc,
-                       params, h0, e, labels, zc, z, saved);
+    if (dim_zm + dim_zl <= 16)
+        hipLaunchKernelGGL(gru_fwd_kernel<16>, dim3((N + GRU_S - 1) / GRU_S), dim3(GRU_S * GRU_U), 0, (hipStream_t)stream, N, T, dim_zm, dim_zl, dim_zc,
+                           params, h0, e, labels, zc, z, saved);
+    else
+        hipLaunchKernelGGL(gru_fwd_kernel<GRU_MAXIN>, dim3((N + GRU_S - 1) / GRU_S), dim3(GRU_S * GRU_U), 0, (hipStream_t)stream, N, T, dim_zm, dim_zl, dim_zc,
+                           params, h0, e, labels, zc, z, saved);
     return launch_status();
 }
 
@@ -992,8 +1021,12 @@ extern "C" int mcg_gru_seq_bwd(int N, int T, int dim_zm, int dim_zl, int dim_zc,
     if (!params || !e || !saved || !gz || !dparams || N <= 0 || T <= 0) return MCG_ERR_BAD_ARG;
     if (dim_zm <= 0 || dim_zm > GRU_U || dim_zl < 0 || dim_zm + dim_zl > GRU_MAXIN || dim_zc < 0) return MCG_ERR_UNSUPPORTED;
     if (dim_zl && !labels) return MCG_ERR_BAD_ARG;
-    hipLaunchKernelGGL(gru_bwd_kernel, dim3((N + GRU_S - 1) / GRU_S), dim3(GRU_S * GRU_U), 0, (hipStream_t)stream, N, T, dim_zm, dim_zl, dim_zc,
-                       params, e, labels, saved, gz, dparams);
+    if (dim_zm + dim_zl <= 16)
+        hipLaunchKernelGGL(gru_bwd_kernel<16>, dim3((N + GRU_S - 1) / GRU_S), dim3(GRU_S * GRU_U), 0, (hipStream_t)stream, N, T, dim_zm, dim_zl, dim_zc,
+                           params, e, labels, saved, gz, dparams);
+    else
+        hipLaunchKernelGGL(gru_bwd_kernel<GRU_MAXIN>, dim3((N + GRU_S - 1) / GRU_S), dim3(GRU_S * GRU_U), 0, (hipStream_t)stream, N, T, dim_zm, dim_zl, dim_zc,
+                           params, e, labels, saved, gz, dparams);
     return launch_status();
 }
 
