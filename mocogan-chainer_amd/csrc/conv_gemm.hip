@@ -103,6 +103,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const float* p, u32 b
 __device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t r, u32 byte_off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
 }
+// per-lane offset + wave-uniform offset (an SGPR operand of the load: no vector add).  The hardware checks the per-lane
+// part against the extent, so this form is for rows whose whole K range lies inside the tensor.
+__device__ __forceinline__ f32x4 bload_s(__amdgpu_buffer_rsrc_t r, u32 lane_off, u32 uniform_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, uniform_off, 0));
+}
 
 // ------------------------------------------------------------------------------------------
 // Problem policies.  Each provides the K range, tile loaders for A (rows = M side) and B (rows = N
@@ -114,8 +119,15 @@ __device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t r, u32 byte_off) {
 // E (all policies): elements per 16-byte operand slot -- 4: the operands are fp32 in memory (both MFMA types);
 // 8: they are bf16 in memory (MCG_PREC_BF16_STORE), a slot is loaded and written to LDS as it is.  Outputs are fp32.
 
+// ST (fprop / dgrad): scalar tap decode.  When a K-step lies inside one filter tap (channel count a power of two and a
+// multiple of BK) the tap decode and the tap's offset are wave-uniform: computed on the scalar unit, per load one vector
+// add and the tap-validity bit moved into bit 31 (offsets >= 2 GiB are outside every buffer), the filter rows addressed
+// through the load's scalar offset operand -- ~15 instead of ~35 vector instructions (several of them quarter-rate integer
+// multiplies) per K-step.  The bf16 kernels use it: their MFMA is 16x faster, and at 12 vector instructions per MFMA
+// (PMC, dc2's input gradient) the loaders, not the matrix pipe, set their pace.  The fp32 kernels do not: there the same
+// change made every launch 0.5-6 % faster on one stream and the side-stream iteration 2 % slower (section 3 of DESIGN.md).
 // ---------------- fprop ----------------
-template <int BM, int BN, int BK, int E_ = 4>
+template <int BM, int BN, int BK, int E_ = 4, bool ST = false>
 struct FpropP {
     static constexpr bool A_KC = true, B_KC = true;
     static constexpr int ORDER = 0;
@@ -163,13 +175,13 @@ struct FpropP {
             int n = div_To(g, q), to = q - n * g.To;
             int hi0 = 2 * ho - 1, wi0 = 2 * wo - 1;
             abase[j] = ((int)x_batch_off(g, n) + ((to * g.Hi + hi0) * g.Wi + wi0) * g.Ci) * ESZ;
-            u32 mk = 0;
+            // the window is separable: 4 column bits, repeated for every row that lies inside the image
+            u32 wbits = 0, mk = 0;
 #pragma unroll
-            for (int kh = 0; kh < 4; ++kh)
+            for (int kw = 0; kw < 4; ++kw) wbits |= ((unsigned)(wi0 + kw) < (unsigned)g.Wi ? 1u : 0u) << kw;
 #pragma unroll
-                for (int kw = 0; kw < 4; ++kw)
-                    if (ok && (unsigned)(hi0 + kh) < (unsigned)g.Hi && (unsigned)(wi0 + kw) < (unsigned)g.Wi) mk |= 1u << (kh * 4 + kw);
-            amask[j] = mk;
+            for (int kh = 0; kh < 4; ++kh) mk |= ((unsigned)(hi0 + kh) < (unsigned)g.Hi ? wbits : 0u) << (kh * 4);
+            amask[j] = ok ? mk : 0u;
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
@@ -182,6 +194,16 @@ struct FpropP {
     __device__ int next_valid(int k0) const { return k0; }
     __device__ int rotated(int k0) const { int k = k0 + krot; return k >= K ? k - K : k; }     // whole K-steps stay inside one tap
     __device__ void load_a(int k0, f32x4 (&r)[NA]) const {
+        if constexpr (ST) {
+            if (g.lgCi >= 0 && (g.Ci & (BK - 1)) == 0) {
+                const int kr = rotated(k0);               // wave-uniform
+                const int tap = kr >> g.lgCi, ci0 = kr & (g.Ci - 1), sp = tap & 15;
+                const int off = ((((tap >> 4) * g.Hi + (sp >> 2)) * g.Wi + (sp & 3)) * g.Ci + ci0 + ak) * ESZ;
+#pragma unroll
+                for (int j = 0; j < NA; ++j) r[j] = bload(xr, (((~amask[j]) >> sp) << 31) | (u32)(abase[j] + off));
+                return;
+            }
+        }
         int k = rotated(k0) + ak;
         int tap, ci;
         divmod_c(k, g.Ci, g.lgCi, tap, ci);
@@ -193,7 +215,7 @@ struct FpropP {
     __device__ void load_b(int k0, f32x4 (&r)[NB]) const {
         const u32 kb = (u32)rotated(k0) * (u32)ESZ;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) r[j] = bload(wr, bbase[j] + kb);
+        for (int j = 0; j < NB; ++j) r[j] = ST ? bload_s(wr, bbase[j], kb) : bload(wr, bbase[j] + kb);
     }
     __device__ void store(int m, int n, float v) const {
         if (m >= M || n >= g.Co) return;
@@ -213,7 +235,7 @@ struct FpropP {
 };
 
 // ---------------- dgrad (one output-parity class per blockIdx.z) ----------------
-template <int BM, int BN, int BK, int E_ = 4>
+template <int BM, int BN, int BK, int E_ = 4, bool ST = false>
 struct DgradP {
     static constexpr bool A_KC = true, B_KC = false;
     static constexpr int ORDER = 1;
@@ -263,13 +285,14 @@ struct DgradP {
             int t = div_N(g, q), n = q - t * g.N;
             int hh = h2 + ph, ww = w2 + pw;
             abase[j] = ((((n * g.To + t) * g.Ho + hh) * g.Wo + ww) * g.Co) * ESZ;
+            // separable: the 4 spatial sub-filter taps (b = bh * 2 + bw), repeated for every temporal tap whose frame exists
+            const u32 h0 = (unsigned)hh < (unsigned)g.Ho, h1 = (unsigned)(hh - 1) < (unsigned)g.Ho;
+            const u32 w0 = (unsigned)ww < (unsigned)g.Wo, w1 = (unsigned)(ww - 1) < (unsigned)g.Wo;
+            const u32 hw = (h0 & w0) | ((h0 & w1) << 1) | ((h1 & w0) << 2) | ((h1 & w1) << 3);
             u32 mk = 0;
-            for (int a = 0; a < g.kt; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    if (ok && (unsigned)(t - a) < (unsigned)g.To && (unsigned)(hh - (b >> 1)) < (unsigned)g.Ho &&
-                        (unsigned)(ww - (b & 1)) < (unsigned)g.Wo) mk |= 1u << (a * 4 + b);
-            amask[j] = mk;
+            for (int a = 0; a < 4; ++a) mk |= (a < g.kt && (unsigned)(t - a) < (unsigned)g.To ? hw : 0u) << (a * 4);
+            amask[j] = ok ? mk : 0u;
         }
         // B tile: rows = k (BK), cols = ci (BN); BN/4 float4 per row
         constexpr int C4 = BN / E;                                  // 16-byte slots per row
@@ -303,6 +326,16 @@ struct DgradP {
     }
     __device__ int rotated(int k0) const { int k = k0 + krot; return k >= K ? k - K : k; }     // K-steps never straddle the wrap
     __device__ void load_a(int k0, f32x4 (&r)[NA]) const {
+        if constexpr (ST) {
+            if (g.lgCo >= 0 && (g.Co & (BK - 1)) == 0) {          // one sub-filter tap per K-step: scalar decode (as FpropP::load_a)
+                const int kr = rotated(k0);
+                const int ts = kr >> g.lgCo, co0 = kr & (g.Co - 1);
+                const int off = (co0 + ak - (((ts >> 2) * g.Ho + ((ts >> 1) & 1)) * g.Wo + (ts & 1)) * g.Co) * ESZ;
+#pragma unroll
+                for (int j = 0; j < NA; ++j) r[j] = bload(yr, (((~amask[j]) >> ts) << 31) | (u32)(abase[j] + off));
+                return;
+            }
+        }
         int k = rotated(k0) + ak;
         int ts, co;
         divmod_c(k, g.Co, g.lgCo, ts, co);
@@ -318,7 +351,7 @@ struct DgradP {
             int tap = (ts >> 2) * 16 + ((1 - ph) + (ts & 2)) * 4 + (1 - pw) + 2 * (ts & 1);
             u32 base = (u32)((co0 * g.taps + tap) * g.Ci) * (u32)ESZ;
 #pragma unroll
-            for (int j = 0; j < NB; ++j) r[j] = bload(wr, bfast[j] + base);
+            for (int j = 0; j < NB; ++j) r[j] = ST ? bload_s(wr, bfast[j], base) : bload(wr, bfast[j] + base);
             return;
         }
 #pragma unroll
@@ -1798,7 +1831,7 @@ int launch_status() { return hipGetLastError() == hipSuccess ? MCG_OK : MCG_ERR_
 // 2 = bf16 MFMA, operands bf16 in memory (MCG_PREC_BF16_STORE).  The fused-epilogue classes 2 / 3 exist for PM 0 / 1.
 template <int BM, int BN, int BK, int PM = 0>
 int launch_fprop(const Geom& g, const float* x, const float* w, const float* bias, float* y, const Epi& e, mcg_conv_epilogue* ep, hipStream_t s) {
-    using Pol = FpropP<BM, BN, BK, PM == 2 ? 8 : 4>;
+    using Pol = FpropP<BM, BN, BK, PM == 2 ? 8 : 4, PM != 0>;
     Pol p;
     p.g = g; p.e = e; p.x = x; p.w = w; p.bias = bias; p.y = y;
     p.M = g.N * g.To * g.Ho * g.Wo; p.K = g.taps * g.Ci;
@@ -1832,7 +1865,7 @@ int launch_fprop(const Geom& g, const float* x, const float* w, const float* bia
 
 template <int BM, int BN, int BK, int PM = 0>
 int launch_dgrad(const Geom& g, const float* y, const float* w, const float* bias, float* x, int act, int acc, const Epi& e, mcg_conv_epilogue* ep, hipStream_t s) {
-    using Pol = DgradP<BM, BN, BK, PM == 2 ? 8 : 4>;
+    using Pol = DgradP<BM, BN, BK, PM == 2 ? 8 : 4, PM != 0>;
     Pol p;
     p.g = g; p.e = e; p.y = y; p.w = w; p.bias = bias; p.x = x; p.act = act; p.accumulate = acc;
     p.M = g.N * g.Ti * g.Ho * g.Wo; p.K = g.kt * 4 * g.Co;
