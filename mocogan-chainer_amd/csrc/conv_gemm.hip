@@ -217,10 +217,13 @@ struct FpropP {
 #pragma unroll
         for (int j = 0; j < NB; ++j) r[j] = ST ? bload_s(wr, bbase[j], kb) : bload(wr, bbase[j] + kb);
     }
-    __device__ void store(int m, int n, float v) const {
-        if (m >= M || n >= g.Co) return;
-        if (kchunk >= K) y[(long long)m * g.Co + n] = v + (bias ? bias[n] : 0.f);
-        else atomicAdd(y + (long long)m * g.Co + n, v + (bias && zz == 0 ? bias[n] : 0.f));
+    // plain epilogue: the row part of an output address is computed once per accumulator row (row_off), not per element
+    static constexpr bool HAS_ROW_OFF = true;
+    __device__ long long row_off(int m) const { return m < M ? (long long)m * g.Co : -1; }
+    __device__ void store_at(long long ro, int n, float v) const {
+        if (ro < 0 || n >= g.Co) return;
+        if (kchunk >= K) y[ro + n] = v + (bias ? bias[n] : 0.f);
+        else atomicAdd(y + ro + n, v + (bias && zz == 0 ? bias[n] : 0.f));
     }
     // ---- fused epilogue interface ----
     __device__ int out_cols() const { return g.Co; }
@@ -364,11 +367,16 @@ struct DgradP {
             r[j] = bload(wr, bok ? vo : OOB);
         }
     }
-    __device__ void store(int m, int n, float v) const {
-        if (m >= M || n >= g.Ci) return;
+    static constexpr bool HAS_ROW_OFF = true;
+    __device__ long long row_off(int m) const {
+        if (m >= M) return -1;
         int w2 = m & (g.Wo - 1), h2 = (m >> g.lgWo) & (g.Ho - 1), q = m >> (g.lgWo + g.lgHo);
         int t = div_N(g, q), nb = q - t * g.N;
-        long long o = x_batch_off(g, nb) + ((long long)(t * g.Hi + 2 * h2 + ph) * g.Wi + 2 * w2 + pw) * g.Ci + n;
+        return x_batch_off(g, nb) + ((long long)(t * g.Hi + 2 * h2 + ph) * g.Wi + 2 * w2 + pw) * g.Ci;
+    }
+    __device__ void store_at(long long ro, int n, float v) const {
+        if (ro < 0 || n >= g.Ci) return;
+        const long long o = ro + n;
         if (kchunk < K) {                          // split-K (act == NONE; x cleared by the host unless accumulating)
             atomicAdd(x + o, v + (bias && zsplit == 0 ? bias[n] : 0.f));
             return;
@@ -399,6 +407,7 @@ struct DgradP {
 template <int BM, int BN, int BK, int E_ = 4>
 struct WgradP {
     static constexpr bool HAS_EPI = false;
+    static constexpr bool HAS_ROW_OFF = false;
     static constexpr bool A_KC = false, B_KC = false;
     static constexpr int ORDER = 2;
     static constexpr int E = E_, ESZ = 16 / E_;
@@ -460,6 +469,7 @@ struct WgradP {
 template <int BM, int BN, int BK>
 struct FcFpropP {
     static constexpr bool HAS_EPI = false;
+    static constexpr bool HAS_ROW_OFF = false;
     static constexpr int E = 4;
     static constexpr bool A_KC = true, B_KC = true;
     static constexpr int ORDER = 0;
@@ -503,6 +513,7 @@ struct FcFpropP {
 template <int BM, int BN, int BK>
 struct FcWgradP {
     static constexpr bool HAS_EPI = false;
+    static constexpr bool HAS_ROW_OFF = false;
     static constexpr int E = 4;
     static constexpr bool A_KC = false, B_KC = false;
     static constexpr int ORDER = 2;
@@ -830,6 +841,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(P p) {
         return;
     }
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if constexpr (P::HAS_ROW_OFF) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long ro = p.row_off(m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
+#pragma unroll
+                for (int b = 0; b < TN; ++b) p.store_at(ro, n0 + wn0 + b * 32 + li, acc[a][b][r]);
+            }
+        return;
+    } else {
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -840,6 +862,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(P p) {
                 int col = n0 + wn0 + b * 32 + li;
                 p.store(row, col, acc[a][b][r]);
             }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -992,6 +1015,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(P p) {
         fused_epilogue<P, BM, BN, WM, WN, TM, TN, EPI>(p, acc, m0, n0, bx, bz, tid, reinterpret_cast<float*>(lds));
         return;
     }
+    if constexpr (P::HAS_ROW_OFF) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long ro = p.row_off(m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
+#pragma unroll
+                for (int b = 0; b < TN; ++b) p.store_at(ro, n0 + wn0 + b * 32 + li, acc[a][b][r]);
+            }
+        return;
+    } else {
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -1002,6 +1036,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(P p) {
                 int col = n0 + wn0 + b * 32 + li;
                 p.store(row, col, acc[a][b][r]);
             }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
