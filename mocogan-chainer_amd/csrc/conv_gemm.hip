@@ -752,6 +752,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(P p) {
     f32x4 ra[NA], rb[NB];
     const int kend = p.k_end(z);
     int k0 = p.next_valid(p.k_begin(z));
+#ifdef MCG_PROBE_NOLOOP        // (tools/probe_variant.py: what a block costs WITHOUT its K loop -- row decode, tap masks, store)
+    k0 = kend;
+#endif
     if (k0 < kend) { p.load_a(k0, ra); p.load_b(k0, rb); }
 
     constexpr int A_C4 = A_C / 4, B_C4 = B_C / 4;
