@@ -48,6 +48,7 @@ enum { MCG_ACT_NONE = 0, MCG_ACT_RELU = 1, MCG_ACT_LRELU = 2, MCG_ACT_TANH = 3 }
 /* MFMA operand type of the convolution GEMMs.  Tensors are fp32 in memory either way and products are
  * accumulated in fp32; MCG_PREC_BF16 rounds both operands to bf16 (round-to-nearest-even) inside the
  * kernel and multiplies them on v_mfma_f32_32x32x16_bf16 (BASELINE config "bf16 MFMA tiles"). */
+enum { MCG_IO_OUT_BF16 = 1, MCG_IO_Y_BF16 = 2, MCG_IO_G_BF16 = 4 };   /* which tensors of an element-wise call are bf16 (see mcg_bn_act_fwd) */
 enum { MCG_PREC_F32 = 0, MCG_PREC_BF16 = 1,
        /* as MCG_PREC_BF16, with the INPUT operands of the call (x and w for fprop, y and w for dgrad, x and y for wgrad)
         * already bf16 in memory (uint16_t, round-to-nearest-even of the fp32 values): they are loaded and staged as they
@@ -141,8 +142,10 @@ typedef struct mcg_conv_epilogue {
                                  * m & 3 of counter (m >> 2) * C + c (mcg_randn_rowquad draws the same stream) */
     uint64_t seed, stream_id[2];
     uint32_t* mask_out;         /* [rows][(C+31)/32] words, bit c & 31 of word c >> 5 set <=> pre-activation >= 0; or NULL */
-    int32_t out_bf16;           /* with act: y is a bf16 tensor (uint16_t) -- the operand of the next layer of a
-                                 * MCG_PREC_BF16_STORE network -- instead of fp32 */
+    int32_t out_bf16;           /* the OUTPUT tensor (y of fprop, x of dgrad) is bf16 (uint16_t, round-to-nearest-even) --
+                                 * what the next layer's GEMMs (with act) or the element-wise passes (without) of a bf16
+                                 * network read.  With the plain store or any epilogue but MCG_SUMS_BN_BWD; never with a
+                                 * split-K tile code, an accumulating dgrad or the Ci = 4 layers (MCG_ERR_UNSUPPORTED) */
     /* dgrad only: v *= (mask bit ? 1 : 0.2) -- leaky_relu's backward from the bits the forward pass stored */
     const uint32_t* mask_in;
     /* out (host side, valid after the call): */
@@ -190,8 +193,10 @@ int mcg_bn_act_fwd(int64_t M, int C, int c_valid, const float* y, int64_t y_rows
                    int64_t y_item_stride, const float* scale_shift, int act,
                    const float* addend, float sigma, uint64_t seed, uint64_t stream_id,
                    void* out, int out_bf16, void* stream);
-/* (out_bf16 != 0: `out` is a bf16 tensor (uint16_t, round-to-nearest-even) -- the activations of a
- * MCG_PREC_BF16_STORE network are only ever read as GEMM operands; likewise gx_bf16 of the backward passes below) */
+/* out_bf16 (and gx_bf16 of the backward passes below) is a set of MCG_IO_* flags saying which tensors of the call are bf16
+ * (uint16_t, round-to-nearest-even) instead of fp32: bf16 networks keep the tensors that are only read by GEMMs
+ * (activations, output gradients: MCG_IO_OUT_BF16) and the GEMM outputs these passes read (pre-BatchNorm values
+ * MCG_IO_Y_BF16, input gradients MCG_IO_G_BF16) in bf16.  1 == MCG_IO_OUT_BF16 keeps the meaning of the former boolean. */
 
 /* Backward of the line above + BN.  g_out: gradient w.r.t. `out`.  Computes
  * g_bn = g_out * act'(y*scale+shift) (the mask is recomputed from the SAVED scale/shift, i.e.

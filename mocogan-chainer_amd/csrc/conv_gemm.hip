@@ -74,7 +74,8 @@ struct Epi {
     const float* bn_y; const float* bn_stats[2]; int bn_act;
     const float* addend[2]; float sigma; u64 seed; u64 stream[2];
     u32* mask_out; const u32* mask_in; int mask_cb;
-    int out16;                  // EPI_ACT: the output tensor is bf16 (the next layer's operand in MCG_PREC_BF16_STORE networks)
+    int out16;                  // the output tensor is bf16 (bf16 networks: what the element-wise passes and the next GEMMs read;
+                                // plain store and epilogue classes 1 / 3; never with split-K, whose partial tiles are added in fp32)
 };
 struct RowInfo { long long base; long long pix; int grp; bool ok; };   // base: element offset of the row's column 0 in the output
 
@@ -222,7 +223,8 @@ struct FpropP {
     __device__ long long row_off(int m) const { return m < M ? (long long)m * g.Co : -1; }
     __device__ void store_at(long long ro, int n, float v) const {
         if (ro < 0 || n >= g.Co) return;
-        if (kchunk >= K) y[ro + n] = v + (bias ? bias[n] : 0.f);
+        if (e.out16) reinterpret_cast<__bf16*>(y)[ro + n] = (__bf16)(v + (bias ? bias[n] : 0.f));
+        else if (kchunk >= K) y[ro + n] = v + (bias ? bias[n] : 0.f);
         else atomicAdd(y + ro + n, v + (bias && zz == 0 ? bias[n] : 0.f));
     }
     // ---- fused epilogue interface ----
@@ -383,6 +385,7 @@ struct DgradP {
         }
         if (bias) v += bias[n];
         if (act == MCG_ACT_TANH) v = tanhf(v);
+        if (e.out16) { reinterpret_cast<__bf16*>(x)[o] = (__bf16)v; return; }      // (never with accumulate: conv_dgrad_impl)
         if (accumulate) v += x[o];
         x[o] = v;
     }
@@ -633,7 +636,7 @@ __device__ __forceinline__ void fused_epilogue(const P& p, f32x16 (&acc)[TM][TN]
                         v = ((wd >> (col & 31)) & 1u) ? v : v * EPI_LRELU_SLOPE;
                     }
                     if (ok) {
-                        if ((mode & EPI_ACT) && e.out16) reinterpret_cast<__bf16*>(out)[o] = (__bf16)v;
+                        if (e.out16) reinterpret_cast<__bf16*>(out)[o] = (__bf16)v;
                         else out[o] = v;
                     }
                     if (mode & EPI_SUMS) {
@@ -1533,7 +1536,8 @@ __global__ __launch_bounds__(NTHREADS) void dgrad_c4_kernel(Geom g, const float*
 bool c4_fprop_ok(const Geom& g, const Epi& e) {
     const long long frame = (long long)g.Ti * g.Hi * g.Wi * g.Ci;
     return g.Ci == 4 && g.Co == 64 && (g.Wo == 32 || g.Wo == 16) && g.Ho % (256 / g.Wo) == 0 && !g.perm_n && g.xs0 == frame &&
-           g.prec != MCG_PREC_BF16_STORE && (e.mode == 0 || e.mode == EPI_ACT);          // (this layer's tensors are fp32 in memory)
+           g.prec != MCG_PREC_BF16_STORE && (e.mode == 0 || e.mode == EPI_ACT) &&        // (this layer's tensors are fp32 in memory)
+           (!e.out16 || e.mode == EPI_ACT);
 }
 
 template <int KT, int WO>
@@ -1563,7 +1567,7 @@ bool c4_dgrad_mfma_ok(const Geom& g, const Epi& e, const float* bias, int act, i
     // (T,N) -> (N,T) frame permutation, which maps the N frames one-to-one onto it
     const bool whole = g.perm_n ? (g.xs1 == frame && g.xs0 == (long long)(g.N / g.perm_n) * frame) : g.xs0 == frame;
     return g.Ci == 4 && g.cv <= 3 && g.Co == 64 && (g.Wo == 32 || g.Wo == 16) && g.Ho % (128 / g.Wo) == 0 && whole &&
-           !e.mode && !bias && act == MCG_ACT_NONE && !accumulate;
+           !e.mode && !e.out16 && !bias && act == MCG_ACT_NONE && !accumulate;
 }
 
 template <int KT, int WO, bool BF>
@@ -2025,13 +2029,14 @@ int make_epi(const mcg_conv_epilogue* ep, const Geom& g, int pass, Epi& e) {
         e.addend[0] = ep->addend[0]; e.addend[1] = ep->addend[1];
         e.sigma = ep->sigma; e.seed = ep->seed; e.stream[0] = ep->stream_id[0]; e.stream[1] = ep->stream_id[1];
         e.mask_out = ep->mask_out;
-        e.out16 = ep->out_bf16 ? 1 : 0;
-    } else if (ep->mask_out || ep->out_bf16) return MCG_ERR_BAD_ARG;
+    } else if (ep->mask_out) return MCG_ERR_BAD_ARG;
+    e.out16 = ep->out_bf16 ? 1 : 0;
     if (ep->mask_in) {
         if (pass != 1) return MCG_ERR_UNSUPPORTED;
         e.mode |= EPI_MASKMUL; e.mask_in = ep->mask_in;
     }
-    if (e.mode && g.ksplit > 1) return MCG_ERR_UNSUPPORTED;        // partial tiles cannot carry an epilogue
+    if ((e.mode || e.out16) && g.ksplit > 1) return MCG_ERR_UNSUPPORTED;        // partial tiles cannot carry an epilogue (and are added in fp32)
+    if (e.out16 && (e.mode & EPI_BNBWD)) return MCG_ERR_UNSUPPORTED;
     if ((e.mode & EPI_ACT) && (e.mode & ~EPI_ACT)) return MCG_ERR_UNSUPPORTED;            // one class per launch (epi_class)
     if ((e.mode & EPI_BNBWD) && (e.mode & ~EPI_BNBWD)) return MCG_ERR_UNSUPPORTED;
     return MCG_OK;
@@ -2128,6 +2133,7 @@ int conv_dgrad_impl(const mcg_conv_geom* c, const float* y, const float* w, cons
         const long long frame_ = (long long)g.Ti * g.Hi * g.Wi * g.Ci;
         if (g.perm_n || g.xs0 != frame_ || act != MCG_ACT_NONE || accumulate) return MCG_ERR_UNSUPPORTED;
     }
+    if (e.out16 && (accumulate || g.Ci == 4)) return MCG_ERR_UNSUPPORTED;   // (the clip-side kernels and accumulating calls write fp32)
     hipStream_t s = (hipStream_t)stream;
     long long M = (long long)g.N * g.Ti * g.Ho * g.Wo;
     int t = g.tile;

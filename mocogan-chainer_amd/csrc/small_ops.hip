@@ -25,6 +25,12 @@ __device__ __forceinline__ void store4(float* out, long long i4, f32x4 v, int ou
     if (out16) reinterpret_cast<bf16x4_t*>(out)[i4] = __builtin_convertvector(v, bf16x4_t);
     else reinterpret_cast<f32x4*>(out)[i4] = v;
 }
+// the four elements starting at ELEMENT offset e (a multiple of 4) of a tensor that is fp32 or (in16) bf16 in memory: bf16
+// networks also keep the GEMM OUTPUTS the element-wise passes read -- pre-BatchNorm activations, input gradients -- in bf16
+__device__ __forceinline__ f32x4 load4(const float* in, long long e, int in16) {
+    if (in16) return __builtin_convertvector(*reinterpret_cast<const bf16x4_t*>(reinterpret_cast<const __bf16*>(in) + e), f32x4);
+    return *reinterpret_cast<const f32x4*>(in + e);
+}
 
 __device__ __forceinline__ float act_fwd(float v, int act) {
     if (act == MCG_ACT_RELU) return fmaxf(v, 0.f);
@@ -48,11 +54,12 @@ __device__ __forceinline__ float act_mask(float v, int act) {
 // Thread layout: C4 = C/4 float4 columns, NT/C4 row lanes per pass; the block's row lanes are
 // combined through LDS; part[block][2][C].
 // ------------------------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, int IO = 0>                      // IO: MCG_IO_* flags of a (G) and y (Y), compile-time (see bn_act_fwd_kernel)
 __global__ __launch_bounds__(NT) void col_partial_kernel(long long M, int C, long long rows_per_block,
                                                          const float* __restrict__ a, const float* __restrict__ y,
                                                          const float* __restrict__ stats, int act,
                                                          float* __restrict__ part) {
+    constexpr int io = IO;
     __shared__ f32x4 red[2][NT];
     const int C4 = C >> 2;
     const int c4 = threadIdx.x % C4, rl = threadIdx.x / C4, RL = NT / C4;
@@ -70,11 +77,11 @@ __global__ __launch_bounds__(NT) void col_partial_kernel(long long M, int C, lon
         // four rows in flight per thread: with at most MAX_PART blocks on the chip a single dependent load per iteration
         // leaves the pass latency-bound (measured 3.3 TB/s); the sums of a row quad are added in a fixed order
         auto row = [&](long long r, f32x4& t0, f32x4& t1) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(a + r * C + c4 * 4);
+            f32x4 v = load4(a, r * C + c4 * 4, io & MCG_IO_G_BF16);
             if (MODE == 0) { t0 = v; t1 = v * v; }
             else if (MODE == 2) { t0 = v; }
             else {
-                f32x4 yy = *reinterpret_cast<const f32x4*>(y + r * C + c4 * 4);
+                f32x4 yy = load4(y, r * C + c4 * 4, io & MCG_IO_Y_BF16);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     float gb = v[i] * act_mask(fmaf(yy[i], sc[i], sh[i]), act);
@@ -247,17 +254,20 @@ __global__ __launch_bounds__(FIN_CH * FIN_SL) void colsum_finalize_kernel(int nb
 }
 
 // out = act(y*scale+shift) + noise
+template <int IO>        // MCG_IO_* flags as a compile-time constant: a run-time element type puts a branch (and a wait) around every load
 __global__ __launch_bounds__(NT) void bn_act_fwd_kernel(long long n4, int C, int c_valid, const float* __restrict__ y,
                                                         long long item4, long long item_stride,
                                                         const float* __restrict__ ss, int act,
                                                         const float* __restrict__ addend, float sigma,
-                                                        uint64_t seed, uint64_t stream_id, float* __restrict__ out, int out16) {
+                                                        uint64_t seed, uint64_t stream_id, float* __restrict__ out) {
+    constexpr int io = IO;
     const int C4 = C >> 2;
-    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long long)gridDim.x * NT) {
-        int c4 = (int)(i % C4);
-        // source may be a batch-strided view (frame t of a clip tensor): item = i / item4
-        long long src = item4 ? (i / item4) * item_stride + (i % item4) * 4 : i * 4;
-        f32x4 v = *reinterpret_cast<const f32x4*>(y + src);
+    constexpr int out16 = io & MCG_IO_OUT_BF16;
+    const long long stride = (long long)gridDim.x * NT;
+    // source may be a batch-strided view (frame t of a clip tensor): item = i / item4
+    auto src_of = [&](long long i) { return item4 ? (i / item4) * item_stride + (i % item4) * 4 : i * 4; };
+    auto finish = [&](long long i, f32x4 v) {
+        const int c4 = (int)(i % C4);
         if (ss) {
             f32x4 sc = *reinterpret_cast<const f32x4*>(ss + c4 * 4);
             f32x4 sh = *reinterpret_cast<const f32x4*>(ss + C + c4 * 4);
@@ -274,18 +284,29 @@ __global__ __launch_bounds__(NT) void bn_act_fwd_kernel(long long n4, int C, int
             for (int k = 0; k < 4; ++k) if (c4 * 4 + k < c_valid) v[k] = fmaf(sigma, z[k], v[k]);
         }
         store4(out, i, v, out16);
+    };
+    // two groups of four per trip, both loads issued before either is used: with bf16 tensors a group is an 8-byte access,
+    // and one per thread in flight leaves the pass latency-bound
+    for (long long i0 = (long long)blockIdx.x * NT + threadIdx.x; i0 < n4; i0 += 2 * stride) {
+        const long long i1 = i0 + stride < n4 ? i0 + stride : i0;          // (the tail repeats group 0's load, its result is dropped)
+        const f32x4 v0 = load4(y, src_of(i0), io & MCG_IO_Y_BF16);
+        const f32x4 v1 = load4(y, src_of(i1), io & MCG_IO_Y_BF16);
+        finish(i0, v0);
+        if (i1 != i0) finish(i1, v1);
     }
 }
 
 // gx = coef0 * (g*mask - x_hat*coef1 - coef2)    (BN)   or   gx = g*mask(y) / g*(1-y^2)  (no BN)
+template <int IO>
 __global__ __launch_bounds__(NT) void bn_act_bwd_apply_kernel(long long n4, int C, const float* __restrict__ g,
                                                               const float* __restrict__ y, const float* __restrict__ stats,
-                                                              const float* __restrict__ coef, int act, float* __restrict__ gx, int out16) {
+                                                              const float* __restrict__ coef, int act, float* __restrict__ gx) {
+    constexpr int io = IO;
     const int C4 = C >> 2;
-    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long long)gridDim.x * NT) {
-        int c4 = (int)(i % C4);
-        f32x4 gv = *reinterpret_cast<const f32x4*>(g + i * 4);
-        f32x4 yv = *reinterpret_cast<const f32x4*>(y + i * 4);
+    constexpr int out16 = io & MCG_IO_OUT_BF16;
+    const long long stride = (long long)gridDim.x * NT;
+    auto finish = [&](long long i, const f32x4& gv, const f32x4& yv) {
+        const int c4 = (int)(i % C4);
         f32x4 o;
         if (stats) {
             f32x4 mean = *reinterpret_cast<const f32x4*>(stats + c4 * 4);
@@ -307,6 +328,13 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_apply_kernel(long long n4, int 
                 o[k] = act == MCG_ACT_TANH ? gv[k] * (1.f - yv[k] * yv[k]) : gv[k] * act_mask(yv[k], act);
         }
         store4(gx, i, o, out16);
+    };
+    for (long long i0 = (long long)blockIdx.x * NT + threadIdx.x; i0 < n4; i0 += 2 * stride) {      // (as bn_act_fwd_kernel)
+        const long long i1 = i0 + stride < n4 ? i0 + stride : i0;
+        const f32x4 g0 = load4(g, i0 * 4, io & MCG_IO_G_BF16), y0 = load4(y, i0 * 4, io & MCG_IO_Y_BF16);
+        const f32x4 g1 = load4(g, i1 * 4, io & MCG_IO_G_BF16), y1 = load4(y, i1 * 4, io & MCG_IO_Y_BF16);
+        finish(i0, g0, y0);
+        if (i1 != i0) finish(i1, g1, y1);
     }
 }
 
@@ -839,16 +867,39 @@ extern "C" int mcg_bn_act_fwd(int64_t M, int C, int c_valid, const float* y, int
     if (!y || !out || M <= 0 || C <= 0 || (C & 3)) return MCG_ERR_BAD_ARG;
     if (y_rows_per_item < 0 || (y_rows_per_item > 0 && (M % y_rows_per_item || (y_item_stride & 3)))) return MCG_ERR_BAD_ARG;
     long long n4 = (long long)M * (C >> 2);
-    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(n4)), dim3(NT), 0, (hipStream_t)stream, n4, C, c_valid, y,
-                       (long long)y_rows_per_item * (C >> 2), (long long)y_item_stride, scale_shift, act,
-                       addend, sigma, seed, stream_id, (float*)out, out_bf16);
+    if (out_bf16 & ~(MCG_IO_OUT_BF16 | MCG_IO_Y_BF16)) return MCG_ERR_BAD_ARG;
+#define MCG_FWD(IO_) hipLaunchKernelGGL(bn_act_fwd_kernel<IO_>, dim3(ew_grid(n4)), dim3(NT), 0, (hipStream_t)stream, n4, C, c_valid, y, \
+                       (long long)y_rows_per_item * (C >> 2), (long long)y_item_stride, scale_shift, act,                             \
+                       addend, sigma, seed, stream_id, (float*)out)
+    switch (out_bf16) { case 0: MCG_FWD(0); break; case 1: MCG_FWD(1); break; case 2: MCG_FWD(2); break; default: MCG_FWD(3); }
+#undef MCG_FWD
     return launch_status();
+}
+
+// launches of the two BatchNorm-backward kernels for a run-time set of MCG_IO_* flags (compile-time in the kernels)
+static void launch_bwd_partial(int io, int blocks, hipStream_t s, long long M, int C, long long rows_per_block, const float* g_out,
+                               const float* y, const float* stats, int act, float* part) {
+#define MCG_CP(IO_) hipLaunchKernelGGL((col_partial_kernel<1, IO_>), dim3(blocks), dim3(NT), 0, s, M, C, rows_per_block, g_out, y, stats, act, part)
+    switch (io & (MCG_IO_Y_BF16 | MCG_IO_G_BF16)) {
+        case 0: MCG_CP(0); break;
+        case MCG_IO_Y_BF16: MCG_CP(MCG_IO_Y_BF16); break;
+        case MCG_IO_G_BF16: MCG_CP(MCG_IO_G_BF16); break;
+        default: MCG_CP(MCG_IO_Y_BF16 | MCG_IO_G_BF16);
+    }
+#undef MCG_CP
+}
+static void launch_bwd_apply(int io, hipStream_t s, long long n4, int C, const float* g_out, const float* y, const float* stats,
+                             const float* coef, int act, float* gx) {
+#define MCG_AP(IO_) case IO_: hipLaunchKernelGGL(bn_act_bwd_apply_kernel<IO_>, dim3(ew_grid(n4)), dim3(NT), 0, s, n4, C, g_out, y, stats, coef, act, gx); break
+    switch (io & 7) { MCG_AP(0); MCG_AP(1); MCG_AP(2); MCG_AP(3); MCG_AP(4); MCG_AP(5); MCG_AP(6); MCG_AP(7); }
+#undef MCG_AP
 }
 
 extern "C" int mcg_bn_act_bwd(int64_t M, int C, const float* g_out, const float* y, const float* stats, const float* gamma, int act,
                               void* gx, int gx_bf16, float* dgamma, float* dbeta, void* workspace, void* stream) {
     if (!g_out || !y || !gx || M <= 0 || C <= 0 || (C & 3)) return MCG_ERR_BAD_ARG;
-    if (gx_bf16 && gx == (const void*)g_out) return MCG_ERR_BAD_ARG;            // a bf16 result cannot overwrite its fp32 input
+    // gx_bf16: MCG_IO_* flags (OUT = gx, Y = y, G = g_out).  In place only between tensors of one element type
+    if (gx == (const void*)g_out && !(gx_bf16 & MCG_IO_OUT_BF16) != !(gx_bf16 & MCG_IO_G_BF16)) return MCG_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     long long n4 = (long long)M * (C >> 2);
     float* coef = nullptr;
@@ -858,11 +909,11 @@ extern "C" int mcg_bn_act_bwd(int64_t M, int C, const float* g_out, const float*
         PartPlan pl = plan_partial(M, C);
         float* part = (float*)workspace;
         coef = part + (long long)MAX_PART * 2 * C;
-        hipLaunchKernelGGL(col_partial_kernel<1>, dim3(pl.blocks), dim3(NT), 0, s, (long long)M, C, pl.rows_per_block, g_out, y, stats, act, part);
+        launch_bwd_partial(gx_bf16, pl.blocks, s, (long long)M, C, pl.rows_per_block, g_out, y, stats, act, part);
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, pl.blocks, C, 1.0 / (double)M, part, stats, gamma,
                            coef, dgamma, dbeta, 0LL);
     }
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(NT), 0, s, n4, C, g_out, y, stats, coef, act, (float*)gx, gx_bf16);
+    launch_bwd_apply(gx_bf16, s, n4, C, g_out, y, stats, coef, act, (float*)gx);
     return launch_status();
 }
 
@@ -870,14 +921,14 @@ extern "C" int mcg_bn_act_bwd_from_partials(int64_t M, int C, const float* g_out
                                             const float* part, int n_slots, int slot_stride, void* gx, int gx_bf16, float* dgamma, float* dbeta,
                                             void* workspace, void* stream) {
     if (!g_out || !y || !gx || !stats || !gamma || !part || !workspace || M <= 0 || bad_c(C) || n_slots <= 0 || slot_stride < 2 * C) return MCG_ERR_BAD_ARG;
-    if (gx_bf16 && gx == (const void*)g_out) return MCG_ERR_BAD_ARG;
+    if (gx == (const void*)g_out && !(gx_bf16 & MCG_IO_OUT_BF16) != !(gx_bf16 & MCG_IO_G_BF16)) return MCG_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     float* coef = (float*)workspace + (long long)MAX_PART * 2 * C;
     const Folded f = fold_slots(part, n_slots, slot_stride, C, (float*)workspace, s);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, f.n, C, 1.0 / (double)M, f.part, stats, gamma,
                        coef, dgamma, dbeta, f.stride);
     long long n4 = (long long)M * (C >> 2);
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(NT), 0, s, n4, C, g_out, y, stats, coef, act, (float*)gx, gx_bf16);
+    launch_bwd_apply(gx_bf16, s, n4, C, g_out, y, stats, coef, act, (float*)gx);
     return launch_status();
 }
 
@@ -930,7 +981,7 @@ extern "C" int mcg_bn_act_bwd_from_sums(int64_t M, int64_t M_total, int C, const
     hipLaunchKernelGGL(bn_bwd_from_sums_kernel, dim3((C + 63) / 64), dim3(64), 0, s, C, 1.0 / (double)M_total, local_sums, global_sums, stats, gamma,
                        coef, dgamma, dbeta);
     long long n4 = (long long)M * (C >> 2);
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(NT), 0, s, n4, C, g_out, y, stats, coef, act, gx, 0);
+    launch_bwd_apply(0, s, n4, C, g_out, y, stats, coef, act, gx);
     return launch_status();
 }
 

@@ -32,6 +32,7 @@ class ConvGeom(C.Structure):
 
 
 SUMS_NONE, SUMS_STATS, SUMS_BN_BWD, SUMS_COL = 0, 1, 2, 3
+IO_OUT_BF16, IO_Y_BF16, IO_G_BF16 = 1, 2, 4          # MCG_IO_*: which tensors of an element-wise call are bf16
 
 
 class ConvEpilogue(C.Structure):
@@ -349,11 +350,16 @@ def _scratch_like(g, which):
 # thin typed wrappers (tensors in; nothing allocated here except the one-off tuning scratch)
 # ------------------------------------------------------------------------------------------
 def _fprop(g, x, w, bias, y):
+    if y.dtype == torch.bfloat16:                     # bf16 output: the flag travels in an (otherwise empty) epilogue
+        return _fprop_ex(g, x, w, bias, y, epilogue(out_bf16=True), split_ok=True)
     g = _with_override(g)
     _check(load().mcg_conv_fprop(C.byref(g), _pin(g, x), _pin(g, _dense(w)), _p(bias), _p(_dense(y)), _stream()), "mcg_conv_fprop")
 
 
 def _dgrad(g, y, w, bias, x, act, accumulate):
+    if x.dtype == torch.bfloat16:
+        assert act == ACT_NONE and not accumulate
+        return _dgrad_ex(g, y, w, bias, x, epilogue(out_bf16=True), split_ok=True)
     g = _with_override(g)
     _check(load().mcg_conv_dgrad(C.byref(g), _pin(g, _dense(y)), _pin(g, _dense(w)), _p(bias), _p(x), act, int(accumulate), _stream()),
            "mcg_conv_dgrad")
@@ -400,15 +406,20 @@ def _no_split(g):
     return gg
 
 
-def _fprop_ex(g, x, w, bias, y, ep):
-    g = _no_split(_with_override(g))
+def _fprop_ex(g, x, w, bias, y, ep, split_ok=False):
+    """split_ok: leave a split-K tile code in place (the library then refuses it for a bf16 output: the caller asked
+    fprop_tile / dgrad_tile first)"""
+    g = _with_override(g) if split_ok else _no_split(_with_override(g))
+    assert bool(ep.out_bf16) == (y.dtype == torch.bfloat16)
     yp = _p(_dense(y), torch.bfloat16) if ep.out_bf16 else _p(_dense(y))
     _check(load().mcg_conv_fprop_ex(C.byref(g), _pin(g, x), _pin(g, _dense(w)), _p(bias), yp, C.byref(ep), _stream()), "mcg_conv_fprop_ex")
 
 
-def _dgrad_ex(g, y, w, bias, x, ep):
-    g = _no_split(_with_override(g))
-    _check(load().mcg_conv_dgrad_ex(C.byref(g), _pin(g, _dense(y)), _pin(g, _dense(w)), _p(bias), _p(_dense(x)), C.byref(ep), _stream()),
+def _dgrad_ex(g, y, w, bias, x, ep, split_ok=False):
+    g = _with_override(g) if split_ok else _no_split(_with_override(g))
+    assert bool(ep.out_bf16) == (x.dtype == torch.bfloat16)
+    xp = _p(_dense(x), torch.bfloat16) if ep.out_bf16 else _p(_dense(x))
+    _check(load().mcg_conv_dgrad_ex(C.byref(g), _pin(g, _dense(y)), _pin(g, _dense(w)), _p(bias), xp, C.byref(ep), _stream()),
            "mcg_conv_dgrad_ex")
 
 
@@ -419,6 +430,20 @@ def dgrad_c4_mfma_covers(g):
     whole = (g.x_stride1 == frame and g.x_stride0 == (g.N // g.x_perm_n) * frame) if g.x_perm_n else g.x_stride0 == frame
     return (g.Ci == 4 and 0 < g.ci_valid <= 3 and g.Co == 64 and g.Wo in (16, 32) and g.Ho % (128 // g.Wo) == 0 and whole
             and g.precision != PREC_BF16_STORE and _with_override(g).tile in (0, 6))
+
+
+def fprop_tile(g, x, w, bias):
+    """the tile code conv_fprop will use for this geometry (tuned now if it has to be): codes >= 1000 split K, and a split
+    launch can neither carry an epilogue nor write a bf16 output -- callers that want either ask before they allocate"""
+    if _autotune and not g.tile:
+        g = _tuned("fprop", g, (), 'y', lambda gg, out: _fprop(gg, x, w, bias, out))
+    return _with_override(g).tile
+
+
+def dgrad_tile(g, y, w, bias, act=ACT_NONE, accumulate=False):
+    if _autotune and not g.tile:
+        g = _tuned("dgrad", g, (act, int(accumulate)), 'x', lambda gg, out: _dgrad(gg, y, w, bias, out, act, accumulate))
+    return _with_override(g).tile
 
 
 def conv_fprop(g, x, w, bias, y, ep=None, must_fuse=False):
@@ -488,14 +513,18 @@ def bn_act_fwd(M, Cn, y, scale_shift, act, out, addend=None, sigma=0.0, seed=0, 
     if rows_per_item == 0:
         _dense(y)
     op, o16 = _pany(_dense(out))
-    _check(load().mcg_bn_act_fwd(M, Cn, Cn if c_valid is None else c_valid, _p(y), rows_per_item, item_stride, _p(scale_shift), act,
-                                 _p(_dense(addend)), sigma, seed, stream_id, op, o16, _stream()), "mcg_bn_act_fwd")
+    yp, y16 = _pany(y)
+    _check(load().mcg_bn_act_fwd(M, Cn, Cn if c_valid is None else c_valid, yp, rows_per_item, item_stride, _p(scale_shift), act,
+                                 _p(_dense(addend)), sigma, seed, stream_id, op, IO_OUT_BF16 * o16 + IO_Y_BF16 * y16, _stream()),
+           "mcg_bn_act_fwd")
 
 
 def bn_act_bwd(M, Cn, g_out, y, stats, gamma, act, gx, dgamma, dbeta, ws, sync=None):
     if sync is None or sync.world == 1 or stats is None:
         gp, g16 = _pany(_dense(gx))
-        _check(load().mcg_bn_act_bwd(M, Cn, _p(_dense(g_out)), _p(_dense(y)), _p(stats), _p(gamma), act, gp, g16,
+        ip, i16 = _pany(_dense(g_out))
+        yp, y16 = _pany(_dense(y))
+        _check(load().mcg_bn_act_bwd(M, Cn, ip, yp, _p(stats), _p(gamma), act, gp, IO_OUT_BF16 * g16 + IO_Y_BF16 * y16 + IO_G_BF16 * i16,
                                      _p(dgamma), _p(dbeta), _p(ws), _stream()), "mcg_bn_act_bwd")
         return
     local = torch.empty(2 * Cn, dtype=torch.float64, device=y.device)
@@ -516,9 +545,11 @@ def bn_stats_from_partials(M, Cn, part, n_slots, slot_stride, gamma, beta, stats
 
 def bn_act_bwd_from_partials(M, Cn, g_out, y, stats, gamma, act, part, n_slots, slot_stride, gx, dgamma, dbeta, ws):
     gp, g16 = _pany(_dense(gx))
-    _check(load().mcg_bn_act_bwd_from_partials(M, Cn, _p(_dense(g_out)), _p(_dense(y)), _p(stats), _p(gamma), act, _p(part), n_slots,
-                                               slot_stride, gp, g16, _p(dgamma), _p(dbeta), _p(ws), _stream()),
-           "mcg_bn_act_bwd_from_partials")
+    ip, i16 = _pany(_dense(g_out))
+    yp, y16 = _pany(_dense(y))
+    _check(load().mcg_bn_act_bwd_from_partials(M, Cn, ip, yp, _p(stats), _p(gamma), act, _p(part), n_slots, slot_stride, gp,
+                                               IO_OUT_BF16 * g16 + IO_Y_BF16 * y16 + IO_G_BF16 * i16, _p(dgamma), _p(dbeta), _p(ws),
+                                               _stream()), "mcg_bn_act_bwd_from_partials")
 
 
 def colsum_from_partials(Cn, part, n_slots, slot_stride, db, ws):

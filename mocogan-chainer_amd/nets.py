@@ -30,6 +30,7 @@ IMG = 64                      # output size hard-coded in the reference, model/n
 #   bwd  : the per-channel sums of BatchNorm's backward pass from the GEMM that produces the incoming gradient
 #          (off by default: measured on MI355X it costs the producing GEMMs more -- they read the saved BatchNorm input
 #          in their epilogue -- than the removed reduction pass took: +0.20 ms against -0.18 ms per iteration at batch 32)
+OUT16 = os.environ.get('MCG_OUT16', '1') == '1'        # bf16 networks: GEMM outputs in bf16 where the schedule allows (A/B switch)
 FUSE = set(filter(None, os.environ.get('MCG_FUSE', 'stats,dc1').split(',')))
 
 
@@ -376,11 +377,15 @@ class DisNet(_Net):
                               ep=hl.epilogue(act=hl.ACT_LRELU, groups=G, mask_out=mask, out_bf16=adt == torch.bfloat16, **kw))
                 saved['y'][1], saved['mask1'], saved['a'][2] = None, mask, a
                 continue
-            y = torch.empty((N, g.To, g.Ho, g.Wo, co), device=dev)
+            # bf16 networks: the pre-BatchNorm values are bf16 too (the element-wise passes that read them are HBM-bound)
+            # -- unless the tuned tile splits K (partial tiles are added in fp32) or the statistics need the stand-alone pass
+            y16 = (OUT16 and l >= 2 and self._s16(l) and self.sync_bn is None and (fuse_stats or not train)
+                   and hl.fprop_tile(g, a, w, b) < 1000)
+            y = torch.empty((N, g.To, g.Ho, g.Wo, co), device=dev, dtype=torch.bfloat16 if y16 else torch.float32)
             ep = None
             if l >= 2 and fuse_stats:
                 part = self._part_buf(g, 'fprop', G)
-                ep = hl.epilogue(sums=hl.SUMS_STATS, groups=G, part=part)
+                ep = hl.epilogue(sums=hl.SUMS_STATS, groups=G, part=part, out_bf16=y16)
                 if not hl.conv_fprop(g, a, w, b, y, ep=ep):
                     ep = None                                    # split-K tile: the stand-alone statistics pass below
             else:
@@ -503,8 +508,11 @@ class DisNet(_Net):
                     self._after_wgrads(on_late_bucket)
             pending = None
             if l > 1:
-                ga = torch.empty_like(saved['a'][l], dtype=torch.float32)
                 w = self._w('dc%d/W' % l, s16)
+                # bf16 networks: the gradient BatchNorm's backward of layer l - 1 reads is bf16 as well (see forward_groups)
+                g16 = (OUT16 and l > 2 and s16 and self.sync_bn is None and not fuse_bwd
+                       and hl.dgrad_tile(geom, g, w, None) < 1000)
+                ga = torch.empty_like(saved['a'][l], dtype=torch.bfloat16 if g16 else torch.float32)
                 if l == 2 and mask1 is not None:
                     part = self._part_buf(geom, 'dgrad', 1) if param_grads else None
                     ep = hl.epilogue(mask_in=mask1, sums=hl.SUMS_COL if param_grads else hl.SUMS_NONE, groups=1, part=part)
@@ -697,9 +705,13 @@ class GenNet(_Net):
                 y = torch.empty((frames, h, h, self.chans[l + 1]), device=dev)
                 geom = self._geom(l + 1, frames)
                 w, b = self._w('dc%d/W' % (l + 1), self._s16(l + 1)), fp.param('dc%d/b' % (l + 1))
+                y16 = (OUT16 and self._s16(l + 1) and self.sync_bn is None and (fuse_stats or not train)
+                       and hl.dgrad_tile(geom, a, w, b) < 1000)                    # (as DisNet.forward_groups)
+                if y16:
+                    y = torch.empty_like(y, dtype=torch.bfloat16)
                 if fuse_stats:
                     part = self._part_buf(geom, 'dgrad', 1)
-                    ep = hl.epilogue(sums=hl.SUMS_STATS, groups=1, part=part)
+                    ep = hl.epilogue(sums=hl.SUMS_STATS, groups=1, part=part, out_bf16=y16)
                     if hl.conv_dgrad(geom, a, w, b, y, ep=ep):
                         pending = (ep, part)
                 else:
@@ -759,9 +771,11 @@ class GenNet(_Net):
             self._wgrad(geom, g, saved['a'][l], fp.grad('dc%d/W' % l))
             if l == 2 and on_late_bucket is not None:
                 self._after_wgrads(on_late_bucket)
-            ga = torch.empty_like(saved['a'][l], dtype=torch.float32)
-            pending = None
             wl = self._w('dc%d/W' % l, s16)
+            g16 = (OUT16 and 2 < l < 5 and s16 and self.sync_bn is None and not fuse_bwd       # (layer 1's gradient feeds the fp32 fully-connected layer)
+                   and hl.fprop_tile(geom, g, wl, None) < 1000)                            # (as DisNet.backward)
+            ga = torch.empty_like(saved['a'][l], dtype=torch.bfloat16 if g16 else torch.float32)
+            pending = None
             if fuse_bwd and not s16:     # ga is the gradient w.r.t. relu(bn_{l-1}(y_{l-1})): the sums of that BatchNorm's backward
                 part = self._part_buf(geom, 'fprop', 1)
                 ep = hl.epilogue(sums=hl.SUMS_BN_BWD, groups=1, part=part, bn_y=saved['y'][l - 1], bn_stats=[saved['stats'][l - 1]],

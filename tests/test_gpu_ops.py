@@ -779,3 +779,76 @@ def test_elementwise_passes_write_bf16_operands(hl):
     p16 = torch.zeros(n, device="cuda", dtype=torch.bfloat16)
     hl.adam_wd(p, gr, m, v, 2e-4, 5e-5, 0.999, 1e-8, 1e-5, p16=p16)
     assert torch.equal(p16, p.to(torch.bfloat16))
+    # bf16 INPUTS (the GEMM outputs of a bf16 network): the same numbers held in bf16 or in fp32 give the same results, bit
+    # for bit, whatever the mix of element types (MCG_IO_* flags); in place on a bf16 gradient too
+    yb, gb = y.to(torch.bfloat16), g.to(torch.bfloat16)
+    yr, gr_ = yb.float(), gb.float()
+    hl.bn_stats(M, C, yr, gamma, beta, stats, None, None, ws)
+    ref_f = torch.empty((M, C), device="cuda")
+    hl.bn_act_fwd(M, C, yr, stats[2 * C:], hl.ACT_LRELU, ref_f, sigma=0.2, seed=3, stream_id=9)
+    for out_dt in (torch.float32, torch.bfloat16):
+        o = torch.empty((M, C), device="cuda", dtype=out_dt)
+        hl.bn_act_fwd(M, C, yb, stats[2 * C:], hl.ACT_LRELU, o, sigma=0.2, seed=3, stream_id=9)
+        assert torch.equal(o, ref_f.to(out_dt)), out_dt
+    ref_b, dg_ref, db_ref = torch.empty((M, C), device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    hl.bn_act_bwd(M, C, gr_, yr, stats, gamma, hl.ACT_LRELU, ref_b, dg_ref, db_ref, ws)
+    for g_in in (gr_, gb):
+        for y_in in (yr, yb):
+            for out_dt in (torch.float32, torch.bfloat16):
+                o, dg, db = torch.empty((M, C), device="cuda", dtype=out_dt), torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+                hl.bn_act_bwd(M, C, g_in, y_in, stats, gamma, hl.ACT_LRELU, o, dg, db, ws)
+                assert torch.equal(o, ref_b.to(out_dt)) and torch.equal(dg, dg_ref) and torch.equal(db, db_ref), (g_in.dtype, y_in.dtype, out_dt)
+    gi = gb.clone()
+    hl.bn_act_bwd(M, C, gi, yb, stats, gamma, hl.ACT_LRELU, gi, None, None, ws)            # in place, bf16 -> bf16
+    assert torch.equal(gi, ref_b.to(torch.bfloat16))
+    alias = torch.empty(0, dtype=torch.bfloat16, device="cuda").set_(gr_.untyped_storage(), 0, (M, C), (C, 1))
+    assert alias.data_ptr() == gr_.data_ptr()
+    with pytest.raises(hl.McgError):                                                       # in place across element types: refused
+        hl.bn_act_bwd(M, C, gr_, yb, stats, gamma, hl.ACT_LRELU, alias, None, None, ws)
+
+
+BF16_OUT_CASES = [(2, 7, 16, 64, 128, 4), (4, 1, 16, 128, 64, 1)]
+
+
+@pytest.mark.parametrize("case", BF16_OUT_CASES)
+def test_bf16_gemm_outputs(hl, case):
+    """bf16 networks keep the GEMM outputs the element-wise passes read in bf16: a launch that writes y (fprop) or x (dgrad)
+    in bf16 stores the round-to-nearest-even of what the fp32 launch stores -- plain and with the statistics epilogue, whose
+    sums stay those of the unrounded values; split-K, accumulating and first-layer launches refuse a bf16 output."""
+    N, Ti, H, Ci, Co, kt = case
+    rng = np.random.RandomState(hash(case) % 2**31 + 9)
+    lay = L()
+    x, W = _bf16_round(rng.uniform(-1, 1, (N, Ci, Ti, H, H))), _bf16_round(rng.randn(Co, Ci, kt, 4, 4) * 0.1)
+    b = rng.randn(Co)
+    gy = _bf16_round(rng.randn(N, Co, Ti - kt + 1, H // 2, H // 2))
+    xd, wd, bd, gyd = lay.act_to_dev(dev(x)), lay.conv_w_to_dev(dev(W)), dev(b), lay.act_to_dev(dev(gy))
+    x16, w16, gy16 = xd.to(torch.bfloat16), wd.to(torch.bfloat16), gyd.to(torch.bfloat16)
+    for tile in (0, 2, 3):
+        g = hl.make_geom(N, Ti, H, H, Ci, Co, kt, precision='bf16s')
+        g.tile = tile
+        y32 = torch.empty((N, g.To, g.Ho, g.Wo, Co), device="cuda")
+        y16 = torch.empty_like(y32, dtype=torch.bfloat16)
+        hl.conv_fprop(g, x16, w16, bd, y32)
+        hl.conv_fprop(g, x16, w16, bd, y16)
+        assert torch.equal(y16, y32.to(torch.bfloat16)), tile
+        M = N * g.To * g.Ho * g.Wo
+        parts = []
+        for out in (y32, y16):
+            part = torch.zeros(hl.epilogue_part_floats(g, 'fprop', 1), device="cuda")
+            ep = hl.epilogue(sums=hl.SUMS_STATS, groups=1, part=part, out_bf16=out.dtype == torch.bfloat16)
+            out.zero_()
+            assert hl.conv_fprop(g, x16, w16, bd, out, ep=ep, must_fuse=True)
+            parts.append((part, ep.n_slots, ep.slot_stride))
+        assert torch.equal(y16, y32.to(torch.bfloat16)) and torch.equal(parts[0][0], parts[1][0]) and parts[0][1:] == parts[1][1:], tile
+        gx32 = torch.empty_like(xd)
+        gx16 = torch.empty_like(xd, dtype=torch.bfloat16)
+        hl.conv_dgrad(g, gy16, w16, None, gx32)
+        hl.conv_dgrad(g, gy16, w16, None, gx16)
+        assert torch.equal(gx16, gx32.to(torch.bfloat16)), tile
+    g = hl.make_geom(N, Ti, H, H, Ci, Co, kt, precision='bf16s')
+    g.tile = 1203                                                  # split K: partial tiles are added in fp32
+    with pytest.raises(hl.McgError):
+        hl.conv_fprop(g, x16, w16, bd, torch.empty((N, g.To, g.Ho, g.Wo, Co), device="cuda", dtype=torch.bfloat16))
+    g.tile = 0
+    with pytest.raises(AssertionError):                            # the binding refuses an accumulating call with a bf16 result
+        hl.conv_dgrad(g, gy16, w16, None, torch.zeros_like(xd, dtype=torch.bfloat16), accumulate=True)
