@@ -266,11 +266,18 @@ __global__ __launch_bounds__(NT) void bn_act_fwd_kernel(long long n4, int C, int
     const long long stride = (long long)gridDim.x * NT;
     // source may be a batch-strided view (frame t of a clip tensor): item = i / item4
     auto src_of = [&](long long i) { return item4 ? (i / item4) * item_stride + (i % item4) * 4 : i * 4; };
+    // a thread's channel group is the same on every trip when the grid stride is a multiple of C / 4 (every power-of-two
+    // channel count): the per-channel vectors are then loaded once, not once per group
+    const bool fixed_c = stride % C4 == 0;
+    f32x4 sc = {1, 1, 1, 1}, sh = {0, 0, 0, 0};
+    auto consts = [&](int c4) {
+        if (ss) { sc = *reinterpret_cast<const f32x4*>(ss + c4 * 4); sh = *reinterpret_cast<const f32x4*>(ss + C + c4 * 4); }
+    };
+    consts((int)(((long long)blockIdx.x * NT + threadIdx.x) % C4));
     auto finish = [&](long long i, f32x4 v) {
         const int c4 = (int)(i % C4);
+        if (!fixed_c) consts(c4);
         if (ss) {
-            f32x4 sc = *reinterpret_cast<const f32x4*>(ss + c4 * 4);
-            f32x4 sh = *reinterpret_cast<const f32x4*>(ss + C + c4 * 4);
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = fmaf(v[k], sc[k], sh[k]);
         }
@@ -305,17 +312,23 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_apply_kernel(long long n4, int 
     const int C4 = C >> 2;
     constexpr int out16 = io & MCG_IO_OUT_BF16;
     const long long stride = (long long)gridDim.x * NT;
+    const bool fixed_c = stride % C4 == 0;                      // (as bn_act_fwd_kernel: the seven per-channel vectors once per thread)
+    f32x4 mean = {0, 0, 0, 0}, istd = mean, sc = mean, sh = mean, k0 = mean, k1 = mean, k2 = mean;
+    auto consts = [&](int c4) {
+        if (!stats) return;
+        mean = *reinterpret_cast<const f32x4*>(stats + c4 * 4);
+        istd = *reinterpret_cast<const f32x4*>(stats + C + c4 * 4);
+        sc = *reinterpret_cast<const f32x4*>(stats + 2 * C + c4 * 4);
+        sh = *reinterpret_cast<const f32x4*>(stats + 3 * C + c4 * 4);
+        k0 = *reinterpret_cast<const f32x4*>(coef + c4 * 4);
+        k1 = *reinterpret_cast<const f32x4*>(coef + C + c4 * 4);
+        k2 = *reinterpret_cast<const f32x4*>(coef + 2 * C + c4 * 4);
+    };
+    consts((int)(((long long)blockIdx.x * NT + threadIdx.x) % C4));
     auto finish = [&](long long i, const f32x4& gv, const f32x4& yv) {
-        const int c4 = (int)(i % C4);
+        if (!fixed_c) consts((int)(i % C4));
         f32x4 o;
         if (stats) {
-            f32x4 mean = *reinterpret_cast<const f32x4*>(stats + c4 * 4);
-            f32x4 istd = *reinterpret_cast<const f32x4*>(stats + C + c4 * 4);
-            f32x4 sc = *reinterpret_cast<const f32x4*>(stats + 2 * C + c4 * 4);
-            f32x4 sh = *reinterpret_cast<const f32x4*>(stats + 3 * C + c4 * 4);
-            f32x4 k0 = *reinterpret_cast<const f32x4*>(coef + c4 * 4);
-            f32x4 k1 = *reinterpret_cast<const f32x4*>(coef + C + c4 * 4);
-            f32x4 k2 = *reinterpret_cast<const f32x4*>(coef + 2 * C + c4 * 4);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float gb = gv[k] * act_mask(fmaf(yv[k], sc[k], sh[k]), act);
