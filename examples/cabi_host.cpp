@@ -24,6 +24,10 @@ static double rel_l2(const std::vector<float>& a, const std::vector<double>& b) 
 }
 
 int main() {
+    if (mcg_version() != MCG_ABI_VERSION) {      // a library built from another revision of the header takes other argument lists
+        printf("libmocogan_hip is ABI revision %d, this host was compiled against %d\n", mcg_version(), MCG_ABI_VERSION);
+        return 4;
+    }
     srand(1);
     // geometry: x [N][Ti][Hi][Wi][Ci] -> y [N][To][Ho][Wo][Co], k = 4x4x4, stride (1,2,2), pad (0,1,1)
     const int N = 2, Ti = 6, Hi = 16, Wi = 16, Ci = 8, Co = 128, kt = 4;

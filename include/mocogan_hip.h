@@ -88,6 +88,9 @@ typedef struct mcg_conv_geom {
     int64_t x_stride0, x_stride1;
 } mcg_conv_geom;
 
+/* ABI revision of this header: a host built against another revision must not call in (argument lists differ).
+ * 3 = round 3 (mcg_randint, bf16 tensors in the synchronised-BatchNorm backward; round 2 changed mcg_bn_act_fwd / mcg_bn_act_bwd / mcg_adam_wd / mcg_conv_geom). */
+#define MCG_ABI_VERSION 3
 int mcg_version(void);
 
 /* ---- implicit-GEMM convolution on the fp32 MFMA (v_mfma_f32_32x32x2_f32) ------------------- */
@@ -145,7 +148,9 @@ typedef struct mcg_conv_epilogue {
     int32_t out_bf16;           /* the OUTPUT tensor (y of fprop, x of dgrad) is bf16 (uint16_t, round-to-nearest-even) --
                                  * what the next layer's GEMMs (with act) or the element-wise passes (without) of a bf16
                                  * network read.  With the plain store or any epilogue but MCG_SUMS_BN_BWD; never with a
-                                 * split-K tile code, an accumulating dgrad or the Ci = 4 layers (MCG_ERR_UNSUPPORTED) */
+                                 * split-K tile code, an accumulating dgrad or the Ci = 4 layers (MCG_ERR_UNSUPPORTED).  The
+                                 * sums of an epilogue are those of the STORED (rounded) values: BatchNorm then normalises the
+                                 * tensor it reads with that tensor's own mean and variance */
     /* dgrad only: v *= (mask bit ? 1 : 0.2) -- leaky_relu's backward from the bits the forward pass stored */
     const uint32_t* mask_in;
     /* out (host side, valid after the call): */
@@ -221,11 +226,13 @@ int mcg_bn_sums(int64_t M, int C, const float* y, double* sums, void* workspace,
 int mcg_bn_stats_from_sums(int64_t M_total, int C, const double* sums, const float* gamma,
                            const float* beta, float* stats, float* avg_mean, float* avg_var, float eps,
                            float decay, void* stream);
-int mcg_bn_bwd_sums(int64_t M, int C, const float* g_out, const float* y, const float* stats, int act,
+/* (io_bf16 / gx_bf16: MCG_IO_* flags as in mcg_bn_act_bwd -- bf16 networks keep gx, and where the schedule allows y and
+ * g_out, in bf16) */
+int mcg_bn_bwd_sums(int64_t M, int C, const float* g_out, const float* y, const float* stats, int act, int io_bf16,
                     double* sums, void* workspace, void* stream);
 int mcg_bn_act_bwd_from_sums(int64_t M, int64_t M_total, int C, const float* g_out, const float* y,
                              const float* stats, const float* gamma, int act, const double* local_sums,
-                             const double* global_sums, float* gx, float* dgamma, float* dbeta,
+                             const double* global_sums, void* gx, int gx_bf16, float* dgamma, float* dbeta,
                              void* workspace, void* stream);
 
 /* The second halves of the three passes above, starting from per-tile partial sums written by a fused conv
@@ -299,6 +306,9 @@ int mcg_randn(int64_t n, float sigma, uint64_t seed, uint64_t stream_id, float* 
 /* out[M][C] = sigma * N(0,1) in the element order of the fused first-layer epilogue (mcg_conv_epilogue.sigma):
  * element (m, c) is normal m & 3 of Philox counter (m >> 2) * C + c.  M % 4 == 0. */
 int mcg_randn_rowquad(int64_t M, int C, float sigma, uint64_t seed, uint64_t stream_id, float* out, void* stream);
+/* out[i] = word (i & 3) of Philox counter (i >> 2) of the stream, modulo `modulus`: the generator's label draw
+ * xp.random.randint(dim_zl, size=batchsize) (model/net.py:91-92) from the same keyed generator as the normals. */
+int mcg_randint(int64_t n, int modulus, uint64_t seed, uint64_t stream_id, int32_t* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -12,9 +12,23 @@ def lib_path():
     return os.environ.get("MCG_LIB_PATH") or os.path.join(HERE, "lib", "libmocogan_hip.so")
 
 
+def _flags():
+    return os.environ.get("MCG_HIPCC_FLAGS", "").split()        # e.g. -DMCG_STAMPS for the diagnostic builds of tools/
+
+
+def _stamp_path():
+    return lib_path() + ".flags"
+
+
 def _stale():
     out = lib_path()
     if not os.path.exists(out):
+        return True
+    # a library built with other compile flags (a diagnostic build such as -DMCG_STAMPS, or the reverse) is not this build
+    try:
+        if open(_stamp_path()).read() != " ".join(_flags()):
+            return True
+    except OSError:
         return True
     t = os.path.getmtime(out)
     deps = [os.path.join(HERE, s) for s in SOURCES] + [os.path.join(HERE, "csrc", "mcg_common.h"),
@@ -29,7 +43,7 @@ def build(force=False, verbose=False):
         return lib_path()
     os.makedirs(os.path.join(HERE, "lib"), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    extra = os.environ.get("MCG_HIPCC_FLAGS", "").split()        # e.g. -DMCG_STAMPS for the diagnostic builds of tools/
+    extra = _flags()
     objdir = os.path.join(HERE, "lib", "obj")
     os.makedirs(objdir, exist_ok=True)
     common = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I" + os.path.join(ROOT, "include")] + extra
@@ -48,6 +62,8 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(link))
     subprocess.run(link, check=True)
+    with open(_stamp_path(), "w") as f:
+        f.write(" ".join(extra))
     return lib_path()
 
 

@@ -640,7 +640,8 @@ __device__ __forceinline__ void fused_epilogue(const P& p, f32x16 (&acc)[TM][TN]
                         else out[o] = v;
                     }
                     if (mode & EPI_SUMS) {
-                        float t0 = v, t1 = v * v;
+                        const float vs = e.out16 ? (float)(__bf16)v : v;          // the sums are those of the value as STORED
+                        float t0 = vs, t1 = vs * vs;
                         if (mode & EPI_BNBWD) {
                             const float yv = ok ? e.bn_y[o] : 0.f;
                             const float gb = v * epi_act_mask(fmaf(yv, ri.grp ? sc[1] : sc[0], ri.grp ? sh[1] : sh[0]), e.bn_act);

@@ -822,6 +822,17 @@ __global__ __launch_bounds__(NT) void randn_rowquad_kernel(long long quads, int 
     }
 }
 
+// element i = word (i & 3) of Philox counter (i >> 2), modulo `modulus` (labels of the generator's draw)
+__global__ __launch_bounds__(NT) void randint_kernel(long long n, uint32_t modulus, uint64_t seed, uint64_t stream_id, int32_t* __restrict__ out) {
+    const long long n4 = (n + 3) / 4;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long long)gridDim.x * NT) {
+        uint32_t r[4];
+        mcg::philox4x32_10((uint32_t)i, (uint32_t)((uint64_t)i >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), r);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (i * 4 + k < n) out[i * 4 + k] = (int32_t)(r[k] % modulus);
+    }
+}
+
 bool bad_c(int C) { return C <= 0 || (C & 3); }
 
 // many conv-epilogue slots -> at most MAX_PART folded partials in `ws` (col_partial_kernel's own layout); returns the
@@ -842,7 +853,7 @@ bool unsupported_c(int C) { return (C >> 2) > NT || (NT % (C >> 2)) != 0; }
 
 }  // namespace
 
-extern "C" int mcg_version(void) { return 1; }
+extern "C" int mcg_version(void) { return MCG_ABI_VERSION; }
 
 extern "C" int64_t mcg_bn_workspace_bytes(int64_t /*M*/, int C) {
     return (int64_t)(MAX_PART * 2 * C + 3 * C) * (int64_t)sizeof(float);
@@ -973,28 +984,31 @@ extern "C" int mcg_bn_stats_from_sums(int64_t M_total, int C, const double* sums
     return launch_status();
 }
 
-extern "C" int mcg_bn_bwd_sums(int64_t M, int C, const float* g_out, const float* y, const float* stats, int act, double* sums,
+extern "C" int mcg_bn_bwd_sums(int64_t M, int C, const float* g_out, const float* y, const float* stats, int act, int io_bf16, double* sums,
                                void* workspace, void* stream) {
     if (!g_out || !y || !stats || !sums || !workspace || M <= 0 || bad_c(C)) return MCG_ERR_BAD_ARG;
+    if (io_bf16 & ~(MCG_IO_Y_BF16 | MCG_IO_G_BF16)) return MCG_ERR_BAD_ARG;
     if (unsupported_c(C)) return MCG_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     PartPlan pl = plan_partial(M, C);
     float* part = (float*)workspace;
-    hipLaunchKernelGGL(col_partial_kernel<1>, dim3(pl.blocks), dim3(NT), 0, s, (long long)M, C, pl.rows_per_block, g_out, y, stats, act, part);
+    launch_bwd_partial(io_bf16, pl.blocks, s, (long long)M, C, pl.rows_per_block, g_out, y, stats, act, part);
     hipLaunchKernelGGL(sums_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_SL), 0, s, pl.blocks, C, part, sums);
     return launch_status();
 }
 
 extern "C" int mcg_bn_act_bwd_from_sums(int64_t M, int64_t M_total, int C, const float* g_out, const float* y, const float* stats,
-                                        const float* gamma, int act, const double* local_sums, const double* global_sums, float* gx,
-                                        float* dgamma, float* dbeta, void* workspace, void* stream) {
+                                        const float* gamma, int act, const double* local_sums, const double* global_sums, void* gx,
+                                        int gx_bf16, float* dgamma, float* dbeta, void* workspace, void* stream) {
     if (!g_out || !y || !gx || !stats || !gamma || !local_sums || !global_sums || !workspace || M <= 0 || M_total < M || bad_c(C)) return MCG_ERR_BAD_ARG;
+    if (gx_bf16 & ~7) return MCG_ERR_BAD_ARG;
+    if (gx == (const void*)g_out && !(gx_bf16 & MCG_IO_OUT_BF16) != !(gx_bf16 & MCG_IO_G_BF16)) return MCG_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     float* coef = (float*)workspace + (long long)MAX_PART * 2 * C;
     hipLaunchKernelGGL(bn_bwd_from_sums_kernel, dim3((C + 63) / 64), dim3(64), 0, s, C, 1.0 / (double)M_total, local_sums, global_sums, stats, gamma,
                        coef, dgamma, dbeta);
     long long n4 = (long long)M * (C >> 2);
-    launch_bwd_apply(0, s, n4, C, g_out, y, stats, coef, act, gx);
+    launch_bwd_apply(gx_bf16, s, n4, C, g_out, y, stats, coef, act, (float*)gx);
     return launch_status();
 }
 
@@ -1122,6 +1136,12 @@ extern "C" int mcg_adam_wd(int64_t n, float* p, const float* g, float* m, float*
 extern "C" int mcg_randn_rowquad(int64_t M, int C, float sigma, uint64_t seed, uint64_t stream_id, float* out, void* stream) {
     if (!out || M <= 0 || (M & 3) || C <= 0) return MCG_ERR_BAD_ARG;
     hipLaunchKernelGGL(randn_rowquad_kernel, dim3(ew_grid((M / 4) * C)), dim3(NT), 0, (hipStream_t)stream, (long long)(M / 4), C, sigma, seed, stream_id, out);
+    return launch_status();
+}
+
+extern "C" int mcg_randint(int64_t n, int modulus, uint64_t seed, uint64_t stream_id, int32_t* out, void* stream) {
+    if (!out || n <= 0 || modulus <= 0) return MCG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(randint_kernel, dim3(ew_grid((n + 3) / 4)), dim3(NT), 0, (hipStream_t)stream, (long long)n, (uint32_t)modulus, seed, stream_id, out);
     return launch_status();
 }
 

@@ -70,8 +70,8 @@ SIGNATURES = {
     "mcg_bn_act_bwd": (_I, [_I64, _I, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P]),
     "mcg_bn_sums": (_I, [_I64, _I, _P, _P, _P, _P]),
     "mcg_bn_stats_from_sums": (_I, [_I64, _I, _P, _P, _P, _P, _P, _P, _F, _F, _P]),
-    "mcg_bn_bwd_sums": (_I, [_I64, _I, _P, _P, _P, _I, _P, _P, _P]),
-    "mcg_bn_act_bwd_from_sums": (_I, [_I64, _I64, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "mcg_bn_bwd_sums": (_I, [_I64, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "mcg_bn_act_bwd_from_sums": (_I, [_I64, _I64, _I, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P]),
     "mcg_colsum_acc": (_I, [_I64, _I, _P, _P, _P, _P]),
     "mcg_pack_clip": (_I, [_I, _I, _I, _I, _I, _P, _I64, _I64, _P, _F, _U64, _U64, _P, _P]),
     "mcg_unpack_clip": (_I, [_I, _I, _I, _I, _I, _P, _P, _P]),
@@ -82,7 +82,10 @@ SIGNATURES = {
     "mcg_loss_gen": (_I, [_I, _I, _P, _P, _P, _I, _P, _P, _P, _P]),
     "mcg_adam_wd": (_I, [_I64, _P, _P, _P, _P, _D, _D, _D, _D, _D, _D, _P, _P]),
     "mcg_randn": (_I, [_I64, _F, _U64, _U64, _P, _P]),
+    "mcg_randint": (_I, [_I64, _I, _U64, _U64, _P, _P]),
 }
+
+ABI_VERSION = 3          # MCG_ABI_VERSION of include/mocogan_hip.h these prototypes were written against
 
 _lib = None
 
@@ -101,6 +104,9 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    if lib.mcg_version() != ABI_VERSION:
+        raise McgError("%s is ABI revision %d, this binding expects %d: rebuild it (__graft_entry__.build())"
+                       % (path, lib.mcg_version(), ABI_VERSION))
     _lib = lib
     return lib
 
@@ -520,21 +526,21 @@ def bn_act_fwd(M, Cn, y, scale_shift, act, out, addend=None, sigma=0.0, seed=0, 
 
 
 def bn_act_bwd(M, Cn, g_out, y, stats, gamma, act, gx, dgamma, dbeta, ws, sync=None):
+    gp, g16 = _pany(_dense(gx))
+    ip, i16 = _pany(_dense(g_out))
+    yp, y16 = _pany(_dense(y))
     if sync is None or sync.world == 1 or stats is None:
-        gp, g16 = _pany(_dense(gx))
-        ip, i16 = _pany(_dense(g_out))
-        yp, y16 = _pany(_dense(y))
         _check(load().mcg_bn_act_bwd(M, Cn, ip, yp, _p(stats), _p(gamma), act, gp, IO_OUT_BF16 * g16 + IO_Y_BF16 * y16 + IO_G_BF16 * i16,
                                      _p(dgamma), _p(dbeta), _p(ws), _stream()), "mcg_bn_act_bwd")
         return
     local = torch.empty(2 * Cn, dtype=torch.float64, device=y.device)
-    _check(load().mcg_bn_bwd_sums(M, Cn, _p(_dense(g_out)), _p(_dense(y)), _p(stats), act, _p(local, torch.float64), _p(ws), _stream()),
-           "mcg_bn_bwd_sums")
+    _check(load().mcg_bn_bwd_sums(M, Cn, ip, yp, _p(stats), act, IO_Y_BF16 * y16 + IO_G_BF16 * i16, _p(local, torch.float64), _p(ws),
+                                  _stream()), "mcg_bn_bwd_sums")
     glob = local.clone()
     sync.all_reduce_sum(glob)
-    _check(load().mcg_bn_act_bwd_from_sums(M, M * sync.world, Cn, _p(g_out), _p(y), _p(stats), _p(gamma), act, _p(local, torch.float64),
-                                           _p(glob, torch.float64), _p(_dense(gx)), _p(dgamma), _p(dbeta), _p(ws), _stream()),
-           "mcg_bn_act_bwd_from_sums")
+    _check(load().mcg_bn_act_bwd_from_sums(M, M * sync.world, Cn, ip, yp, _p(stats), _p(gamma), act, _p(local, torch.float64),
+                                           _p(glob, torch.float64), gp, IO_OUT_BF16 * g16 + IO_Y_BF16 * y16 + IO_G_BF16 * i16,
+                                           _p(dgamma), _p(dbeta), _p(ws), _stream()), "mcg_bn_act_bwd_from_sums")
 
 
 def bn_stats_from_partials(M, Cn, part, n_slots, slot_stride, gamma, beta, stats, avg_mean, avg_var, ws, eps=2e-5, decay=0.9):
@@ -606,6 +612,11 @@ def adam_wd(p, g, m, v, lr_t, beta1, beta2, eps, wd, grad_scale=1.0, p16=None):
     """p16: optional bf16 buffer of p's size that receives a copy of the updated parameters"""
     _check(load().mcg_adam_wd(p.numel(), _p(_dense(p)), _p(_dense(g)), _p(_dense(m)), _p(_dense(v)), lr_t, beta1, beta2, eps, wd,
                               grad_scale, _p(_dense(p16), torch.bfloat16), _stream()), "mcg_adam_wd")
+
+
+def randint(out, modulus, seed, stream_id):
+    """out (int32)[i] = Philox word i of the stream, modulo `modulus` (oracle.philox.randint states the same draw)"""
+    _check(load().mcg_randint(out.numel(), int(modulus), seed, stream_id, _p(_dense(out), torch.int32), _stream()), "mcg_randint")
 
 
 def randn(out, sigma, seed, stream_id):

@@ -635,14 +635,14 @@ class GenNet(_Net):
 
     # ---- latent draws (model/net.py:55-56,66,71,92,102) ------------------------------------------
     def draw(self, n, rng):
-        """Perf-mode latent draw on the device: rng = (seed, base_stream_id)."""
+        """Perf-mode latent draw on the device: rng = (seed, base_stream_id).  Philox streams base .. base + 3 hold h0, e, zc
+        and the labels (oracle.philox states the same draws)."""
         dev = self.device
         T, dz = self.video_len, self.dim_zm
         d = {'labels': None}
         if self.dim_zl:
-            gen = torch.Generator(device=dev)
-            gen.manual_seed((rng[0] * 1000003 + rng[1]) % (2 ** 63))
-            d['labels'] = torch.randint(0, self.dim_zl, (n,), device=dev, dtype=torch.int32, generator=gen)
+            d['labels'] = torch.empty(n, device=dev, dtype=torch.int32)
+            hl.randint(d['labels'], self.dim_zl, rng[0], rng[1] + 3)
         d['h0'] = torch.empty((n, dz), device=dev)
         d['e'] = torch.empty((T, n, dz), device=dev)
         d['zc'] = torch.empty((n, self.dim_zc), device=dev)

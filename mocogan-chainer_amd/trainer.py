@@ -147,6 +147,11 @@ class PrefetchIterator(SerialIterator):
         super().load_state(epoch, current_position, order, is_new_epoch, previous_epoch_detail)
         self._head = self._state()
 
+    def consumed_batches(self):
+        """number of batches handed out so far (the look-ahead's are not counted): what a snapshot stores, so that a
+        resumed run seeds the workers' per-batch draws (sub-sequence offsets) where this one stopped"""
+        return self._batch_no - len(self._queue)
+
     # -- bookkeeping: SerialIterator.next() minus the loading ------------------------------------------
     def _state(self):
         return (self.current_position, self.epoch, self.is_new_epoch, self._previous_epoch_detail, self._order)
@@ -304,6 +309,8 @@ class Trainer:
              'updater/iterator:main/previous_epoch_detail': np.asarray(float(getattr(it, '_previous_epoch_detail', -1.0)))}
         if getattr(it, '_order', None) is not None:                 # Chainer's SerialIterator serializes its permutation too
             d['updater/iterator:main/order'] = np.asarray(it._order)
+        if hasattr(it, '_batch_no'):                                # PrefetchIterator: seeds the workers' sub-sequence offsets per batch
+            d['updater/iterator:main/batch_no'] = np.asarray(it.consumed_batches())
         for name, link in u.links().items():
             for k, v in link.impl.export_reference_params().items():
                 d['updater/model:%s/%s' % (name, k)] = v
@@ -323,8 +330,16 @@ class Trainer:
             u._step.iteration = u.iteration
         it = u.get_iterator('main')
         opt = lambda k: d['updater/iterator:main/' + k] if 'updater/iterator:main/' + k in d else None
-        args = (int(d['updater/iterator:main/epoch']), int(d['updater/iterator:main/current_position']), opt('order'),
+        # Data parallel: only rank 0 writes snapshots, so the stored permutation is rank 0's.  Every rank keeps ITS OWN
+        # permutation (seeded per rank in train.py) and restores position and epoch only -- restoring rank 0's order on
+        # every rank would make all ranks read identical clips for the rest of the resumed epoch.
+        import torch.distributed as dist
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        order = opt('order') if world == 1 else None
+        args = (int(d['updater/iterator:main/epoch']), int(d['updater/iterator:main/current_position']), order,
                 opt('is_new_epoch'), opt('previous_epoch_detail'))
+        if hasattr(it, '_batch_no') and opt('batch_no') is not None:
+            it._batch_no = int(opt('batch_no'))                     # before load_state: the look-ahead restarts from this number
         if hasattr(it, 'load_state'):
             it.load_state(*args)
         else:

@@ -48,6 +48,18 @@ def randn(n, sigma, seed, stream_id):
     return sigma * out[:n]
 
 
+def randint(n, modulus, seed, stream_id):
+    """The first n integers of the stream (mcg_randint): element i = word i & 3 of counter i >> 2, modulo `modulus` -- the
+    device's stand-in for the generator's label draw xp.random.randint(dim_zl, size=batchsize) (model/net.py:91-92)."""
+    n4 = (n + 3) // 4
+    idx = np.arange(n4, dtype=np.uint64)
+    z = np.zeros(n4, np.uint32)
+    r = philox4x32_10((idx & np.uint64(0xFFFFFFFF)).astype(np.uint32), (idx >> np.uint64(32)).astype(np.uint32),
+                      z + np.uint32(stream_id & 0xFFFFFFFF), z + np.uint32(stream_id >> 32),
+                      seed & 0xFFFFFFFF, seed >> 32)
+    return (np.stack(r, axis=1).reshape(-1)[:n] % np.uint32(modulus)).astype(np.int64)
+
+
 def randn_rowquad(M, C, sigma, seed, stream_id):
     """[M][C] noise in the element order of the fused first-layer epilogue (mcg_conv_epilogue.sigma,
     mcg_randn_rowquad): element (m, c) is normal m & 3 of counter (m >> 2) * C + c -- the same generator, one

@@ -36,7 +36,8 @@ def test_library_exports_every_declared_symbol(hl):
         assert hasattr(lib, n), "libmocogan_hip.so does not export %s" % n
         assert n in hl.SIGNATURES, "hiplib.SIGNATURES has no ctypes prototype for %s" % n
     assert set(hl.SIGNATURES) == set(names)
-    assert lib.mcg_version() >= 1
+    assert lib.mcg_version() == hl.ABI_VERSION
+    assert 'define MCG_ABI_VERSION %d' % hl.ABI_VERSION in open(os.path.join(ROOT, 'include', 'mocogan_hip.h')).read()
 
 
 def test_header_cites_reference_call_sites():

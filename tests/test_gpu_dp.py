@@ -14,14 +14,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NF, N, MODEL, DIM_ZL = 4, 2, 'infogan', 6
 
 
-def _worker(rank, world, port, q, sync_bn=False):
+def _worker(rank, world, port, q, sync_bn=False, precision='f32', nf=NF, backend='gloo'):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     import traceback
     import torch.distributed as dist
-    torch.cuda.set_device(0)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(rank if backend == 'nccl' else 0)       # nccl (= RCCL): one GPU per rank; gloo: both ranks on cuda:0
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         import dp_common
         from oracle import updater as oupd
@@ -30,11 +31,13 @@ def _worker(rank, world, port, q, sync_bn=False):
         import mocogan_chainer_amd.nets as nets
         import mocogan_chainer_amd.step as step
         hl.load()
-        (gen, di, dv), shards = dp_common.setup(nf=NF, n=N, seed=11, model=MODEL, dim_zl=DIM_ZL, world=world)
-        G = nets.GenNet(dim_zl=DIM_ZL, n_filters=NF)
-        DI = nets.DisNet(2, 3, 7, NF, use_noise=True)
-        DV = nets.DisNet(3, 3, 7, NF, use_noise=True)
-        ts = step.TrainStep(MODEL, G, DI, DV, exchange=step.GradExchange(), rank=rank, overlap=True, sync_bn=sync_bn)
+        (gen, di, dv), shards = dp_common.setup(nf=nf, n=N, seed=11, model=MODEL, dim_zl=DIM_ZL, world=world)
+        G = nets.GenNet(dim_zl=DIM_ZL, n_filters=nf)
+        DI = nets.DisNet(2, 3, 7, nf, use_noise=True)
+        DV = nets.DisNet(3, 3, 7, nf, use_noise=True)
+        ts = step.TrainStep(MODEL, G, DI, DV, exchange=step.GradExchange(), rank=rank, overlap=True, sync_bn=sync_bn,
+                            precision=precision)
+        assert dist.get_backend() == backend
         for net, p in ((G, gen), (DI, di), (DV, dv)):
             net.load_reference_params(p)
             net.load_adam_state(oupd.new_adam_state(p))
@@ -55,14 +58,14 @@ def _worker(rank, world, port, q, sync_bn=False):
         dist.destroy_process_group()
 
 
-def _run_ranks(sync_bn, port_base):
+def _run_ranks(sync_bn, port_base, precision='f32', nf=NF, backend='gloo'):
     import queue
     import time
     import torch.multiprocessing as mp
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = port_base + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, sync_bn)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, sync_bn, precision, nf, backend)) for r in range(2)]
     [p.start() for p in procs]
     res, t0 = [], time.time()
     while len(res) < 2:
@@ -159,3 +162,45 @@ def test_two_rank_hip_step_matches_the_sharded_oracle():
         oupd.update_core = orig
     worst = _update_errors(res, nets, ref)
     print('worst relative update error', worst)
+
+
+
+def test_two_rank_bf16_networks_with_synchronised_batchnorm():
+    """bf16 networks keep the gradient BatchNorm's backward writes in bf16; with sync_bn the backward pass goes through
+    mcg_bn_bwd_sums / mcg_bn_act_bwd_from_sums, which take the same MCG_IO_* flags as mcg_bn_act_bwd (round 2 raised
+    'expected float32, got bfloat16' here).  n_filters = 8 puts layers 2..4 of D and 3..5 of G on bf16-stored operands.
+    The replicas must stay bit-identical and the losses must agree with the fp32 run of the same shards to the bf16
+    tolerance (loss abs <= 5e-2)."""
+    res16 = _run_ranks(True, 33600, precision='bf16', nf=8)
+    res32 = _run_ranks(True, 35600, precision='f32', nf=8)
+    for name in ('gen', 'di', 'dv'):
+        for k, v in res16[0][1][name].items():
+            if not k.endswith('/N'):
+                assert np.array_equal(v, res16[1][1][name][k]), (name, k)
+    for r in range(2):
+        for k in res16[r][2]:
+            assert abs(res16[r][2][k] - res32[r][2][k]) < 5e-2, (r, k, res16[r][2][k], res32[r][2][k])
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs two GPUs (the driver's multi-GPU node)")
+def test_two_rank_rccl_matches_the_sharded_oracle():
+    """The same parity over the nccl backend (= RCCL over xGMI), one GPU per rank: covers what gloo cannot -- the
+    late-bucket all_reduce issued from the weight-gradient stream and work.wait()'s stream semantics."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import dp_common
+    from oracle import updater as oupd
+    res = _run_ranks(False, 37600, backend='nccl')
+    for name in ('gen', 'di', 'dv'):
+        for k, v in res[0][1][name].items():
+            if 'avg_' in k or k.endswith('/N'):
+                continue
+            assert np.array_equal(v, res[1][1][name][k]), (name, k)
+    nets, shards = dp_common.setup(nf=NF, n=N, seed=11, model=MODEL, dim_zl=DIM_ZL, world=2)
+    orig = oupd.update_core
+    oupd.update_core = lambda model, gen, di, dv, og, oi, ov, x, t_real, rnd, **kw: orig(
+        model, gen, di, dv, og, oi, ov, x, np.zeros(N, dtype=np.int64), rnd, **kw)
+    try:
+        ref = dp_common.emulate(nets, shards, model=MODEL, dim_zl=DIM_ZL)
+    finally:
+        oupd.update_core = orig
+    print('RCCL: worst relative update error', _update_errors(res, nets, ref))

@@ -76,7 +76,7 @@ FULL_WIDTH_LAYERS = [
 def test_true_width_layers_with_shipped_tiles_match_the_oracle(pkg, layer):
     hl, lay, _, _ = pkg
     name, N, Ti, H, Ci, Co, kt = layer
-    rng = np.random.RandomState(abs(hash(name)) % 2 ** 31)
+    rng = np.random.RandomState(8100 + [l[0] for l in FULL_WIDTH_LAYERS].index(name))      # fixed table: a failure can be replayed
     x = rng.uniform(-1, 1, (N, Ci, Ti, H, H))
     W = rng.randn(Co, Ci, kt, 4, 4) * np.sqrt(2.0 / ((Ci + Co) * 16 * kt))          # GlorotNormal scale (model/net.py:131,172)
     b = rng.randn(Co) * 0.1

@@ -151,7 +151,56 @@ def test_generator_forward_backward(pkg, dim_zl, nf):
 TIGHT_MARGIN = 2e-6     # see oracle.updater.update_core: min |pre-activation| over every ReLU / LeakyReLU decision
 
 
-def _run_steps(pkg, model, dim_zl, nf, n, steps, seed, min_tight_steps=1, overlap=False):
+# ---- perf mode: the randomness of the BENCHMARKED schedule, restated from its specification -----------------------
+# TrainStep.run(inject=None) draws every random tensor in-kernel from Philox4x32-10 keyed by (seed, stream id).  The id
+# arithmetic below is written out independently of step.py / nets.py (DESIGN.md section 1 is the specification):
+#   base(it, rank) = (it * 64 + rank + 1) * 64
+#   call k of the iteration owns ids base + 8 k ..: k = 0 D_I(real), 1 D_V(real), 2 the generator's latent draw,
+#   3 D_I(fake), 4 D_V(fake); a discriminator call uses id + l - 1 for the add_noise in front of layer l = 1..4
+#   (model/net.py:148-154,189-195), the latent draw id + 0 / 1 / 2 / 3 for h0 / e / zc / labels (model/net.py:66,71,102,92).
+# Element order: flat device layout [n][T][H][W][C] in groups of four channels per Philox counter, except the tensor
+# behind D's first layer, which the fused epilogue draws one counter per (row quad, channel) (oracle.philox.randn_rowquad).
+def perf_mode_randomness(seed, it, rank, model, n, nf, dim_zl, c_img=3, T=16, dim_zc=50, dim_zm=10, sigma=0.2):
+    from oracle import philox
+    base = (it * 64 + rank + 1) * 64
+    cd = c_img + (dim_zl if model == 'cgan' else 0)
+    cp = (cd + 3) // 4 * 4
+
+    def to_ref(z, ndim):                                  # [n][T][H][W][C] -> (n,C,T,H,W) / (n,C,H,W)
+        z = z.transpose(0, 4, 1, 2, 3)
+        return np.ascontiguousarray(z[:, :, 0] if ndim == 2 else z)
+
+    def dis_noise(ndim, k):
+        sid = base + 8 * k
+        t = T if ndim == 3 else 1
+        out = [to_ref(philox.randn(n * t * 64 * 64 * cp, sigma, seed, sid).reshape(n, t, 64, 64, cp)[..., :cd], ndim)]
+        t = t - 3 if ndim == 3 else 1
+        out.append(to_ref(philox.randn_rowquad(n * t * 32 * 32, nf, sigma, seed, sid + 1).reshape(n, t, 32, 32, nf), ndim))
+        for l, (h, c) in ((3, (16, 2 * nf)), (4, (8, 4 * nf))):
+            t = t - 3 if ndim == 3 else 1
+            out.append(to_ref(philox.randn(n * t * h * h * c, sigma, seed, sid + l - 1).reshape(n, t, h, h, c), ndim))
+        return out
+
+    g = torch.Generator()
+    g.manual_seed(seed * 7919 + it)                       # the frame index: one host draw per iteration, shared by all ranks (Q7)
+    rnd = {'t': int(torch.randint(0, T, (1,), generator=g))}
+    rnd['noise_i_real'], rnd['noise_v_real'] = dis_noise(2, 0), dis_noise(3, 1)
+    sid = base + 16
+    rnd['gen'] = {'h0': philox.randn(n * dim_zm, 0.33, seed, sid).reshape(n, dim_zm),
+                  'e': philox.randn(T * n * dim_zm, 0.33, seed, sid + 1).reshape(T, n, dim_zm),
+                  'zc': philox.randn(n * dim_zc, 0.33, seed, sid + 2).reshape(n, dim_zc),
+                  'labels': philox.randint(n, dim_zl, seed, sid + 3) if dim_zl else None}
+    rnd['noise_i_fake'], rnd['noise_v_fake'] = dis_noise(2, 3), dis_noise(3, 4)
+    return rnd
+
+
+def perf_mode_stream_ids(it, rank):
+    """every Philox stream id iteration `it` of rank `rank` consumes (the specification above)"""
+    base = (it * 64 + rank + 1) * 64
+    return [base + 8 * k + j for k in (0, 1, 3, 4) for j in range(4)] + [base + 16 + j for j in range(4)]
+
+
+def _run_steps(pkg, model, dim_zl, nf, n, steps, seed, min_tight_steps=1, overlap=False, perf=None):
     """Teacher-forced multi-step parity: before every iteration the device state (parameters, Adam
     moments and step counters, BN running statistics) is loaded from the oracle, so each iteration
     is compared on identical inputs and errors cannot compound through Adam's sign-like early steps.
@@ -173,7 +222,7 @@ def _run_steps(pkg, model, dim_zl, nf, n, steps, seed, min_tight_steps=1, overla
     G = nets.GenNet(dim_zl=dim_zl, n_filters=nf)
     DI = nets.DisNet(2, c_d, out_c, nf, use_noise=True)
     DV = nets.DisNet(3, c_d, out_c, nf, use_noise=True)
-    ts = step.TrainStep(model, G, DI, DV, overlap=overlap)
+    ts = step.TrainStep(model, G, DI, DV, overlap=overlap, **({'seed': perf[0], 'rank': perf[1]} if perf else {}))
     og, oi, ov = (oupd.new_adam_state(q) for q in (gen, di, dv))
     tight_steps = 0
     for s in range(steps):
@@ -182,13 +231,24 @@ def _run_steps(pkg, model, dim_zl, nf, n, steps, seed, min_tight_steps=1, overla
             net.load_adam_state(st)
         x_real = rng.uniform(-1, 1, (n, 3, 16, 64, 64))
         t_real = rng.randint(0, 6, n)
-        rnd = oupd.draw_step_randomness(rng, model, n, 3, nf, dim_zl=dim_zl, dtype=F64)
+        if perf:
+            # perf mode (what bench.py and Updater.update_core run): nothing is injected; the oracle is fed the draws
+            # oracle.philox states for the ids of this (seed, iteration, rank)
+            assert ts.iteration == s
+            rnd = perf_mode_randomness(perf[0], s, perf[1], model, n, nf, dim_zl)
+            inject = None
+        else:
+            rnd = oupd.draw_step_randomness(rng, model, n, 3, nf, dim_zl=dim_zl, dtype=F64)
+            inject = {'t': rnd['t'], 'gen': draw_to_dev(rnd['gen'])}
+            for k in ('noise_i_real', 'noise_v_real', 'noise_i_fake', 'noise_v_fake'):
+                inject[k] = noise_to_dev(lay, rnd[k])
         ref = oupd.update_core(model, gen, di, dv, og, oi, ov, x_real, t_real, rnd, dim_zl=dim_zl, keep=True)
-        inject = {'t': rnd['t'], 'gen': draw_to_dev(rnd['gen'])}
-        for k in ('noise_i_real', 'noise_v_real', 'noise_i_fake', 'noise_v_fake'):
-            inject[k] = noise_to_dev(lay, rnd[k])
         out = ts.run(dev(x_real), dev(t_real, torch.int32), inject)
         losses = ts.losses()
+        if perf:
+            assert out['t'] == rnd['t']
+            if dim_zl:
+                assert np.array_equal(out['t_fake'].cpu().numpy(), rnd['gen']['labels'])
         # ---- forward: always tight
         assert abs(losses['image_dis/loss'] - ref['loss_dis_i']) < 1e-5, s
         assert abs(losses['video_dis/loss'] - ref['loss_dis_v']) < 1e-5, s
@@ -224,6 +284,29 @@ def test_update_core_with_side_streams(pkg):
     the same teacher-forced parity must hold."""
     _run_steps(pkg, "infogan", 6, nf=4, n=2, steps=3, seed=313, overlap=True)
     _run_steps(pkg, "normal", 6, nf=16, n=3, steps=2, seed=77, min_tight_steps=0, overlap=True)
+
+
+PERF_CASES = [("normal", 0, 1303), ("normal", 6, 1311), ("infogan", 6, 1313), ("cgan", 6, 1320)]
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+@pytest.mark.parametrize("model,dim_zl,seed", PERF_CASES)
+def test_update_core_perf_mode_matches_oracle_philox(pkg, model, dim_zl, seed, overlap):
+    """The schedule bench.py times and Updater.update_core runs (inject=None: in-kernel Philox for the eight noise
+    tensors, GenNet.draw, the seeded frame index) against the oracle fed with oracle.philox draws of the same
+    (seed, stream id)s -- three iterations, every model variant, with and without side streams, on rank 0 and on a
+    non-zero rank.  Same tolerances as the injected-randomness test (model/updater.py:78-113, model/net.py:10-15,
+    55-56,90-93)."""
+    _run_steps(pkg, model, dim_zl, nf=4, n=2, steps=3, seed=seed, overlap=overlap, perf=(77 + dim_zl, 0 if overlap else 3))
+
+
+def test_perf_mode_parity_notices_a_wrong_stream_id(pkg, monkeypatch):
+    """the check above has teeth: shift the ids the DEVICE uses by one and it must fail"""
+    _, _, _, step = pkg
+    orig = step.TrainStep.stream_base.__func__
+    monkeypatch.setattr(step.TrainStep, 'stream_base', classmethod(lambda cls, it, rank: orig(cls, it, rank) + 1))
+    with pytest.raises(AssertionError):
+        _run_steps(pkg, "normal", 6, nf=4, n=2, steps=1, seed=1311, perf=(83, 0), min_tight_steps=0)
 
 
 def test_update_core_full_width_one_step(pkg):

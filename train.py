@@ -160,9 +160,21 @@ def main(argv=None):
         # Epoch semantics: every rank walks the WHOLE dataset in its own order with its own batchsize, i.e. one
         # "epoch" is world-size passes over the data and --max_epoch counts those; BatchNorm running statistics
         # are per rank and rank 0's are the ones saved.
+        import torch
         for link in (image_gen, image_dis, video_dis):
             net = link.impl
             exchange.broadcast_params([net.fp.p, net.fp.m, net.fp.v] + list(net.running.values()))
+            # the Adam step counter (it sets lr_t) and the BatchNorm call counts travel too; the bf16 copy of the
+            # weights is rebuilt from what arrived
+            names = sorted(net.bn_count)
+            cnt = torch.tensor([net.t] + [net.bn_count[k] for k in names], dtype=torch.int64, device=net.fp.p.device)
+            exchange.broadcast_params([cnt])
+            cnt = cnt.tolist()
+            net.t = int(cnt[0])
+            for k, v in zip(names, cnt[1:]):
+                net.bn_count[k] = int(v)
+            if net.precision == 'bf16':
+                net.fp.refresh16()
 
     if rank == 0:
         # the reference's start-up banner (train.py:165-187), same lines and order
