@@ -49,16 +49,18 @@ def dv_conv_flops_per_step(batch):
     return batch * (fwd + wgrad + dgrad), batch * fwd, batch * wgrad, batch * dgrad
 
 
-def dv_conv_algorithmic_bytes_per_step(batch):
-    """Bytes the D_V conv family has to move if every tensor crossed HBM exactly once per launch (fp32):
-    fprop reads x_l and writes y_l; wgrad reads x_l and g_l and writes dW; dgrad reads g_l and writes gx_l."""
+def dv_conv_algorithmic_bytes_per_step(batch, dtype='f32'):
+    """Bytes the D_V conv family has to move if every tensor crossed HBM exactly once per launch:
+    fprop reads x_l and writes y_l; wgrad reads x_l and g_l and writes dW; dgrad reads g_l and writes gx_l.
+    fp32 networks: 4 bytes per element; bf16 networks: 2 bytes for every tensor but the 4-channel clip side and dW."""
     chans = [4, 64, 128, 256, 512]
     t, h = 16, 64
     x_b, y_b, w_b = [], [], []
+    es = 2.0 if dtype == 'bf16' else 4.0
     for l in range(4):
         to, ho = t - 3, h // 2
-        x_b.append(4.0 * t * h * h * chans[l])
-        y_b.append(4.0 * to * ho * ho * chans[l + 1])
+        x_b.append((4.0 if l == 0 else es) * t * h * h * chans[l])
+        y_b.append(es * to * ho * ho * chans[l + 1])
         w_b.append(4.0 * 64 * chans[l] * chans[l + 1])
         t, h = to, ho
     fprop = 2 * batch * (sum(x_b) + sum(y_b)) + sum(w_b)
@@ -67,11 +69,13 @@ def dv_conv_algorithmic_bytes_per_step(batch):
     return fprop + wgrad + dgrad
 
 
-def pmc_traffic(batch):
+def pmc_traffic(batch, dtype='f32'):
     """HBM-side traffic of the D_V conv launches of one step, from the committed rocprofv3 --pmc summary
     (FETCH_SIZE / WRITE_SIZE cannot be read from inside the process; tools/pmc_traffic.py documents the
     collection).  Scaled linearly from the profiled batch.  Returns (bytes_per_step | None, source)."""
-    for name in ('r02_dv_conv_traffic.json', 'r01_dv_conv_traffic.json'):          # newest collection first
+    names = ('r03_dv_conv_traffic_bf16.json',) if dtype == 'bf16' else \
+        ('r03_dv_conv_traffic.json', 'r02_dv_conv_traffic.json', 'r01_dv_conv_traffic.json')
+    for name in names:                                                              # newest collection first
         try:
             d = json.load(open(os.path.join(ROOT, 'profiles', name)))
             return d['dv_conv_hbm_bytes_per_step'] * batch / d['batch'], 'profiles/%s (PMC, batch %d)' % (name, d['batch'])
@@ -206,6 +210,11 @@ def main():
                          'HIP streams; 0: one stream throughout.  Default: 1, except 0 for the bf16 mode at batch >= 128, where '
                          'the step is dominated by bandwidth-bound passes that only contend (measured: 5178 vs 4768 clips/s '
                          'at batch 256).  The roofline pass is always one-stream.')
+    ap.add_argument('--secondary', type=int, default=1,
+                    help='1 (default): when the headline workload is configs[1] (no --model/--dtype/--batch), also time '
+                         'configs[2] (bf16, batch 256) and configs[3] (infogan) -- or, on 8 GPUs, configs[4] (128 clips per GPU) -- '
+                         'for a few steps each and report them under "secondary" on the same line')
+    ap.add_argument('--secondary-steps', type=int, default=8)
     ap.add_argument('--cpu-sample-batch', type=int, default=8, help='BASELINE.md section 3: batch 8')
     ap.add_argument('--cpu-sample-steps', type=int, default=5, help='timed iterations (median reported)')
     ap.add_argument('--cpu-sample-warmup', type=int, default=3)
@@ -248,68 +257,77 @@ def main():
     if args.tiles:
         hl.load_tile_choices(args.tiles)
 
-    gen, di, dv = mstep.make_models(args.model, num_labels=6, seed=0)         # identical init on every rank
-    if exchange is not None:                                                    # ... and made identical by construction
-        for net in (gen, di, dv):
-            exchange.broadcast_params([net.fp.p, net.fp.m, net.fp.v] + list(net.running.values()))
-    ts = mstep.TrainStep(args.model, gen, di, dv, exchange=exchange, seed=1234, rank=rank, precision=args.dtype, overlap=False,
-                          sync_bn=bool(args.sync_bn))
-    B = args.batch
-    g = torch.Generator(device='cuda')
-    g.manual_seed(rank)
-    x_real = torch.rand((B, 3, 16, 64, 64), device='cuda', generator=g) * 2 - 1   # synthetic U(-1,1), resident in HBM
-    t_real = torch.randint(0, 6, (B,), device='cuda', dtype=torch.int32, generator=g)
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Pass 1 (roofline): one stream, every conv launch bracketed by HIP events on that stream -- kernels run
-    # alone, so a launch's duration is the kernel's own time (this is what rocprofv3 --stats of
-    # `bench.py --overlap 0` reports too).
-    for _ in range(args.warmup):
-        ts.run(x_real, t_real)
-    barrier()
-    hl.timing_begin()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ts.run(x_real, t_real)
-    barrier()
-    dt_serial_instr = time.perf_counter() - t0
-    timing = hl.timing_end()
-    # Pass 2 (headline): un-instrumented, EXACTLY args.steps iterations between barrier + synchronize, with the
-    # side-stream placement unless --overlap 0.  Same kernels, same arithmetic, same results.
-    ts.set_overlap(bool(args.overlap))
-    for _ in range(args.warmup if args.overlap else 0):
-        ts.run(x_real, t_real)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ts.run(x_real, t_real)
-    barrier()
-    dt_best = time.perf_counter() - t0
-    tmax = torch.tensor([dt_best], device='cuda', dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt_best = float(tmax)
-    losses = ts.losses()
-
-    if rank == 0 and args.save_tiles:
-        hl.save_tile_choices(args.save_tiles)
-    if rank == 0:
-        ms_per_step = dt_best / args.steps * 1e3
-        value = B * world * args.steps / dt_best
+    def measure(model, dtype, B, steps, warmup, overlap):
+        """One workload: builds the three networks, runs the roofline pass (one stream, HIP events around every conv
+        launch) and the timed headline pass; returns the fields of a result line."""
+        if exchange is not None:
+            # every rank runs the SAME tile codes: geometries the shipped table does not hold are tuned by one local
+            # iteration on throw-away networks, then rank 0's choices are broadcast (a straggler sets the step time)
+            mstep.pretune_and_share_tiles(exchange, model, dtype, B, rank)
+        gen, di, dv = mstep.make_models(model, num_labels=6, seed=0)           # identical init on every rank
+        if exchange is not None:                                                # ... and made identical by construction
+            for net in (gen, di, dv):
+                exchange.broadcast_params([net.fp.p, net.fp.m, net.fp.v] + list(net.running.values()))
+        ts = mstep.TrainStep(model, gen, di, dv, exchange=exchange, seed=1234, rank=rank, precision=dtype, overlap=False,
+                              sync_bn=bool(args.sync_bn))
+        g = torch.Generator(device='cuda')
+        g.manual_seed(rank)
+        x_real = torch.rand((B, 3, 16, 64, 64), device='cuda', generator=g) * 2 - 1   # synthetic U(-1,1), resident in HBM
+        t_real = torch.randint(0, 6, (B,), device='cuda', dtype=torch.int32, generator=g)
+        # Pass 1 (roofline): one stream, every conv launch bracketed by HIP events on that stream -- kernels run
+        # alone, so a launch's duration is the kernel's own time (this is what rocprofv3 --stats of
+        # `bench.py --overlap 0` reports too).
+        for _ in range(warmup):
+            ts.run(x_real, t_real)
+        barrier()
+        hl.timing_begin()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ts.run(x_real, t_real)
+        barrier()
+        dt_serial_instr = time.perf_counter() - t0
+        timing = hl.timing_end()
+        # Pass 2 (headline): un-instrumented, EXACTLY `steps` iterations between barrier + synchronize, with the
+        # side-stream placement unless --overlap 0.  Same kernels, same arithmetic, same results.
+        ts.set_overlap(bool(overlap))
+        for _ in range(warmup if overlap else 0):
+            ts.run(x_real, t_real)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ts.run(x_real, t_real)
+        barrier()
+        dt_local = time.perf_counter() - t0
+        tall = torch.tensor([dt_local], device='cuda', dtype=torch.float64)
+        per_rank = [dt_local]
+        if world > 1:
+            gathered = [torch.zeros_like(tall) for _ in range(world)]
+            dist.all_gather(gathered, tall)
+            per_rank = [float(t) for t in gathered]
+            dist.all_reduce(tall, op=dist.ReduceOp.MAX)
+        dt_best = float(tall)
+        losses = ts.losses()
+        del ts, gen, di, dv, x_real
+        torch.cuda.empty_cache()
+        if rank != 0:
+            return None
+        ms_per_step = dt_best / steps * 1e3
+        value = B * world * steps / dt_best
         tot, f_fwd, f_wg, f_dg = dv_conv_flops_per_step(B)
         dv_ms = {k: timing.get('D_V.' + k, (0, 0.0)) for k in ('fprop', 'wgrad', 'dgrad')}
-        dv_total_ms = sum(v[1] for v in dv_ms.values()) / args.steps
+        dv_total_ms = sum(v[1] for v in dv_ms.values()) / steps
         achieved = tot / (dv_total_ms * 1e-3) / 1e12 if dv_total_ms > 0 else 0.0
         kern = {}
         for k, fl in (('fprop', f_fwd), ('wgrad', f_wg), ('dgrad', f_dg)):
             n_l, ms = dv_ms[k]
-            kern[k] = {"launches_per_step": n_l / args.steps, "ms_per_step": ms / args.steps,
-                       "tflops": fl / (ms / args.steps * 1e-3) / 1e12 if ms > 0 else 0.0}
-        all_conv_ms = sum(v[1] for k, v in timing.items() if ' N=' not in k) / args.steps
+            kern[k] = {"launches_per_step": n_l / steps, "ms_per_step": ms / steps,
+                       "tflops": fl / (ms / steps * 1e-3) / 1e12 if ms > 0 else 0.0}
+        all_conv_ms = sum(v[1] for k, v in timing.items() if ' N=' not in k) / steps
         by_layer = {}
         for k, (n_l, ms) in sorted(timing.items()):
             if ' N=' not in k:
@@ -318,40 +336,68 @@ def main():
             N_, T_, H_, Ci_, Co_ = (int(f[x]) for x in ('N', 'T', 'H', 'Ci', 'Co'))
             kt_ = 4 if T_ > 1 else 1
             gflop = 2.0 * N_ * (T_ - kt_ + 1) * (H_ // 2) ** 2 * kt_ * 16 * min(Ci_, 3 if Ci_ == 4 else Ci_) * Co_ / 1e9
-            by_layer[k] = {"launches_per_step": n_l / args.steps, "ms_per_launch": ms / n_l,
+            by_layer[k] = {"launches_per_step": n_l / steps, "ms_per_launch": ms / n_l,
                            "tflops": gflop * n_l / ms if ms > 0 else 0.0}
-        traffic, traffic_src = pmc_traffic(B) if args.dtype == 'f32' else (None, None)
-        peak = PEAK_FP32_MFMA_TFLOPS if args.dtype == 'f32' else PEAK_BF16_MFMA_TFLOPS
-        cfg_name = "configs[2]" if (args.dtype == 'bf16' and B == 256) else "configs[1]" if (args.dtype == 'f32' and B == 32) else \
-            "off-list variant of configs[1]"
-        out = {
+        traffic, traffic_src = pmc_traffic(B, dtype)
+        peak = PEAK_FP32_MFMA_TFLOPS if dtype == 'f32' else PEAK_BF16_MFMA_TFLOPS
+        cfg_name = "configs[2]" if (dtype == 'bf16' and B == 256 and model == 'normal') else \
+            "configs[1]" if (dtype == 'f32' and B == 32 and model == 'normal') else \
+            "configs[3]" if (dtype == 'f32' and B == 32 and model == 'infogan') else \
+            "configs[4]" if (B == 128 and world == 8 and model == 'normal') else "off-list variant of configs[1]"
+        per_rank_ms = sorted(t / steps * 1e3 for t in per_rank)
+        return {
             "metric": "training clips/sec (16\u00d73\u00d764\u00d764)", "value": value, "unit": "clips/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic" + (" (single-device rehearsal)" if rehearsal else ""),
+            "steps": steps, "warmup": warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic" + (" (single-device rehearsal)" if rehearsal else ""),
             "config": {"workload": "MUG-shape synthetic (B,3,16,64,64) U(-1,1), one update_core iteration per step "
-                                   "(BASELINE.json %s)" % cfg_name, "variant": args.model,
+                                   "(BASELINE.json %s)" % cfg_name, "variant": model,
                        "per_gpu_batch": B, "global_batch": B * world, "n_filters": 64, "dim_zl": 6,
-                       "parallelism": "dp%d" % world, "side_streams": bool(args.overlap),
+                       "parallelism": "dp%d" % world, "side_streams": bool(overlap),
                        "sync_bn": bool(args.sync_bn)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "dv_conv3d_mfma_util_pct": 100.0 * achieved / peak, "traffic": traffic, "algorithmic_bytes": dv_conv_algorithmic_bytes_per_step(B), "traffic_unit": "bytes per step (memory side of L2, incl. Infinity-Cache hits)",
+                         "frac": achieved / peak, "dv_conv3d_mfma_util_pct": 100.0 * achieved / peak, "traffic": traffic,
+                         "algorithmic_bytes": dv_conv_algorithmic_bytes_per_step(B, dtype),
+                         "traffic_unit": "bytes per step (memory side of L2, incl. Infinity-Cache hits)",
                          "traffic_source": traffic_src,
                          "traffic_measured_in_run": False,      # PMC counters need rocprofv3 around the process: see traffic_source
                          "kernel": "VideoDiscriminator Conv3d implicit-GEMM family (%s<FpropP|DgradP|WgradP>), "
-                                   % ("gemm_kernel" if args.dtype == 'f32' else "gemm_bf16_kernel") +
+                                   % ("gemm_kernel" if dtype == 'f32' else "gemm_bf16_kernel") +
                                    "dc1..dc4, all launches of one step",
                          "algorithmic_gflop_per_step": tot / 1e9, "kernel_ms_per_step": dv_total_ms, "by_pass": kern,
                          "all_conv_kernels_ms_per_step": all_conv_ms, "by_layer": by_layer,
                          "measured": "HIP events around every launch of the family during %d one-stream iterations "
                                      "(%.3f ms/step with the event records); the headline pass %s"
-                                     % (args.steps, dt_serial_instr / args.steps * 1e3,
+                                     % (steps, dt_serial_instr / steps * 1e3,
                                         "overlaps independent kernels on side streams, which stretches individual launches"
-                                        if args.overlap else "is one-stream too"),
-                         "dv_conv_share_of_step_time": dv_total_ms / (dt_serial_instr / args.steps * 1e3)},
-            "tile_choices": {"%s N=%d T=%d H=%d Ci=%d Co=%d" % (k[0], k[1], k[2], k[3], k[5], k[6]): v
-                             for k, v in sorted(hl.tile_choices().items(), key=str)},
+                                        if overlap else "is one-stream too"),
+                         "dv_conv_share_of_step_time": dv_total_ms / (dt_serial_instr / steps * 1e3)},
+            "dist": {"backend": dist.get_backend() if world > 1 else None, "world_size": dist.get_world_size() if world > 1 else 1,
+                     "per_rank_ms_per_step": {"min": per_rank_ms[0], "median": per_rank_ms[len(per_rank_ms) // 2],
+                                              "max": per_rank_ms[-1]}},
             "losses": losses,
         }
+
+    def default_overlap(dtype, B):
+        return int(os.environ.get('MCG_OVERLAP', '0' if (dtype == 'bf16' and B >= 128) else '1'))
+
+    out = measure(args.model, args.dtype, args.batch, args.steps, args.warmup, args.overlap)
+    # The other single-GPU workloads BASELINE.json names ride on the same line (a few steps each): configs[2] (bf16
+    # networks, batch 256) and configs[3] (--model infogan, batch 32); on 8 GPUs configs[4] (global batch 1024).
+    headline_cfg = args.model == 'normal' and args.dtype == 'f32' and args.batch == 32
+    secondary = []
+    if args.secondary and headline_cfg:
+        if world == 1:
+            secondary.append(measure('normal', 'bf16', 256, args.secondary_steps, 3, default_overlap('bf16', 256)))
+            secondary.append(measure('infogan', 'f32', 32, args.secondary_steps, 3, default_overlap('f32', 32)))
+        elif world == 8:
+            secondary.append(measure('normal', 'f32', 128, args.secondary_steps, 3, default_overlap('f32', 128)))
+    if rank == 0 and args.save_tiles:
+        hl.save_tile_choices(args.save_tiles)
+    if rank == 0:
+        keep = ("config", "dtype", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "roofline", "dist", "losses")
+        out["secondary"] = [{k: s_[k] for k in keep} for s_ in secondary]
+        out["tile_choices"] = {"%s N=%d T=%d H=%d Ci=%d Co=%d p=%d" % (k[0], k[1], k[2], k[3], k[5], k[6], k[9]): v
+                               for k, v in sorted(hl.tile_choices().items(), key=str)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_batch, args.cpu_sample_warmup, args.cpu_sample_steps)
         print(json.dumps(out))

@@ -128,12 +128,15 @@ __device__ __forceinline__ f32x4 bload_s(__amdgpu_buffer_rsrc_t r, u32 lane_off,
 // (PMC, dc2's input gradient) the loaders, not the matrix pipe, set their pace.  The fp32 kernels do not: there the same
 // change made every launch 0.5-6 % faster on one stream and the side-stream iteration 2 % slower (section 3 of DESIGN.md).
 // ---------------- fprop ----------------
-template <int BM, int BN, int BK, int E_ = 4, bool ST = false>
+// NT: threads per block (the slot convention with NT threads); SW: the K-contiguous 16-byte slot a thread LOADS is XOR-swizzled
+// by its tile row, ((row >> 1) & 7) -- the source-side half of the LDS-DMA kernels' bank-conflict-free tile image (the
+// destination of an LDS-DMA load is lane-linear, so the permutation goes on the source address; gemm_bf16_v2_kernel).
+template <int BM, int BN, int BK, int E_ = 4, bool ST = false, int NT = NTHREADS, bool SW = false>
 struct FpropP {
     static constexpr bool A_KC = true, B_KC = true;
     static constexpr int ORDER = 0;
     static constexpr int E = E_, ESZ = 16 / E_;
-    static constexpr int NA = BM * BK / E / NTHREADS, NB = BN * BK / E / NTHREADS;
+    static constexpr int NA = BM * BK / E / NT, NB = BN * BK / E / NT;
     static constexpr bool HAS_EPI = true;
     Geom g;
     Epi e;
@@ -155,10 +158,10 @@ struct FpropP {
                         // for the quarter of a tile's run time that otherwise separates the four uses).
 
     __device__ void init(int m0, int n0, int tid, int z) {
-        constexpr int KC4 = BK / E, RSTEP = NTHREADS / KC4;        // 16-byte slots per tile row, rows per pass
+        constexpr int KC4 = BK / E, RSTEP = NT / KC4;              // 16-byte slots per tile row, rows per pass
         xr = make_srd(x, g.x_bytes); wr = make_srd(w, g.w_bytes);
         zz = z;
-        ak = (tid % KC4) * E;
+        ak = SW ? ((tid % KC4) ^ ((tid / (2 * KC4)) & (KC4 - 1))) * E : (tid % KC4) * E;
         krot = 0;
 #ifndef MCG_NO_KROT          // (timing A/B only)
         if (g.kt == 4) {
@@ -217,6 +220,22 @@ struct FpropP {
         const u32 kb = (u32)rotated(k0) * (u32)ESZ;
 #pragma unroll
         for (int j = 0; j < NB; ++j) r[j] = ST ? bload_s(wr, bbase[j], kb) : bload(wr, bbase[j] + kb);
+    }
+    // the same addresses for the LDS-DMA kernels: f(slot, per-lane byte offset (bit 31: out of range), wave-uniform byte offset).
+    // Only for layers whose K-steps lie inside one filter tap (channel count a power of two and a multiple of BK: v2_ok).
+    __device__ __amdgpu_buffer_rsrc_t a_rsrc() const { return xr; }
+    __device__ __amdgpu_buffer_rsrc_t b_rsrc() const { return wr; }
+    template <class F> __device__ void each_a(int k0, F&& f) const {
+        const int kr = rotated(k0);
+        const int tap = kr >> g.lgCi, ci0 = kr & (g.Ci - 1), sp = tap & 15;
+        const int off = ((((tap >> 4) * g.Hi + (sp >> 2)) * g.Wi + (sp & 3)) * g.Ci + ci0 + ak) * ESZ;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) f(j, (((~amask[j]) >> sp) << 31) | (u32)(abase[j] + off), 0u);
+    }
+    template <class F> __device__ void each_b(int k0, F&& f) const {
+        const u32 kb = (u32)rotated(k0) * (u32)ESZ;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) f(j, bbase[j], kb);
     }
     // plain epilogue: the row part of an output address is computed once per accumulator row (row_off), not per element
     static constexpr bool HAS_ROW_OFF = true;
@@ -571,7 +590,7 @@ __device__ __forceinline__ float epi_act_mask(float v, int act) {
     return 1.f;
 }
 
-template <class P, int BM, int BN, int WM, int WN, int TM, int TN, int EPI>
+template <class P, int BM, int BN, int WM, int WN, int TM, int TN, int EPI, int NT = NTHREADS>
 __device__ __forceinline__ void fused_epilogue(const P& p, f32x16 (&acc)[TM][TN], int m0, int n0, int bx, int bz,
                                                int tid, float* red) {
     // EPI selects what this instantiation can do (each class has its own register needs; the plain kernel is EPI = 0):
@@ -668,7 +687,7 @@ __device__ __forceinline__ void fused_epilogue(const P& p, f32x16 (&acc)[TM][TN]
     if (mode & EPI_SUMS) {
         __syncthreads();
         const int slot = p.slot(bx, bz);
-        for (int idx = tid; idx < BN * 4; idx += NTHREADS) {
+        for (int idx = tid; idx < BN * 4; idx += NT) {
             const int c = idx >> 2, g = (idx >> 1) & 1, w = idx & 1;
             if (g >= e.groups || n0 + c >= C) continue;
             float t = 0.f;
@@ -1044,6 +1063,168 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(P p) {
                 p.store(row, col, acc[a][b][r]);
             }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// The bf16 GEMM core built for the bf16 matrix pipe (round 3): gemm_bf16_v2_kernel.
+//
+// gemm_bf16_kernel above inherits the fp32 kernel's structure -- 128x128 tile, 4 waves, operands staged through
+// registers, one LDS buffer, two barriers per K-step -- which suits an MFMA that takes 64 cycles.  The bf16 MFMA is 16x
+// faster: a 128x128x64 K-step is 512 MFMA cycles per wave, less than the latency of the global loads that feed it, and
+// at 64 FLOP per operand byte the tile asks the L2s for more than they deliver.  This kernel:
+//   * block tile 256x128 or 256x256, BK = 64, 512 threads = 8 waves (4x2 or 2x4; a wave owns 64x64 or 128x64 outputs):
+//     87 / 128 FLOP per operand byte;
+//   * operands go global -> LDS directly (buffer_load_dwordx4 ... lds: no staging registers, no ds_write pass); the
+//     policies' per-slot byte offsets are the loads' voffset, out-of-range / padding slots carry bit 31 and the buffer
+//     range check fills their 16 LDS bytes with zeros;
+//   * a ring of STAGES tile buffers, ONE barrier per K-step: before the barrier a wave waits (counted vmcnt) for its own
+//     pieces of the step it is about to read -- the loads of the following STAGES - 2 steps stay in flight across the barrier;
+//     after it, it issues the loads of step + STAGES - 1 into the buffer every wave has just finished reading;
+//   * LDS image of a K-contiguous tile: rows of 64 bf16 = 128 B, the 16-byte chunk c of row r at position c ^ ((r >> 1) & 7)
+//     -- an LDS-DMA load writes lane-linear, so the permutation is applied to the SOURCE chunk a lane loads (policy flag
+//     SW) and again to the address of the ds_read_b128; the 16-lane groups of a b128 read then touch 16 distinct slots of
+//     the 256-byte bank row (conflict-free: checked for both lane-group lists of the microarchitecture guide).
+// Served by the policies above with NT = 512, SW = true, scalar tap decode.  Layers it covers: bf16-stored operands,
+// channel counts powers of two >= 64 (v2_ok); everything else stays on gemm_bf16_kernel.
+// ------------------------------------------------------------------------------------------
+#define MCG_LDSP(p) ((__attribute__((address_space(3))) void*)(p))
+constexpr int NT2 = 512;
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+}
+
+template <class P, int BM, int BN, int STAGES, int EPI = 0>
+__global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
+    constexpr int BK = 64;
+    constexpr int WM = (BM >= 2 * BN) ? 4 : 2, WN = 8 / WM;            // 256x128: 4 x 2 waves of 64x64; 256x256: 2 x 4 of 128x64
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+    constexpr int NA = P::NA, NB = P::NB, PIECES = NA + NB;             // 1-KiB LDS-DMA pieces a wave issues per K-step
+    static_assert(P::A_KC && P::B_KC, "K-contiguous operands");
+    static_assert(NA * NT2 * 16 == A_BYTES && NB * NT2 * 16 == B_BYTES, "slot convention");
+    static_assert(STAGES == 2 || STAGES == 3, "ring depth");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // STAGES * STAGE bytes, reused by the fused epilogue
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+    int bx, by, bz;
+    {   // XCD-aware tile mapping, as in gemm_kernel
+        const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+        const int nwg = gx * gy * gz;
+        const int L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const int xcd = L & 7, q = nwg >> 3, r = nwg & 7;
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+        if constexpr (P::ORDER == 0) {
+            by = t % gy; bx = (t / gy) % gx; bz = t / (gy * gx);
+        } else {
+            const int Lb = blockIdx.x, xq = Lb & 7, qq = Lb >> 3;
+            const int cls = qq & 3, rr = qq >> 2;
+            const int split = rr / p.tiles8, tl = (rr - split * p.tiles8) * 8 + xq;
+            if (tl >= p.gxm * p.gyn) return;
+            by = tl % p.gyn; bx = tl / p.gyn; bz = split * 4 + cls;
+        }
+    }
+    const int m0 = bx * BM, n0 = by * BN;
+    const int z = bz;
+    p.init(m0, n0, tid, z);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int kend = p.k_end(z);
+    const __amdgpu_buffer_rsrc_t ar = p.a_rsrc(), br = p.b_rsrc();
+    // slot j of this thread is the 16-byte LDS position tid + NT2 * j of its tile: piece (wave, j) starts at wave KiB + 8 j KiB
+    auto issue = [&](int k, int buf) {
+        unsigned char* sa = smem + buf * STAGE + wave * 1024;
+        unsigned char* sb = sa + A_BYTES;
+        const bool live = k < kend;
+        const int kk = live ? k : kend - BK;                     // past the end: the offsets are forced out of range (zeros land in
+        p.each_a(kk, [&](int j, u32 vo, u32 so) {                // a buffer nobody reads), which keeps the vmcnt arithmetic uniform
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ar, MCG_LDSP(sa + j * 8192), 16, live ? vo : OOB, so, 0, 0);
+        });
+        p.each_b(kk, [&](int j, u32 vo, u32 so) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(br, MCG_LDSP(sb + j * 8192), 16, live ? vo : OOB, so, 0, 0);
+        });
+    };
+
+    // MFMA operand reads: row r = w?0 + 32 i + li of a tile, k chunk q = 2 kc + lh at position q ^ ((r >> 1) & 7);
+    // w?0 and 32 i are multiples of 16, so the swizzle term is that of li
+    const int sw = (li >> 1) & 7;
+    u32 xo[4];
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) xo[kc] = (u32)(((2 * kc + lh) ^ sw) << 4);
+    const u32 a_row = (u32)(wm0 + li) * 128u, b_row = (u32)A_BYTES + (u32)(wn0 + li) * 128u;
+
+    int k_cur = p.next_valid(p.k_begin(z));
+    int k_nx[STAGES - 1];                                        // the K-steps whose loads are (to be) in flight
+    {
+        int k = k_cur;
+#pragma unroll
+        for (int s = 0; s < STAGES - 1; ++s) {
+            issue(k, s);
+            k = k < kend ? p.next_valid(k + BK) : kend;
+            k_nx[s] = k;
+        }
+    }
+    int buf = 0;
+    while (k_cur < kend) {
+        wait_vmcnt<(STAGES - 2) * PIECES>();                     // this wave's pieces of step k_cur have landed
+        __builtin_amdgcn_s_barrier();                            // ... and everyone's; everyone has finished reading the previous step
+        {
+            const int kl = k_nx[STAGES - 2];                     // the step STAGES - 1 ahead: into the buffer read one step ago
+            int nb = buf + STAGES - 1; nb = nb >= STAGES ? nb - STAGES : nb;
+            issue(kl, nb);
+            const int kn = kl < kend ? p.next_valid(kl + BK) : kend;
+            k_cur = k_nx[0];                                     // (the MFMA phase below works on `buf`, not on k_cur)
+#pragma unroll
+            for (int s = 0; s < STAGES - 2; ++s) k_nx[s] = k_nx[s + 1];
+            k_nx[STAGES - 2] = kn;
+        }
+        const unsigned char* sbase = smem + buf * STAGE;
+        // operand fragments two deep: the reads of k chunk kc + 1 are in flight under the MFMAs of chunk kc
+        bf16x8 fa[2][TM], fb[2][TN];
+        auto frags = [&](int kc, int slot) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[slot][i] = *reinterpret_cast<const bf16x8*>(sbase + a_row + xo[kc] + i * 4096);
+#pragma unroll
+            for (int i = 0; i < TN; ++i) fb[slot][i] = *reinterpret_cast<const bf16x8*>(sbase + b_row + xo[kc] + i * 4096);
+        };
+        frags(0, 0);
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            if (kc + 1 < 4) frags(kc + 1, (kc + 1) & 1);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kc & 1][a], fb[kc & 1][b], acc[a][b], 0, 0, 0);
+        }
+        buf = buf + 1 == STAGES ? 0 : buf + 1;
+    }
+    wait_vmcnt<0>();                                             // the (dummy) loads still in flight write LDS: drain them before the
+    __syncthreads();                                             // epilogue reuses the buffers
+
+    if constexpr (EPI != 0) {
+        fused_epilogue<P, BM, BN, WM, WN, TM, TN, EPI, NT2>(p, acc, m0, n0, bx, bz, tid, reinterpret_cast<float*>(smem));
+        return;
+    }
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long ro = p.row_off(m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) p.store_at(ro, n0 + wn0 + b * 32 + li, acc[a][b][r]);
+        }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1841,7 +2022,7 @@ int make_geom(const mcg_conv_geom* c, Geom& g) {
     if (c->ci_valid < 0 || c->ci_valid > c->Ci) return MCG_ERR_BAD_ARG;
     g.cv = c->ci_valid ? c->ci_valid : c->Ci;
     if (g.prec != MCG_PREC_F32 && g.prec != MCG_PREC_BF16 && g.prec != MCG_PREC_BF16_STORE) return MCG_ERR_BAD_ARG;
-    if (c->tile < 0 || c->tile % 100 > 6 || (c->tile / 100) % 10 > 2 || c->tile / 1000 > 2) return MCG_ERR_BAD_ARG;
+    if (c->tile < 0 || c->tile % 100 > 8 || (c->tile / 100) % 10 > 2 || c->tile / 1000 > 2) return MCG_ERR_BAD_ARG;
     g.tile = c->tile % 100; g.bk = ((c->tile / 100) % 10) * 32; g.ksplit = 1 << (c->tile / 1000);
     g.lgHo = ilog2_exact(g.Ho); g.lgWo = ilog2_exact(g.Wo);
     g.lgCi = ilog2_exact(g.Ci); g.lgCo = ilog2_exact(g.Co);
@@ -1964,6 +2145,41 @@ int launch_wgrad(const Geom& g, const float* x, const float* y, float* dw, hipSt
     return MCG_OK;
 }
 
+// ---- launches of gemm_bf16_v2_kernel (tile codes 7 = 256x128, three-buffer ring; 8 = 256x256, two buffers) ----
+// what the LDS-DMA kernels cover: bf16-stored operands, every K-step inside one filter tap
+bool v2_ok(const Geom& g, int kdim /* channel count along K: Ci (fprop), Co (dgrad) */) {
+    return g.prec == MCG_PREC_BF16_STORE && kdim >= 64 && (kdim & (kdim - 1)) == 0 && g.ksplit == 1;
+}
+
+template <class K> int v2_set_lds(K kernel, size_t lds, std::once_flag& once) {
+    hipError_t attr = hipSuccess;
+    std::call_once(once, [&] { attr = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+    return attr == hipSuccess ? MCG_OK : MCG_ERR_LAUNCH;
+}
+#define MCG_V2_LAUNCH(KERNEL, GRID, LDS, P)                                                     \
+    do {                                                                                        \
+        static std::once_flag once_;                                                            \
+        if (v2_set_lds(KERNEL, LDS, once_) != MCG_OK) return MCG_ERR_LAUNCH;                    \
+        hipLaunchKernelGGL(KERNEL, GRID, dim3(NT2), LDS, s, P);                                 \
+    } while (0)
+
+template <int BM, int BN, int STAGES>
+int launch_fprop_v2(const Geom& g, const float* x, const float* w, const float* bias, float* y, const Epi& e, mcg_conv_epilogue* ep, hipStream_t s) {
+    using Pol = FpropP<BM, BN, 64, 8, true, NT2, true>;
+    Pol p;
+    p.g = g; p.e = e; p.x = x; p.w = w; p.bias = bias; p.y = y;
+    p.M = g.N * g.To * g.Ho * g.Wo; p.K = g.taps * g.Ci;
+    p.kchunk = p.K;
+    if (ep) { ep->n_slots = (p.M + BM - 1) / BM; ep->slot_stride = e.slot_stride; }
+    const int cls = e.mode ? epi_class(e.mode) : 0;
+    if (cls > 1) return MCG_ERR_UNSUPPORTED;
+    const dim3 grid((p.M + BM - 1) / BM, (g.Co + BN - 1) / BN, 1);
+    constexpr size_t lds = (size_t)STAGES * (BM + BN) * 128;
+    if (cls == 0) MCG_V2_LAUNCH((gemm_bf16_v2_kernel<Pol, BM, BN, STAGES, 0>), grid, lds, p);
+    else MCG_V2_LAUNCH((gemm_bf16_v2_kernel<Pol, BM, BN, STAGES, 1>), grid, lds, p);
+    return MCG_OK;
+}
+
 // tile / K-depth / MFMA-type dispatch of the launch_* templates
 #ifdef MCG_FAST_BUILD       // compile-time experiments: one tile, one K depth, fp32 only
 #define MCG_TILES(fn, t, BK, BF, ...) do { st = fn<128, 128, 32, 0>(__VA_ARGS__); } while (0)
@@ -2073,6 +2289,11 @@ int conv_fprop_impl(const mcg_conv_geom* c, const float* x, const float* w, cons
         return finish(st);
     }
     if (t == 6) return MCG_ERR_UNSUPPORTED;
+    if (t == 7 || t == 8) {                                        // the LDS-DMA kernels (bf16-stored operands, wide layers)
+        if (!v2_ok(g, g.Ci) || e.mode & ~(EPI_STATS | EPI_COL | EPI_MASKMUL)) return MCG_ERR_UNSUPPORTED;
+        st = t == 7 ? launch_fprop_v2<256, 128, 3>(g, x, w, bias, y, e, ep, s) : launch_fprop_v2<256, 256, 2>(g, x, w, bias, y, e, ep, s);
+        return finish(st);
+    }
     const long long mt = (M + 127) / 128;
     if (!t) t = g.Co <= 64 ? 2 : (mt * ((g.Co + 127) / 128) >= 1024 ? 1 : (mt * ((g.Co + 63) / 64) >= 512 ? 2 : 3));
     // 64-deep K-steps halve the per-step overhead (barriers, LDS refill, address math) and pay off when the

@@ -304,3 +304,26 @@ def make_models(model='normal', num_labels=6, channel=3, dim_zc=50, dim_zm=10, n
     dis_i = nets.DisNet(2, c_d, out_d, n_filters, use_noise, noise_sigma, video_length, device=device, seed=seed + 1)
     dis_v = nets.DisNet(3, c_d, out_d, n_filters, use_noise, noise_sigma, video_length, device=device, seed=seed + 2)
     return gen, dis_i, dis_v
+
+
+def pretune_and_share_tiles(exchange, model, precision, batch, rank, num_labels=6):
+    """Data parallel: make every rank run the SAME GEMM tile codes.  With autotune on, a geometry the shipped table does
+    not hold is timed at its first launch -- per rank, so two ranks may keep different winners (results stay identical:
+    Adam consumes the all-reduced gradient; but a rank with a slower choice sets the step time).  Here every rank runs ONE
+    local iteration (no exchange) on throw-away networks, which tunes whatever is missing, then rank 0's table replaces
+    everyone's.  No reference counterpart (the reference is single-device, train.py:87-91)."""
+    if exchange is None or exchange.world == 1:
+        return
+    if hl._autotune:
+        gen, di, dv = make_models(model, num_labels=num_labels, seed=0)
+        ts = TrainStep(model, gen, di, dv, seed=0, rank=rank, precision=precision)
+        x = torch.zeros((batch, gen.out_channels, gen.video_len, nets.IMG, nets.IMG), device=gen.device)
+        t = torch.zeros(batch, dtype=torch.int32, device=gen.device)
+        ts.run(x, t)
+        torch.cuda.synchronize()
+        del ts, gen, di, dv, x
+    table = [[[list(k), v] for k, v in hl.tile_choices().items()]] if rank == 0 else [None]
+    exchange.dist.broadcast_object_list(table, src=0, group=exchange.group)
+    hl._tile_cache.clear()
+    for k, v in table[0]:
+        hl._tile_cache[tuple(k)] = int(v)
