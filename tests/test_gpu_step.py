@@ -266,7 +266,11 @@ def _run_steps(pkg, model, dim_zl, nf, n, steps, seed, min_tight_steps=1, overla
             got = net.export_reference_grads()
             for k in refg:
                 if not is_pre_bn_bias(k, kind):
-                    assert rel_l2(got[k], refg[k]) < gtol, (s, name, k, ref['min_margin'])
+                    # (the bias of the logit layer is 1..7 numbers, each the sum of a few loss gradients of either sign with
+                    # magnitude <= 1/n: after cancellation fp32 rounding of the TERMS, ~6e-8 each, is all that is left to
+                    # compare -- held to an absolute bound where the relative one is below that floor)
+                    tiny = refg[k].size <= 8 and np.abs(np.asarray(got[k], F64) - refg[k]).max() < 5e-7
+                    assert tiny or rel_l2(got[k], refg[k]) < gtol, (s, name, k, ref['min_margin'])
         check_params(DI.export_reference_params(), di, 'dis', ptol, 'D_I step %d' % s)
         check_params(DV.export_reference_params(), dv, 'dis', ptol, 'D_V step %d' % s)
         check_params(G.export_reference_params(), gen, 'gen', ptol, 'G step %d' % s)
