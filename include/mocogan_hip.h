@@ -74,6 +74,10 @@ typedef struct mcg_conv_geom {
                                 * 3 = 64x64, 4 = 256x64, 5 = 64x256 (the last two with K-steps of 32 in fp32 mode);
                                 * 6 = the patch-in-LDS kernels of the Ci = 4, Co = 64 layers (refused elsewhere; what
                                 * tile 0 picks for those layers in fprop / dgrad; in wgrad, fp32 only, by request only);
+                                * 7 / 8 = the LDS-DMA kernels of bf16-stored operands (MCG_PREC_BF16_STORE, channel counts
+                                * powers of two >= 64; refused elsewhere): 512 threads, operands straight from global
+                                * memory into a ring of LDS tile buffers, block tile 256x128 / 256x256 (fprop, dgrad;
+                                * dgrad with Ci = 64: 256x64) or 128x256 / 256x256 (wgrad); no K split, no +100 / +200;
                                 * +100 / +200 also fixes the K-step depth to 32 / 64; +1000 / +2000
                                 * makes mcg_conv_fprop / mcg_conv_dgrad split the K range over 2 / 4 blocks per tile
                                 * (partial tiles are added atomically onto a cleared output; for long-K layers with

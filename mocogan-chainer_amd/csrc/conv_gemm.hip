@@ -127,6 +127,12 @@ __device__ __forceinline__ f32x4 bload_s(__amdgpu_buffer_rsrc_t r, u32 lane_off,
 // multiplies) per K-step.  The bf16 kernels use it: their MFMA is 16x faster, and at 12 vector instructions per MFMA
 // (PMC, dc2's input gradient) the loaders, not the matrix pipe, set their pace.  The fp32 kernels do not: there the same
 // change made every launch 0.5-6 % faster on one stream and the side-stream iteration 2 % slower (section 3 of DESIGN.md).
+// (SW, tiles kept in global orientation [k][cols], read with ds_read_b64_tr_b16: the 16-byte column chunk a thread loads is
+// XOR-swizzled by its k row -- sw_cols -- so that the four k rows of a transposed-read block fall into different banks)
+__device__ __forceinline__ constexpr int sw_cols(int row, int chunks_per_row) {
+    return chunks_per_row >= 16 ? (row & 3) << 2 : ((row >> 1) & 1) << 2;
+}
+
 // ---------------- fprop ----------------
 // NT: threads per block (the slot convention with NT threads); SW: the K-contiguous 16-byte slot a thread LOADS is XOR-swizzled
 // by its tile row, ((row >> 1) & 7) -- the source-side half of the LDS-DMA kernels' bank-conflict-free tile image (the
@@ -259,12 +265,12 @@ struct FpropP {
 };
 
 // ---------------- dgrad (one output-parity class per blockIdx.z) ----------------
-template <int BM, int BN, int BK, int E_ = 4, bool ST = false>
+template <int BM, int BN, int BK, int E_ = 4, bool ST = false, int NT = NTHREADS, bool SW = false>
 struct DgradP {
     static constexpr bool A_KC = true, B_KC = false;
     static constexpr int ORDER = 1;
     static constexpr int E = E_, ESZ = 16 / E_;
-    static constexpr int NA = BM * BK / E / NTHREADS, NB = BN * BK / E / NTHREADS;
+    static constexpr int NA = BM * BK / E / NT, NB = BN * BK / E / NT;
     static constexpr bool HAS_EPI = true;
     Geom g;
     Epi e;
@@ -287,10 +293,10 @@ struct DgradP {
     // t: a temporal tap `a` whose source frame t - a falls outside [0, To) is then invalid for the whole
     // block and its K-steps are skipped (no loads, no MFMAs).  For D_V this removes 19..43 % of the work.
     __device__ void init(int m0, int n0, int tid, int z) {
-        constexpr int KC4 = BK / E, RSTEP = NTHREADS / KC4;
+        constexpr int KC4 = BK / E, RSTEP = NT / KC4;
         yr = make_srd(y, g.y_bytes); wr = make_srd(w, g.w_bytes);
         ph = (z >> 1) & 1; pw = z & 1; zsplit = z >> 2;
-        ak = (tid % KC4) * E;
+        ak = SW ? ((tid % KC4) ^ ((tid / (2 * KC4)) & (KC4 - 1))) * E : (tid % KC4) * E;
         {
             int mlast = m0 + BM - 1 < M ? m0 + BM - 1 : M - 1;
             tmin = div_N(g, m0 >> (g.lgWo + g.lgHo));
@@ -320,13 +326,31 @@ struct DgradP {
         }
         // B tile: rows = k (BK), cols = ci (BN); BN/4 float4 per row
         constexpr int C4 = BN / E;                                  // 16-byte slots per row
-        bci = n0 + (tid % C4) * E;
+        bci = n0 + (SW ? ((tid % C4) ^ sw_cols(tid / C4, C4)) : tid % C4) * E;
         bok = bci < g.Ci;
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            bkrow[j] = tid / C4 + (NTHREADS / C4) * j;
+            bkrow[j] = tid / C4 + (NT / C4) * j;
             bfast[j] = bok ? (u32)(bkrow[j] * g.taps * g.Ci + bci) * (u32)ESZ : OOB;
         }
+    }
+    // LDS-DMA kernels (as FpropP::each_a / each_b; layers with Co a power of two and a multiple of BK)
+    __device__ __amdgpu_buffer_rsrc_t a_rsrc() const { return yr; }
+    __device__ __amdgpu_buffer_rsrc_t b_rsrc() const { return wr; }
+    template <class F> __device__ void each_a(int k0, F&& f) const {
+        const int kr = rotated(k0);
+        const int ts = kr >> g.lgCo, co0 = kr & (g.Co - 1);
+        const int off = (co0 + ak - (((ts >> 2) * g.Ho + ((ts >> 1) & 1)) * g.Wo + (ts & 1)) * g.Co) * ESZ;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) f(j, (((~amask[j]) >> ts) << 31) | (u32)(abase[j] + off), 0u);
+    }
+    template <class F> __device__ void each_b(int k0r, F&& f) const {
+        const int k0 = rotated(k0r);
+        const int ts = k0 >> g.lgCo, co0 = k0 & (g.Co - 1);
+        const int tap = (ts >> 2) * 16 + ((1 - ph) + (ts & 2)) * 4 + (1 - pw) + 2 * (ts & 1);
+        const u32 base = (u32)((co0 * g.taps + tap) * g.Ci) * (u32)ESZ;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) f(j, bfast[j], base);
     }
     __device__ int k_begin(int z) const { return (z >> 2) * kchunk; }
     __device__ int k_end(int z) const { int e = ((z >> 2) + 1) * kchunk; return e < K ? e : K; }
@@ -426,14 +450,14 @@ struct DgradP {
 };
 
 // ---------------- wgrad (blockIdx.z = pixel split) ----------------
-template <int BM, int BN, int BK, int E_ = 4>
+template <int BM, int BN, int BK, int E_ = 4, int NT = NTHREADS, bool SW = false>
 struct WgradP {
     static constexpr bool HAS_EPI = false;
     static constexpr bool HAS_ROW_OFF = false;
     static constexpr bool A_KC = false, B_KC = false;
     static constexpr int ORDER = 2;
     static constexpr int E = E_, ESZ = 16 / E_;
-    static constexpr int NA = BM * BK / E / NTHREADS, NB = BN * BK / E / NTHREADS;
+    static constexpr int NA = BM * BK / E / NT, NB = BN * BK / E / NT;
     Geom g;
     const float* x; const float* y; float* dw;
     int Mpix, Kf, chunk;          // Kf = taps*Ci ; chunk = pixels per split (multiple of BK)
@@ -444,17 +468,38 @@ struct WgradP {
     __device__ void init(int m0, int n0, int tid, int /*z*/) {
         constexpr int AC4 = BM / E, BC4 = BN / E;
         xr = make_srd(x, g.x_bytes); yr = make_srd(y, g.y_bytes);
-        int aco = m0 + (tid % AC4) * E;
+        int aco = m0 + (SW ? ((tid % AC4) ^ sw_cols(tid / AC4, AC4)) : tid % AC4) * E;
         aoff = aco < g.Co ? (u32)aco * (u32)ESZ : OOB;
 #pragma unroll
-        for (int j = 0; j < NA; ++j) akrow[j] = tid / AC4 + (NTHREADS / AC4) * j;
-        int bkf = n0 + (tid % BC4) * E;
+        for (int j = 0; j < NA; ++j) akrow[j] = tid / AC4 + (NT / AC4) * j;
+        int bkf = n0 + (SW ? ((tid % BC4) ^ sw_cols(tid / BC4, BC4)) : tid % BC4) * E;
         bok = bkf < Kf;
         int kk = bok ? bkf : 0, tap;
         divmod_c(kk, g.Ci, g.lgCi, tap, bci);
         bt = tap >> 4; bkh = (tap >> 2) & 3; bkw = tap & 3;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) bkrow[j] = tid / BC4 + (NTHREADS / BC4) * j;
+        for (int j = 0; j < NB; ++j) bkrow[j] = tid / BC4 + (NT / BC4) * j;
+    }
+    // LDS-DMA kernels (as FpropP::each_a / each_b)
+    __device__ __amdgpu_buffer_rsrc_t a_rsrc() const { return yr; }
+    __device__ __amdgpu_buffer_rsrc_t b_rsrc() const { return xr; }
+    template <class F> __device__ void each_a(int k0, F&& f) const {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) f(j, aoff + (u32)((k0 + akrow[j]) * g.Co) * (u32)ESZ, 0u);
+    }
+    template <class F> __device__ void each_b(int k0, F&& f) const {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            int pix = k0 + bkrow[j];
+            bool ok = bok && pix < Mpix;
+            int wo = pix & (g.Wo - 1), ho = (pix >> g.lgWo) & (g.Ho - 1), q = pix >> (g.lgWo + g.lgHo);
+            int n = div_To(g, q), to = q - n * g.To;
+            int hi = 2 * ho - 1 + bkh, wi = 2 * wo - 1 + bkw;
+            ok = ok && (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)g.Wi;
+            int base = g.perm_n ? (int)x_batch_off(g, n) : n * (int)g.xs0;
+            u32 vo = (u32)(base + (((to + bt) * g.Hi + hi) * g.Wi + wi) * g.Ci + bci) * (u32)ESZ;
+            f(j, ok ? vo : OOB, 0u);
+        }
     }
     __device__ int k_begin(int z) const { return z * chunk; }
     __device__ int k_end(int z) const { int e = (z + 1) * chunk; return e < Mpix ? e : Mpix; }
@@ -1098,11 +1143,12 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 template <class P, int BM, int BN, int STAGES, int EPI = 0>
 __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
     constexpr int BK = 64;
-    constexpr int WM = (BM >= 2 * BN) ? 4 : 2, WN = 8 / WM;            // 256x128: 4 x 2 waves of 64x64; 256x256: 2 x 4 of 128x64
+    // wave grid: 256x128 -> 4 x 2 waves of 64x64; 256x256 -> 2 x 4 of 128x64; 128x256 -> 2 x 4 of 64x64; 256x64 -> 4 x 2 of 64x32
+    constexpr int WM = (BM >= 2 * BN) ? 4 : 2, WN = 8 / WM;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
     constexpr int NA = P::NA, NB = P::NB, PIECES = NA + NB;             // 1-KiB LDS-DMA pieces a wave issues per K-step
-    static_assert(P::A_KC && P::B_KC, "K-contiguous operands");
+    static_assert(TM >= 1 && TN >= 1, "a wave owns at least one 32x32 tile");
     static_assert(NA * NT2 * 16 == A_BYTES && NB * NT2 * 16 == B_BYTES, "slot convention");
     static_assert(STAGES == 2 || STAGES == 3, "ring depth");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // STAGES * STAGE bytes, reused by the fused epilogue
@@ -1120,13 +1166,13 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
         const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
         if constexpr (P::ORDER == 0) {
             by = t % gy; bx = (t / gy) % gx; bz = t / (gy * gx);
-        } else {
+        } else if constexpr (P::ORDER == 1) {
             const int Lb = blockIdx.x, xq = Lb & 7, qq = Lb >> 3;
             const int cls = qq & 3, rr = qq >> 2;
             const int split = rr / p.tiles8, tl = (rr - split * p.tiles8) * 8 + xq;
             if (tl >= p.gxm * p.gyn) return;
             by = tl % p.gyn; bx = tl / p.gyn; bz = split * 4 + cls;
-        }
+        } else { bx = t % gx; by = (t / gx) % gy; bz = t / (gx * gy); }
     }
     const int m0 = bx * BM, n0 = by * BN;
     const int z = bz;
@@ -1156,13 +1202,30 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
         });
     };
 
-    // MFMA operand reads: row r = w?0 + 32 i + li of a tile, k chunk q = 2 kc + lh at position q ^ ((r >> 1) & 7);
-    // w?0 and 32 i are multiples of 16, so the swizzle term is that of li
+    // MFMA operand reads.
+    // K-contiguous tile ([row][64 bf16]): row r = w?0 + 32 i + li, k chunk q = 2 kc + lh at position q ^ ((r >> 1) & 7);
+    // w?0 and 32 i are multiples of 16, so the swizzle term is that of li: one ds_read_b128 at (a_row | b_row) + xo[kc] + 4096 i.
+    // Tile in global orientation ([k][C cols], RB = 2 C bytes per k row): the transposing read ds_read_b64_tr_b16 -- a group of
+    // 16 lanes reads a 4 (k) x 16 (col) block, lane 4 q + p of the group addresses row q, columns 4 p .. 4 p + 3, and each
+    // lane receives the 4 k values of its column; two reads (k rows +0, +4) make the 8 k values of a lane.  Column chunk ch
+    // of k row r sits at position ch ^ sw_cols(r): with r = 16 kc + 8 lh + 4 h + q the term depends on q only.
     const int sw = (li >> 1) & 7;
     u32 xo[4];
 #pragma unroll
     for (int kc = 0; kc < 4; ++kc) xo[kc] = (u32)(((2 * kc + lh) ^ sw) << 4);
     const u32 a_row = (u32)(wm0 + li) * 128u, b_row = (u32)A_BYTES + (u32)(wn0 + li) * 128u;
+    const int tq = (lane & 15) >> 2, tcl = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);       // block row; 16-byte chunk within 32 columns
+    u32 ta[TM], tb[TN];                                                                       // byte address of (k row 8 lh + q, tile i) in a stage
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        constexpr int C4 = BM / 8, RB = BM * 2;
+        ta[i] = (u32)((8 * lh + tq) * RB + ((((wm0 >> 3) + 4 * i + tcl) ^ sw_cols(tq, C4)) << 4) + (lane & 1) * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        constexpr int C4 = BN / 8, RB = BN * 2;
+        tb[i] = (u32)A_BYTES + (u32)((8 * lh + tq) * RB + ((((wn0 >> 3) + 4 * i + tcl) ^ sw_cols(tq, C4)) << 4) + (lane & 1) * 8);
+    }
 
     int k_cur = p.next_valid(p.k_begin(z));
     int k_nx[STAGES - 1];                                        // the K-steps whose loads are (to be) in flight
@@ -1194,9 +1257,23 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
         bf16x8 fa[2][TM], fb[2][TN];
         auto frags = [&](int kc, int slot) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[slot][i] = *reinterpret_cast<const bf16x8*>(sbase + a_row + xo[kc] + i * 4096);
+            for (int i = 0; i < TM; ++i) {
+                if constexpr (P::A_KC) fa[slot][i] = *reinterpret_cast<const bf16x8*>(sbase + a_row + xo[kc] + i * 4096);
+                else {
+                    const u16* b = reinterpret_cast<const u16*>(sbase + ta[i] + kc * 16 * (BM * 2));
+                    s16x4 lo = lds_tr16(b), hi = lds_tr16(b + 4 * BM);
+                    fa[slot][i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+            }
 #pragma unroll
-            for (int i = 0; i < TN; ++i) fb[slot][i] = *reinterpret_cast<const bf16x8*>(sbase + b_row + xo[kc] + i * 4096);
+            for (int i = 0; i < TN; ++i) {
+                if constexpr (P::B_KC) fb[slot][i] = *reinterpret_cast<const bf16x8*>(sbase + b_row + xo[kc] + i * 4096);
+                else {
+                    const u16* b = reinterpret_cast<const u16*>(sbase + tb[i] + kc * 16 * (BN * 2));
+                    s16x4 lo = lds_tr16(b), hi = lds_tr16(b + 4 * BN);
+                    fb[slot][i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+            }
         };
         frags(0, 0);
 #pragma unroll
@@ -1217,14 +1294,24 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
         fused_epilogue<P, BM, BN, WM, WN, TM, TN, EPI, NT2>(p, acc, m0, n0, bx, bz, tid, reinterpret_cast<float*>(smem));
         return;
     }
+    if constexpr (P::HAS_ROW_OFF) {
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
+        for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const long long ro = p.row_off(m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
+            for (int r = 0; r < 16; ++r) {
+                const long long ro = p.row_off(m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
 #pragma unroll
-            for (int b = 0; b < TN; ++b) p.store_at(ro, n0 + wn0 + b * 32 + li, acc[a][b][r]);
-        }
+                for (int b = 0; b < TN; ++b) p.store_at(ro, n0 + wn0 + b * 32 + li, acc[a][b][r]);
+            }
+    } else {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    p.store(m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, n0 + wn0 + b * 32 + li, acc[a][b][r]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2180,6 +2267,45 @@ int launch_fprop_v2(const Geom& g, const float* x, const float* w, const float* 
     return MCG_OK;
 }
 
+template <int BM, int BN, int STAGES>
+int launch_dgrad_v2(const Geom& g, const float* y, const float* w, const float* bias, float* x, int act, int acc, const Epi& e, mcg_conv_epilogue* ep, hipStream_t s) {
+    using Pol = DgradP<BM, BN, 64, 8, true, NT2, true>;
+    Pol p;
+    p.g = g; p.e = e; p.y = y; p.w = w; p.bias = bias; p.x = x; p.act = act; p.accumulate = acc;
+    p.M = g.N * g.Ti * g.Ho * g.Wo; p.K = g.kt * 4 * g.Co;
+    p.kchunk = p.K;
+    if (ep) { ep->n_slots = 4 * ((p.M + BM - 1) / BM); ep->slot_stride = e.slot_stride; }
+    p.gxm = (p.M + BM - 1) / BM; p.gyn = (g.Ci + BN - 1) / BN; p.tiles8 = (p.gxm * p.gyn + 7) / 8;
+    const dim3 grid(8 * p.tiles8 * 4, 1, 1);
+    const int cls = e.mode ? epi_class(e.mode) : 0;
+    if (cls > 1) return MCG_ERR_UNSUPPORTED;
+    constexpr size_t lds = (size_t)STAGES * (BM + BN) * 128;
+    if (cls == 0) MCG_V2_LAUNCH((gemm_bf16_v2_kernel<Pol, BM, BN, STAGES, 0>), grid, lds, p);
+    else MCG_V2_LAUNCH((gemm_bf16_v2_kernel<Pol, BM, BN, STAGES, 1>), grid, lds, p);
+    return MCG_OK;
+}
+
+template <int BM, int BN, int STAGES>
+int launch_wgrad_v2(const Geom& g, const float* x, const float* y, float* dw, hipStream_t s) {
+    using Pol = WgradP<BM, BN, 64, 8, NT2, true>;
+    Pol p;
+    p.g = g; p.x = x; p.y = y; p.dw = dw;
+    p.Mpix = g.N * g.To * g.Ho * g.Wo; p.Kf = g.taps * g.Ci;
+    const int tiles = ((g.Co + BM - 1) / BM) * ((p.Kf + BN - 1) / BN);
+    const int ksteps = (p.Mpix + 63) / 64;
+    // one block per CU at a time (LDS): aim at 2 rounds of blocks; every block ends in BM x BN float atomics, so fewer, longer
+    // blocks than the register-staged kernel's
+    int splits = (512 + tiles - 1) / tiles;
+    if (splits > ksteps / 8) splits = ksteps / 8;        // keep >= 8 K-steps per block
+    if (splits < 1) splits = 1;
+    p.chunk = ((ksteps + splits - 1) / splits) * 64;
+    splits = (p.Mpix + p.chunk - 1) / p.chunk;
+    const dim3 grid((g.Co + BM - 1) / BM, (p.Kf + BN - 1) / BN, splits);
+    constexpr size_t lds = (size_t)STAGES * (BM + BN) * 128;
+    MCG_V2_LAUNCH((gemm_bf16_v2_kernel<Pol, BM, BN, STAGES, 0>), grid, lds, p);
+    return MCG_OK;
+}
+
 // tile / K-depth / MFMA-type dispatch of the launch_* templates
 #ifdef MCG_FAST_BUILD       // compile-time experiments: one tile, one K depth, fp32 only
 #define MCG_TILES(fn, t, BK, BF, ...) do { st = fn<128, 128, 32, 0>(__VA_ARGS__); } while (0)
@@ -2371,6 +2497,15 @@ int conv_dgrad_impl(const mcg_conv_geom* c, const float* y, const float* w, cons
         return finish(st);
     }
     if (t == 6) t = 0;                                           // elsewhere the first-layer code means "the kernel written for it"
+    if (t == 7 || t == 8) {                                      // the LDS-DMA kernels (bf16-stored operands, wide layers)
+        const long long frame_ = (long long)g.Ti * g.Hi * g.Wi * g.Ci;
+        if (!v2_ok(g, g.Co) || g.Ci < 64 || (g.Ci & (g.Ci - 1)) || (e.mode & ~(EPI_STATS | EPI_COL | EPI_MASKMUL))) return MCG_ERR_UNSUPPORTED;
+        (void)frame_;
+        if (g.Ci == 64) st = launch_dgrad_v2<256, 64, 3>(g, y, w, bias, x, act, accumulate, e, ep, s);
+        else if (g.Ci == 128 || t == 7) st = launch_dgrad_v2<256, 128, 3>(g, y, w, bias, x, act, accumulate, e, ep, s);
+        else st = launch_dgrad_v2<256, 256, 2>(g, y, w, bias, x, act, accumulate, e, ep, s);
+        return finish(st);
+    }
     if (!t && !e.mode && g.Ci == 4 && g.Co == 64 && (g.Wo & 15) == 0) {      // VALU kernel for the padded 3-channel clip
         const int runs = (int)(M / 16);                          // M = N*Ti*Ho*Wo half-resolution positions
         const int per_block = (NTHREADS / 64) * C4_RUNS_PER_WAVE;
@@ -2419,6 +2554,12 @@ extern "C" int mcg_conv_wgrad(const mcg_conv_geom* c, const float* x, const floa
         return finish(st);
     }
     if (t == 6) return MCG_ERR_UNSUPPORTED;
+    if (t == 7 || t == 8) {                                      // the LDS-DMA kernels: 128x256 (Co = 128) or 256x256
+        if (g.prec != MCG_PREC_BF16_STORE || g.Co < 128 || (g.Co & 63) || g.Ci < 64 || (g.Ci & (g.Ci - 1))) return MCG_ERR_UNSUPPORTED;
+        if (g.Co == 128 || t == 7) st = launch_wgrad_v2<128, 256, 3>(g, x, y, dw, s);
+        else st = launch_wgrad_v2<256, 256, 2>(g, x, y, dw, s);
+        return finish(st);
+    }
     if (!t) t = (g.Co <= 64 || Kf <= 64) ? 3 : 1;
     const bool bk64 = bk ? bk == 64 : g.prec != MCG_PREC_F32;
     MCG_DISPATCH(launch_wgrad, t, bk64, g.prec, g, x, y, dw, s);

@@ -858,3 +858,73 @@ def test_bf16_gemm_outputs(hl, case):
     g.tile = 0
     with pytest.raises(AssertionError):                            # the binding refuses an accumulating call with a bf16 result
         hl.conv_dgrad(g, gy16, w16, None, torch.zeros_like(xd, dtype=torch.bfloat16), accumulate=True)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The LDS-DMA GEMM kernels of bf16 networks (tile codes 7 = 256x128, 8 = 256x256: gemm_bf16_v2_kernel): wide layers
+# only (channel counts powers of two >= 64), bf16-stored operands
+# ------------------------------------------------------------------------------------------------------------------
+V2_CASES = [(2, 7, 16, 64, 128, 4),      # M = 512 rows, 3-D
+            (3, 1, 16, 128, 64, 1),      # M = 192: a ragged 256-row tile; Co = 64 < BN
+            (1, 5, 8, 256, 256, 4),      # M = 32: one nearly empty tile, long K
+            (2, 6, 32, 64, 128, 4),      # M = 1536: several tiles per frame
+            (5, 1, 8, 128, 512, 1)]      # 2-D, four N tiles of 128
+
+
+@pytest.mark.parametrize("case", V2_CASES)
+@pytest.mark.parametrize("tile", [7, 8])
+def test_lds_dma_kernels_match_the_oracle(hl, case, tile):
+    """fprop / dgrad / wgrad of the round-3 bf16 kernels (operands straight from global memory into a swizzled LDS image,
+    a ring of tile buffers, 8 waves) on bf16-representable inputs against the float64 oracle at the fp32 tolerances, plain
+    and with the statistics epilogue / a bf16 output; the padding taps are the zeros the buffer range check writes."""
+    N, Ti, H, Ci, Co, kt = case
+    rng = np.random.RandomState(9000 + V2_CASES.index(case))
+    lay = L()
+    x, W = _bf16_round(rng.uniform(-1, 1, (N, Ci, Ti, H, H))), _bf16_round(rng.randn(Co, Ci, kt, 4, 4) * 0.1)
+    b = rng.randn(Co)
+    gy = _bf16_round(rng.randn(N, Co, Ti - kt + 1, H // 2, H // 2))
+    y_ref = F.conv3d_fwd(x, W, b, (1, 2, 2), (0, 1, 1))
+    gx_ref, gW_ref, _ = F.conv3d_bwd(x, W, gy, (1, 2, 2), (0, 1, 1))
+    xd, wd, bd, gyd = lay.act_to_dev(dev(x)), lay.conv_w_to_dev(dev(W)), dev(b), lay.act_to_dev(dev(gy))
+    x16, w16, gy16 = xd.to(torch.bfloat16), wd.to(torch.bfloat16), gyd.to(torch.bfloat16)
+    g = hl.make_geom(N, Ti, H, H, Ci, Co, kt, precision='bf16s')
+    g.tile = tile
+    M = N * g.To * g.Ho * g.Wo
+    yd = torch.full((N, g.To, g.Ho, g.Wo, Co), 3.0, device="cuda")
+    hl.conv_fprop(g, x16, w16, bd, yd)
+    assert rel_l2(lay.act_from_dev(yd, Co), y_ref) < FWD_TOL
+    # statistics epilogue + bf16 output
+    y16 = torch.empty_like(yd, dtype=torch.bfloat16)
+    part = torch.zeros(hl.epilogue_part_floats(g, 'fprop', 1), device="cuda")
+    ep = hl.epilogue(sums=hl.SUMS_STATS, groups=1, part=part, out_bf16=True)
+    assert hl.conv_fprop(g, x16, w16, bd, y16, ep=ep, must_fuse=True)
+    assert torch.equal(y16, yd.to(torch.bfloat16))
+    sums = part[:ep.n_slots * ep.slot_stride].view(ep.n_slots, ep.slot_stride).double().sum(0)
+    v = y16.double().view(M, Co)
+    assert torch.allclose(sums[:Co], v.sum(0), rtol=1e-5, atol=1e-3) and torch.allclose(sums[Co:2 * Co], (v * v).sum(0), rtol=1e-5, atol=1e-3)
+    # input gradient (the filter tile stays in global orientation: transposing LDS reads), plain / bf16 output / column sums
+    gxd = torch.full((N, Ti, H, H, Ci), 7.0, device="cuda")
+    hl.conv_dgrad(g, gy16, w16, None, gxd)
+    assert rel_l2(lay.act_from_dev(gxd, Ci), gx_ref) < BWD_TOL
+    gx16 = torch.empty_like(gxd, dtype=torch.bfloat16)
+    part = torch.zeros(hl.epilogue_part_floats(g, 'dgrad', 1), device="cuda")
+    ep = hl.epilogue(sums=hl.SUMS_STATS, groups=1, part=part, out_bf16=True)
+    assert hl.conv_dgrad(g, gy16, w16, None, gx16, ep=ep, must_fuse=True)
+    assert torch.equal(gx16, gxd.to(torch.bfloat16))
+    sums = part[:ep.n_slots * ep.slot_stride].view(ep.n_slots, ep.slot_stride).double().sum(0)
+    v = gx16.double().view(-1, Ci)
+    assert torch.allclose(sums[:Ci], v.sum(0), rtol=1e-5, atol=1e-3)
+    gxa = torch.full((N, Ti, H, H, Ci), 0.5, device="cuda")
+    hl.conv_dgrad(g, gy16, w16, dev(rng.randn(Ci) * 0), gxa, accumulate=True)          # accumulate onto x (the frame-t add of the step)
+    assert rel_l2(lay.act_from_dev(gxa, Ci), gx_ref + 0.5) < BWD_TOL
+    # weight gradient (both tiles in global orientation), added onto what dw holds
+    if Co >= 128:
+        dwd = torch.ones_like(wd)
+        hl.conv_wgrad(g, x16, gy16, dwd)
+        assert rel_l2(lay.conv_w_from_dev(dwd, Ci, 3), gW_ref + 1) < BWD_TOL
+    # a narrow layer is refused (the caller keeps such layers on the register-staged kernels)
+    gn = hl.make_geom(2, 5, 16, 16, 16, 32, 4, precision='bf16s')
+    gn.tile = tile
+    with pytest.raises(hl.McgError):
+        hl.conv_fprop(gn, torch.zeros((2, 5, 16, 16, 16), device="cuda", dtype=torch.bfloat16),
+                      torch.zeros((32, 4, 4, 4, 16), device="cuda", dtype=torch.bfloat16), None, torch.zeros((2, 2, 8, 8, 32), device="cuda"))
