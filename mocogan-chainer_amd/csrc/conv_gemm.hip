@@ -23,6 +23,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <mutex>
+#include <type_traits>
 #include "mocogan_hip.h"
 #include "mcg_common.h"
 
@@ -326,7 +327,8 @@ struct DgradP {
         }
         // B tile: rows = k (BK), cols = ci (BN); BN/4 float4 per row
         constexpr int C4 = BN / E;                                  // 16-byte slots per row
-        bci = n0 + (SW ? ((tid % C4) ^ sw_cols(tid / C4, C4)) : tid % C4) * E;
+        bci = n0 + (SW && E == 8 ? ((tid % C4) ^ sw_cols(tid / C4, C4)) : tid % C4) * E;      // (fp32 tiles in global orientation are
+                                                                                              //  read column-wise with ds_read_b32: no swizzle)
         bok = bci < g.Ci;
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
@@ -468,11 +470,11 @@ struct WgradP {
     __device__ void init(int m0, int n0, int tid, int /*z*/) {
         constexpr int AC4 = BM / E, BC4 = BN / E;
         xr = make_srd(x, g.x_bytes); yr = make_srd(y, g.y_bytes);
-        int aco = m0 + (SW ? ((tid % AC4) ^ sw_cols(tid / AC4, AC4)) : tid % AC4) * E;
+        int aco = m0 + (SW && E == 8 ? ((tid % AC4) ^ sw_cols(tid / AC4, AC4)) : tid % AC4) * E;
         aoff = aco < g.Co ? (u32)aco * (u32)ESZ : OOB;
 #pragma unroll
         for (int j = 0; j < NA; ++j) akrow[j] = tid / AC4 + (NT / AC4) * j;
-        int bkf = n0 + (SW ? ((tid % BC4) ^ sw_cols(tid / BC4, BC4)) : tid % BC4) * E;
+        int bkf = n0 + (SW && E == 8 ? ((tid % BC4) ^ sw_cols(tid / BC4, BC4)) : tid % BC4) * E;
         bok = bkf < Kf;
         int kk = bok ? bkf : 0, tap;
         divmod_c(kk, g.Ci, g.lgCi, tap, bci);
@@ -629,6 +631,10 @@ struct FcWgradP {
 //   * in-kernel noise draws one Philox counter per (row quad, channel), whose four normals belong to the four
 //     rows the lane holds of that channel -- no normal is generated twice and none crosses lanes.
 // ------------------------------------------------------------------------------------------
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
 __device__ __forceinline__ float epi_act_mask(float v, int act) {
     if (act == MCG_ACT_RELU) return v > 0.f ? 1.f : 0.f;
     if (act == MCG_ACT_LRELU) return v < 0.f ? EPI_LRELU_SLOPE : 1.f;
@@ -665,10 +671,9 @@ __device__ __forceinline__ void fused_epilogue(const P& p, f32x16 (&acc)[TM][TN]
                     mu[g] = st[col]; is[g] = st[C + col]; sc[g] = st[2 * C + col]; sh[g] = st[3 * C + col];
                 }
         }
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
+        // (a compile-time loop: with TM = 4 the unroller gave up on the pragma and the dynamically indexed accumulators went to scratch)
+        static_for<0, TM * 4>([&](auto aq_) {
+                constexpr int a = decltype(aq_)::value / 4, q = decltype(aq_)::value % 4;
                 int row0 = m0 + wm0 + a * 32 + 8 * q + 4 * lh;
                 asm volatile("" : "+v"(row0));           // keeps the row decode INSIDE this iteration: hoisted out of the
                                                          // column loop, the 16 * TM decoded rows would cost a wave of occupancy
@@ -715,7 +720,7 @@ __device__ __forceinline__ void fused_epilogue(const P& p, f32x16 (&acc)[TM][TN]
                         if (ri.grp) { s0[1] += t0; s1[1] += t1; } else { s0[0] += t0; s1[0] += t1; }
                     }
                 }
-            }
+            });
         if (mode & EPI_SUMS) {
             // lanes l and l + 32 hold the same column; the WM waves that share the columns meet in LDS below
 #pragma unroll
@@ -1142,11 +1147,15 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 
 template <class P, int BM, int BN, int STAGES, int EPI = 0>
 __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
-    constexpr int BK = 64;
-    // wave grid: 256x128 -> 4 x 2 waves of 64x64; 256x256 -> 2 x 4 of 128x64; 128x256 -> 2 x 4 of 64x64; 256x64 -> 4 x 2 of 64x32
-    constexpr int WM = (BM >= 2 * BN) ? 4 : 2, WN = 8 / WM;
+    // P::E == 8: bf16 operands, BK = 64, v_mfma_f32_32x32x16_bf16.  P::E == 4: fp32 operands, BK = 32, v_mfma_f32_32x32x2_f32 --
+    // the same tile bytes, the same LDS images (a K-contiguous row is 128 bytes either way), the same ring; tiles in global
+    // orientation are read column-wise with ds_read_b32 (conflict-free as they are: no swizzle, no transposing read for 4-byte data).
+    constexpr bool F32 = P::E == 4;
+    constexpr int BK = F32 ? 32 : 64;
+    // wave grid: 256x128 -> 4 x 2 waves of 64x64; 256x256 -> 4 x 2 of 64x128; 128x256 -> 2 x 4 of 64x64; 256x64 -> 4 x 2 of 64x32
+    constexpr int WM = BM >= 256 ? 4 : 2, WN = 8 / WM;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
     constexpr int NA = P::NA, NB = P::NB, PIECES = NA + NB;             // 1-KiB LDS-DMA pieces a wave issues per K-step
     static_assert(TM >= 1 && TN >= 1, "a wave owns at least one 32x32 tile");
     static_assert(NA * NT2 * 16 == A_BYTES && NB * NT2 * 16 == B_BYTES, "slot convention");
@@ -1254,12 +1263,17 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
         }
         const unsigned char* sbase = smem + buf * STAGE;
         // operand fragments two deep: the reads of k chunk kc + 1 are in flight under the MFMAs of chunk kc
-        bf16x8 fa[2][TM], fb[2][TN];
+        typedef typename std::conditional<F32, f32x4, bf16x8>::type frag_t;
+        frag_t fa[2][TM], fb[2][TN];
         auto frags = [&](int kc, int slot) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                if constexpr (P::A_KC) fa[slot][i] = *reinterpret_cast<const bf16x8*>(sbase + a_row + xo[kc] + i * 4096);
-                else {
+                if constexpr (P::A_KC) fa[slot][i] = *reinterpret_cast<const frag_t*>(sbase + a_row + xo[kc] + i * 4096);
+                else if constexpr (F32) {
+                    const float* b = reinterpret_cast<const float*>(sbase) + (kc * 8 + 4 * lh) * BM + wm0 + i * 32 + li;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fa[slot][i][j] = b[j * BM];
+                } else {
                     const u16* b = reinterpret_cast<const u16*>(sbase + ta[i] + kc * 16 * (BM * 2));
                     s16x4 lo = lds_tr16(b), hi = lds_tr16(b + 4 * BM);
                     fa[slot][i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
@@ -1267,8 +1281,12 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
             }
 #pragma unroll
             for (int i = 0; i < TN; ++i) {
-                if constexpr (P::B_KC) fb[slot][i] = *reinterpret_cast<const bf16x8*>(sbase + b_row + xo[kc] + i * 4096);
-                else {
+                if constexpr (P::B_KC) fb[slot][i] = *reinterpret_cast<const frag_t*>(sbase + b_row + xo[kc] + i * 4096);
+                else if constexpr (F32) {
+                    const float* b = reinterpret_cast<const float*>(sbase + A_BYTES) + (kc * 8 + 4 * lh) * BN + wn0 + i * 32 + li;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fb[slot][i][j] = b[j * BN];
+                } else {
                     const u16* b = reinterpret_cast<const u16*>(sbase + tb[i] + kc * 16 * (BN * 2));
                     s16x4 lo = lds_tr16(b), hi = lds_tr16(b + 4 * BN);
                     fb[slot][i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
@@ -1279,11 +1297,21 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
             if (kc + 1 < 4) frags(kc + 1, (kc + 1) & 1);
+            if constexpr (F32) {
 #pragma unroll
-            for (int a = 0; a < TM; ++a)
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int b = 0; b < TN; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kc & 1][a], fb[kc & 1][b], acc[a][b], 0, 0, 0);
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int b = 0; b < TN; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kc & 1][a][j], fb[kc & 1][b][j], acc[a][b], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kc & 1][a], fb[kc & 1][b], acc[a][b], 0, 0, 0);
+            }
         }
         buf = buf + 1 == STAGES ? 0 : buf + 1;
     }
@@ -2235,7 +2263,7 @@ int launch_wgrad(const Geom& g, const float* x, const float* y, float* dw, hipSt
 // ---- launches of gemm_bf16_v2_kernel (tile codes 7 = 256x128, three-buffer ring; 8 = 256x256, two buffers) ----
 // what the LDS-DMA kernels cover: bf16-stored operands, every K-step inside one filter tap
 bool v2_ok(const Geom& g, int kdim /* channel count along K: Ci (fprop), Co (dgrad) */) {
-    return g.prec == MCG_PREC_BF16_STORE && kdim >= 64 && (kdim & (kdim - 1)) == 0 && g.ksplit == 1;
+    return (g.prec == MCG_PREC_BF16_STORE || g.prec == MCG_PREC_F32) && kdim >= 64 && (kdim & (kdim - 1)) == 0 && g.ksplit == 1;
 }
 
 template <class K> int v2_set_lds(K kernel, size_t lds, std::once_flag& once) {
@@ -2250,9 +2278,10 @@ template <class K> int v2_set_lds(K kernel, size_t lds, std::once_flag& once) {
         hipLaunchKernelGGL(KERNEL, GRID, dim3(NT2), LDS, s, P);                                 \
     } while (0)
 
-template <int BM, int BN, int STAGES>
+// PM as in launch_fprop: 0 = fp32 operands (fp32 MFMA), 2 = bf16-stored operands
+template <int BM, int BN, int STAGES, int PM>
 int launch_fprop_v2(const Geom& g, const float* x, const float* w, const float* bias, float* y, const Epi& e, mcg_conv_epilogue* ep, hipStream_t s) {
-    using Pol = FpropP<BM, BN, 64, 8, true, NT2, true>;
+    using Pol = FpropP<BM, BN, PM ? 64 : 32, PM ? 8 : 4, true, NT2, true>;
     Pol p;
     p.g = g; p.e = e; p.x = x; p.w = w; p.bias = bias; p.y = y;
     p.M = g.N * g.To * g.Ho * g.Wo; p.K = g.taps * g.Ci;
@@ -2267,9 +2296,9 @@ int launch_fprop_v2(const Geom& g, const float* x, const float* w, const float* 
     return MCG_OK;
 }
 
-template <int BM, int BN, int STAGES>
+template <int BM, int BN, int STAGES, int PM>
 int launch_dgrad_v2(const Geom& g, const float* y, const float* w, const float* bias, float* x, int act, int acc, const Epi& e, mcg_conv_epilogue* ep, hipStream_t s) {
-    using Pol = DgradP<BM, BN, 64, 8, true, NT2, true>;
+    using Pol = DgradP<BM, BN, PM ? 64 : 32, PM ? 8 : 4, true, NT2, true>;
     Pol p;
     p.g = g; p.e = e; p.y = y; p.w = w; p.bias = bias; p.x = x; p.act = act; p.accumulate = acc;
     p.M = g.N * g.Ti * g.Ho * g.Wo; p.K = g.kt * 4 * g.Co;
@@ -2285,20 +2314,21 @@ int launch_dgrad_v2(const Geom& g, const float* y, const float* w, const float* 
     return MCG_OK;
 }
 
-template <int BM, int BN, int STAGES>
+template <int BM, int BN, int STAGES, int PM>
 int launch_wgrad_v2(const Geom& g, const float* x, const float* y, float* dw, hipStream_t s) {
-    using Pol = WgradP<BM, BN, 64, 8, NT2, true>;
+    constexpr int BK = PM ? 64 : 32;
+    using Pol = WgradP<BM, BN, BK, PM ? 8 : 4, NT2, true>;
     Pol p;
     p.g = g; p.x = x; p.y = y; p.dw = dw;
     p.Mpix = g.N * g.To * g.Ho * g.Wo; p.Kf = g.taps * g.Ci;
     const int tiles = ((g.Co + BM - 1) / BM) * ((p.Kf + BN - 1) / BN);
-    const int ksteps = (p.Mpix + 63) / 64;
+    const int ksteps = (p.Mpix + BK - 1) / BK;
     // one block per CU at a time (LDS): aim at 2 rounds of blocks; every block ends in BM x BN float atomics, so fewer, longer
     // blocks than the register-staged kernel's
     int splits = (512 + tiles - 1) / tiles;
     if (splits > ksteps / 8) splits = ksteps / 8;        // keep >= 8 K-steps per block
     if (splits < 1) splits = 1;
-    p.chunk = ((ksteps + splits - 1) / splits) * 64;
+    p.chunk = ((ksteps + splits - 1) / splits) * BK;
     splits = (p.Mpix + p.chunk - 1) / p.chunk;
     const dim3 grid((g.Co + BM - 1) / BM, (p.Kf + BN - 1) / BN, splits);
     constexpr size_t lds = (size_t)STAGES * (BM + BN) * 128;
@@ -2417,7 +2447,10 @@ int conv_fprop_impl(const mcg_conv_geom* c, const float* x, const float* w, cons
     if (t == 6) return MCG_ERR_UNSUPPORTED;
     if (t == 7 || t == 8) {                                        // the LDS-DMA kernels (bf16-stored operands, wide layers)
         if (!v2_ok(g, g.Ci) || e.mode & ~(EPI_STATS | EPI_COL | EPI_MASKMUL)) return MCG_ERR_UNSUPPORTED;
-        st = t == 7 ? launch_fprop_v2<256, 128, 3>(g, x, w, bias, y, e, ep, s) : launch_fprop_v2<256, 256, 2>(g, x, w, bias, y, e, ep, s);
+        if (g.prec == MCG_PREC_F32)
+            st = t == 7 ? launch_fprop_v2<256, 128, 3, 0>(g, x, w, bias, y, e, ep, s) : launch_fprop_v2<256, 256, 2, 0>(g, x, w, bias, y, e, ep, s);
+        else
+            st = t == 7 ? launch_fprop_v2<256, 128, 3, 2>(g, x, w, bias, y, e, ep, s) : launch_fprop_v2<256, 256, 2, 2>(g, x, w, bias, y, e, ep, s);
         return finish(st);
     }
     const long long mt = (M + 127) / 128;
@@ -2501,9 +2534,12 @@ int conv_dgrad_impl(const mcg_conv_geom* c, const float* y, const float* w, cons
         const long long frame_ = (long long)g.Ti * g.Hi * g.Wi * g.Ci;
         if (!v2_ok(g, g.Co) || g.Ci < 64 || (g.Ci & (g.Ci - 1)) || (e.mode & ~(EPI_STATS | EPI_COL | EPI_MASKMUL))) return MCG_ERR_UNSUPPORTED;
         (void)frame_;
-        if (g.Ci == 64) st = launch_dgrad_v2<256, 64, 3>(g, y, w, bias, x, act, accumulate, e, ep, s);
-        else if (g.Ci == 128 || t == 7) st = launch_dgrad_v2<256, 128, 3>(g, y, w, bias, x, act, accumulate, e, ep, s);
-        else st = launch_dgrad_v2<256, 256, 2>(g, y, w, bias, x, act, accumulate, e, ep, s);
+#define MCG_DG2(PM_) do {                                                                                              \
+            if (g.Ci == 64) st = launch_dgrad_v2<256, 64, 3, PM_>(g, y, w, bias, x, act, accumulate, e, ep, s);                 \
+            else if (g.Ci == 128 || t == 7) st = launch_dgrad_v2<256, 128, 3, PM_>(g, y, w, bias, x, act, accumulate, e, ep, s); \
+            else st = launch_dgrad_v2<256, 256, 2, PM_>(g, y, w, bias, x, act, accumulate, e, ep, s); } while (0)
+        if (g.prec == MCG_PREC_F32) MCG_DG2(0); else MCG_DG2(2);
+#undef MCG_DG2
         return finish(st);
     }
     if (!t && !e.mode && g.Ci == 4 && g.Co == 64 && (g.Wo & 15) == 0) {      // VALU kernel for the padded 3-channel clip
@@ -2555,9 +2591,14 @@ extern "C" int mcg_conv_wgrad(const mcg_conv_geom* c, const float* x, const floa
     }
     if (t == 6) return MCG_ERR_UNSUPPORTED;
     if (t == 7 || t == 8) {                                      // the LDS-DMA kernels: 128x256 (Co = 128) or 256x256
-        if (g.prec != MCG_PREC_BF16_STORE || g.Co < 128 || (g.Co & 63) || g.Ci < 64 || (g.Ci & (g.Ci - 1))) return MCG_ERR_UNSUPPORTED;
-        if (g.Co == 128 || t == 7) st = launch_wgrad_v2<128, 256, 3>(g, x, y, dw, s);
-        else st = launch_wgrad_v2<256, 256, 2>(g, x, y, dw, s);
+        if ((g.prec != MCG_PREC_BF16_STORE && g.prec != MCG_PREC_F32) || g.Co < 128 || (g.Co & 63) || g.Ci < 64 || (g.Ci & (g.Ci - 1))) return MCG_ERR_UNSUPPORTED;
+        if (g.prec == MCG_PREC_F32) {
+            if (g.Co == 128 || t == 7) st = launch_wgrad_v2<128, 256, 3, 0>(g, x, y, dw, s);
+            else st = launch_wgrad_v2<256, 256, 2, 0>(g, x, y, dw, s);
+        } else {
+            if (g.Co == 128 || t == 7) st = launch_wgrad_v2<128, 256, 3, 2>(g, x, y, dw, s);
+            else st = launch_wgrad_v2<256, 256, 2, 2>(g, x, y, dw, s);
+        }
         return finish(st);
     }
     if (!t) t = (g.Co <= 64 || Kf <= 64) ? 3 : 1;

@@ -243,7 +243,7 @@ def _launch(kind, fn, *args):
 TILE_CANDIDATES = (0, 101, 102, 103, 201, 202, 203)     # (the long tiles 4 = 256x64 and 5 = 64x256 exist, but when they
                                                         # win the isolated timing they lose inside the iteration: measured)
 FPROP_SPLIT_CANDIDATES = (1103, 1203, 1202, 2103, 2203, 2202)     # 2- / 4-way split-K: only when few tiles (see _tuned)
-V2_CANDIDATES = (7, 8)                                  # gemm_bf16_v2_kernel: 256x128 / 256x256 (wgrad 128x256 / 256x256), LDS-DMA ring
+V2_CANDIDATES = (7, 8)                                  # gemm_bf16_v2_kernel (bf16-stored or fp32 operands): 256x128 / 256x256 (wgrad 128x256 / 256x256), LDS-DMA ring
 _autotune = False
 _tile_cache = {}
 
@@ -313,7 +313,10 @@ def _tuned(kind, g, extra, out_side, run_on):
             if kind in ("fprop", "dgrad") and g.Ci > 4 and out_elems <= (1 << (23 if kind == "fprop" else 25)):
                 cands = cands + FPROP_SPLIT_CANDIDATES          # <= 1024 tiles of 64x64: K splits can fill the CUs
             if g.precision == PREC_BF16_STORE and g.Ci >= 64 and g.Co >= 64:
-                cands = cands + V2_CANDIDATES                   # the LDS-DMA kernels (the library refuses what they do not cover)
+                # the LDS-DMA kernels (the library refuses what they do not cover).  fp32 networks can run them too (tile codes
+                # 7 / 8 by request), but measured on the MI355X they do not beat the register-staged fp32 kernels: 110-127
+                # against 128-134 TFLOP/s on the big layers, and one 256-row block per CU quantises badly at batch 32
+                cands = cands + V2_CANDIDATES
             for cand in cands:
                 gg.tile = cand
                 try:

@@ -873,7 +873,8 @@ V2_CASES = [(2, 7, 16, 64, 128, 4),      # M = 512 rows, 3-D
 
 @pytest.mark.parametrize("case", V2_CASES)
 @pytest.mark.parametrize("tile", [7, 8])
-def test_lds_dma_kernels_match_the_oracle(hl, case, tile):
+@pytest.mark.parametrize("prec", ['bf16s', 'f32'])
+def test_lds_dma_kernels_match_the_oracle(hl, case, tile, prec):
     """fprop / dgrad / wgrad of the round-3 bf16 kernels (operands straight from global memory into a swizzled LDS image,
     a ring of tile buffers, 8 waves) on bf16-representable inputs against the float64 oracle at the fp32 tolerances, plain
     and with the statistics epilogue / a bf16 output; the padding taps are the zeros the buffer range check writes."""
@@ -886,19 +887,21 @@ def test_lds_dma_kernels_match_the_oracle(hl, case, tile):
     y_ref = F.conv3d_fwd(x, W, b, (1, 2, 2), (0, 1, 1))
     gx_ref, gW_ref, _ = F.conv3d_bwd(x, W, gy, (1, 2, 2), (0, 1, 1))
     xd, wd, bd, gyd = lay.act_to_dev(dev(x)), lay.conv_w_to_dev(dev(W)), dev(b), lay.act_to_dev(dev(gy))
-    x16, w16, gy16 = xd.to(torch.bfloat16), wd.to(torch.bfloat16), gyd.to(torch.bfloat16)
-    g = hl.make_geom(N, Ti, H, H, Ci, Co, kt, precision='bf16s')
+    s16 = prec == 'bf16s'                                         # fp32 networks: the same kernels on the fp32 MFMA, fp32 tensors
+    odt = torch.bfloat16 if s16 else torch.float32
+    x16, w16, gy16 = (xd.to(torch.bfloat16), wd.to(torch.bfloat16), gyd.to(torch.bfloat16)) if s16 else (xd, wd, gyd)
+    g = hl.make_geom(N, Ti, H, H, Ci, Co, kt, precision=prec)
     g.tile = tile
     M = N * g.To * g.Ho * g.Wo
     yd = torch.full((N, g.To, g.Ho, g.Wo, Co), 3.0, device="cuda")
     hl.conv_fprop(g, x16, w16, bd, yd)
     assert rel_l2(lay.act_from_dev(yd, Co), y_ref) < FWD_TOL
-    # statistics epilogue + bf16 output
-    y16 = torch.empty_like(yd, dtype=torch.bfloat16)
+    # statistics epilogue (+ bf16 output in bf16 networks)
+    y16 = torch.empty_like(yd, dtype=odt)
     part = torch.zeros(hl.epilogue_part_floats(g, 'fprop', 1), device="cuda")
-    ep = hl.epilogue(sums=hl.SUMS_STATS, groups=1, part=part, out_bf16=True)
+    ep = hl.epilogue(sums=hl.SUMS_STATS, groups=1, part=part, out_bf16=s16)
     assert hl.conv_fprop(g, x16, w16, bd, y16, ep=ep, must_fuse=True)
-    assert torch.equal(y16, yd.to(torch.bfloat16))
+    assert torch.equal(y16, yd.to(odt))
     sums = part[:ep.n_slots * ep.slot_stride].view(ep.n_slots, ep.slot_stride).double().sum(0)
     v = y16.double().view(M, Co)
     assert torch.allclose(sums[:Co], v.sum(0), rtol=1e-5, atol=1e-3) and torch.allclose(sums[Co:2 * Co], (v * v).sum(0), rtol=1e-5, atol=1e-3)
@@ -906,11 +909,11 @@ def test_lds_dma_kernels_match_the_oracle(hl, case, tile):
     gxd = torch.full((N, Ti, H, H, Ci), 7.0, device="cuda")
     hl.conv_dgrad(g, gy16, w16, None, gxd)
     assert rel_l2(lay.act_from_dev(gxd, Ci), gx_ref) < BWD_TOL
-    gx16 = torch.empty_like(gxd, dtype=torch.bfloat16)
+    gx16 = torch.empty_like(gxd, dtype=odt)
     part = torch.zeros(hl.epilogue_part_floats(g, 'dgrad', 1), device="cuda")
-    ep = hl.epilogue(sums=hl.SUMS_STATS, groups=1, part=part, out_bf16=True)
+    ep = hl.epilogue(sums=hl.SUMS_STATS, groups=1, part=part, out_bf16=s16)
     assert hl.conv_dgrad(g, gy16, w16, None, gx16, ep=ep, must_fuse=True)
-    assert torch.equal(gx16, gxd.to(torch.bfloat16))
+    assert torch.equal(gx16, gxd.to(odt))
     sums = part[:ep.n_slots * ep.slot_stride].view(ep.n_slots, ep.slot_stride).double().sum(0)
     v = gx16.double().view(-1, Ci)
     assert torch.allclose(sums[:Ci], v.sum(0), rtol=1e-5, atol=1e-3)
@@ -923,8 +926,8 @@ def test_lds_dma_kernels_match_the_oracle(hl, case, tile):
         hl.conv_wgrad(g, x16, gy16, dwd)
         assert rel_l2(lay.conv_w_from_dev(dwd, Ci, 3), gW_ref + 1) < BWD_TOL
     # a narrow layer is refused (the caller keeps such layers on the register-staged kernels)
-    gn = hl.make_geom(2, 5, 16, 16, 16, 32, 4, precision='bf16s')
+    gn = hl.make_geom(2, 5, 16, 16, 16, 32, 4, precision=prec)
     gn.tile = tile
     with pytest.raises(hl.McgError):
-        hl.conv_fprop(gn, torch.zeros((2, 5, 16, 16, 16), device="cuda", dtype=torch.bfloat16),
-                      torch.zeros((32, 4, 4, 4, 16), device="cuda", dtype=torch.bfloat16), None, torch.zeros((2, 2, 8, 8, 32), device="cuda"))
+        hl.conv_fprop(gn, torch.zeros((2, 5, 16, 16, 16), device="cuda", dtype=odt),
+                      torch.zeros((32, 4, 4, 4, 16), device="cuda", dtype=odt), None, torch.zeros((2, 2, 8, 8, 32), device="cuda"))
