@@ -232,6 +232,7 @@ struct FpropP {
     // Only for layers whose K-steps lie inside one filter tap (channel count a power of two and a multiple of BK: v2_ok).
     __device__ __amdgpu_buffer_rsrc_t a_rsrc() const { return xr; }
     __device__ __amdgpu_buffer_rsrc_t b_rsrc() const { return wr; }
+    __device__ void store_probe(float v) const { y[0] = v; }
     template <class F> __device__ void each_a(int k0, F&& f) const {
         const int kr = rotated(k0);
         const int tap = kr >> g.lgCi, ci0 = kr & (g.Ci - 1), sp = tap & 15;
@@ -339,6 +340,7 @@ struct DgradP {
     // LDS-DMA kernels (as FpropP::each_a / each_b; layers with Co a power of two and a multiple of BK)
     __device__ __amdgpu_buffer_rsrc_t a_rsrc() const { return yr; }
     __device__ __amdgpu_buffer_rsrc_t b_rsrc() const { return wr; }
+    __device__ void store_probe(float v) const { x[0] = v; }
     template <class F> __device__ void each_a(int k0, F&& f) const {
         const int kr = rotated(k0);
         const int ts = kr >> g.lgCo, co0 = kr & (g.Co - 1);
@@ -485,6 +487,7 @@ struct WgradP {
     // LDS-DMA kernels (as FpropP::each_a / each_b)
     __device__ __amdgpu_buffer_rsrc_t a_rsrc() const { return yr; }
     __device__ __amdgpu_buffer_rsrc_t b_rsrc() const { return xr; }
+    __device__ void store_probe(float v) const { dw[0] = v; }
     template <class F> __device__ void each_a(int k0, F&& f) const {
 #pragma unroll
         for (int j = 0; j < NA; ++j) f(j, aoff + (u32)((k0 + akrow[j]) * g.Co) * (u32)ESZ, 0u);
@@ -1185,7 +1188,11 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
     }
     const int m0 = bx * BM, n0 = by * BN;
     const int z = bz;
+#ifdef MCG_PROBE_SAMETILE        // (tools/probe_variant.py: every block LOADS tile (0,0): what the memory system costs)
+    p.init(0, 0, tid, z);
+#else
     p.init(m0, n0, tid, z);
+#endif
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -1317,6 +1324,10 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
     }
     wait_vmcnt<0>();                                             // the (dummy) loads still in flight write LDS: drain them before the
     __syncthreads();                                             // epilogue reuses the buffers
+#ifdef MCG_PROBE_NOEPI           // (tools/probe_variant.py: what a block costs without its epilogue; one element keeps the MFMAs alive)
+    if (acc[0][0][0] == 12345.678f) p.store_probe(acc[0][0][1]);
+    return;
+#endif
 
     if constexpr (EPI != 0) {
         fused_epilogue<P, BM, BN, WM, WN, TM, TN, EPI, NT2>(p, acc, m0, n0, bx, bz, tid, reinterpret_cast<float*>(smem));

@@ -281,6 +281,7 @@ class TrainStep:
         adam_update(gen, self.hyper['image_gen'], gs)
         self.iteration += 1
         return {'x_fake': x_fake, 't_fake': t_fake, 't': t, 'gx_fake': gx, 'saved_gen': s_gen, 'saved_fake_i': s_fake_i, 'saved_fake_v': s_fake_v,
+                'saved_i': s_i, 'saved_v': s_v,
                 'y_real_i': y_real_i, 'y_real_v': y_real_v, 'y_fake_i': y_fake_i, 'y_fake_v': y_fake_v}
 
     def losses(self):

@@ -81,15 +81,31 @@ def dis_noise_shapes(ndim, n, in_channels=3, n_filters=64, t=16, size=64):
             (n, nf * 2, t - 6, size // 4, size // 4), (n, nf * 4, t - 9, size // 8, size // 8)]
 
 
-def dis_forward(p, x, noise=None, train=True, update_stats=True):
+def _decide(y, strict, kinks, l, cache):
+    """The branch an activation takes per element: y >= 0 (leaky_relu) or y > 0 (relu, strict).  kinks (tests only):
+    {'eps': e, l: boolean array of another implementation's decisions for layer l} -- inside the band |y| < e, where
+    an fp32 implementation may legitimately land on the other side of the kink, THAT implementation's decision is
+    taken over (and counted); outside the band a disagreement is counted as an error for the caller to assert on."""
+    pos = (y > 0) if strict else (y >= 0)
+    if kinks is not None and l in kinks:
+        other = np.asarray(kinks[l], bool).reshape(y.shape)
+        band = np.abs(y) < kinks['eps']
+        differ = pos != other
+        cache['kink_forced'] = cache.get('kink_forced', 0) + int(np.count_nonzero(differ & band))
+        cache['kink_disagree'] = cache.get('kink_disagree', 0) + int(np.count_nonzero(differ & ~band))
+        pos = np.where(band, other, pos)
+    return pos
+
+
+def dis_forward(p, x, noise=None, train=True, update_stats=True, kinks=None):
     """ImageDiscriminator.__call__ (model/net.py:143-158) / VideoDiscriminator.__call__ (:184-199).
 
     x: (N,C,H,W) or (N,C,T,H,W).  noise: list of 4 pre-scaled addends (or None) for the
-    inputs of dc1..dc4.  Returns (y, cache); y has shape (N,out,1,1[,1]).
+    inputs of dc1..dc4.  Returns (y, cache); y has shape (N,out,1,1[,1]).  kinks: see _decide.
     """
     ndim = x.ndim - 2
     h = x[:, :, None] if ndim == 2 else x
-    cache = {'ndim': ndim, 'a': {}, 'lrelu': {}, 'bn': {}}
+    cache = {'ndim': ndim, 'a': {}, 'lrelu': {}, 'bn': {}, 'pos': {}}
     for l in (1, 2, 3, 4):
         add = None
         if train and noise is not None and noise[l - 1] is not None:
@@ -111,8 +127,10 @@ def dis_forward(p, x, noise=None, train=True, update_stats=True):
                 y = F.bn_test_fwd(y, p['bn%d/gamma' % l], p['bn%d/beta' % l],
                                   p['bn%d/avg_mean' % l], p['bn%d/avg_var' % l])
         cache['min_margin'] = min(cache.get('min_margin', np.inf), float(np.abs(y).min()))
-        h = F.leaky_relu_fwd(y, 0.2)
+        pos = _decide(y, False, kinks, l, cache)
+        h = np.where(pos, y, y * 0.2).astype(y.dtype, copy=False)           # F.leaky_relu_fwd with the decision made explicit
         cache['lrelu'][l] = h
+        cache['pos'][l] = pos
     cache['a'][5] = h
     stride, pad = _dis_geometry(ndim, 5)
     W = p['dc5/W']
@@ -144,7 +162,7 @@ def dis_backward(p, cache, gy, grads=None, need_gx=False):
             g = gx
             break
         # gx is the gradient w.r.t. a_l = lrelu_{l-1} + noise  ->  through lrelu, then BN of layer l-1
-        g = F.leaky_relu_bwd(cache['lrelu'][l - 1], gx, 0.2)
+        g = np.where(cache['pos'][l - 1], gx, gx * 0.2).astype(gx.dtype, copy=False)   # F.leaky_relu_bwd on the forward's decisions
         if l - 1 >= 2:
             g, gg, gbeta = F.bn_train_bwd(cache['bn'][l - 1], p['bn%d/gamma' % (l - 1)], g)
             if grads is not None:
@@ -172,7 +190,7 @@ def gen_draw(rng, batchsize, dim_zc=50, dim_zm=10, dim_zl=0, video_len=16, dtype
     return d
 
 
-def gen_forward(p, draw, video_len=16, train=True, update_stats=True):
+def gen_forward(p, draw, video_len=16, train=True, update_stats=True, kinks=None):
     """ImageGenerator.__call__ (model/net.py:83-117) with make_zm (:61-81).
 
     Returns (x, labels, cache) with x of shape (T, N, C, 64, 64)."""
@@ -193,7 +211,7 @@ def gen_forward(p, draw, video_len=16, train=True, update_stats=True):
     zm = np.stack(hs)                                              # (T,N,dim_zm)
     zct = np.tile(zc, (video_len, 1, 1))                           # :103
     z = np.concatenate((zct, zm), axis=2).reshape(video_len * n, -1, 1, 1)   # :106-107
-    cache = {'gru': steps, 'n': n, 'T': video_len, 'dim_zc': zc.shape[1], 'in': {}, 'bn': {}, 'act': {}}
+    cache = {'gru': steps, 'n': n, 'T': video_len, 'dim_zc': zc.shape[1], 'in': {}, 'bn': {}, 'act': {}, 'pos': {}}
     x = z
     for l in (1, 2, 3, 4, 5):
         s, pd = GEN_DECONV[l]
@@ -209,7 +227,8 @@ def gen_forward(p, draw, video_len=16, train=True, update_stats=True):
                 y = F.bn_test_fwd(y, p['bn%d/gamma' % l], p['bn%d/beta' % l],
                                   p['bn%d/avg_mean' % l], p['bn%d/avg_var' % l])
             cache['min_margin'] = min(cache.get('min_margin', np.inf), float(np.abs(y).min()))
-            x = F.relu_fwd(y)
+            cache['pos'][l] = _decide(y, True, kinks, l, cache)
+            x = np.where(cache['pos'][l], y, 0).astype(y.dtype, copy=False)    # F.relu_fwd with the decision made explicit
         else:
             x = np.tanh(y)
         cache['act'][l] = x
@@ -226,7 +245,7 @@ def gen_backward(p, cache, gx, grads):
         if l == 5:
             g = F.tanh_bwd(cache['act'][5], g)
         else:
-            g = F.relu_bwd(cache['act'][l], g)
+            g = np.where(cache['pos'][l], g, 0).astype(g.dtype, copy=False)    # F.relu_bwd on the forward's decisions
             g, gg, gbeta = F.bn_train_bwd(cache['bn'][l], p['bn%d/gamma' % l], g)
             grads['bn%d/gamma' % l] += gg
             grads['bn%d/beta' % l] += gbeta

@@ -104,7 +104,7 @@ def zero_grads(p):
 # one iteration
 # ----------------------------------------------------------------------------------------
 def update_core(model, gen, dis_i, dis_v, opt_g, opt_i, opt_v, x_real, t_real, rnd,
-                dim_zl=0, video_len=16, keep=False, reduce=None, q1_rows=None):
+                dim_zl=0, video_len=16, keep=False, reduce=None, q1_rows=None, kinks=None):
     """model/updater.py:78-113 with injected randomness.
 
     gen/dis_i/dis_v: parameter dicts (updated IN PLACE, as Chainer does).
@@ -115,6 +115,9 @@ def update_core(model, gen, dis_i, dis_v, opt_g, opt_i, opt_v, x_real, t_real, r
          before its Adam update -- the hook the data-parallel tests use to average gradients over
          ranks (the reference is single-device; SURVEY 8e defines DP as "mean of the per-shard
          gradients, per-shard BatchNorm statistics").
+    kinks (tests only): {'eps': e, 'real_i' | 'real_v' | 'fake_i' | 'fake_v' | 'gen': {layer: boolean array}} -- another
+         implementation's ReLU / LeakyReLU decisions, taken over inside the band |pre-activation| < e (net._decide);
+         the result then carries 'kink_forced' and 'kink_disagree' counts.
     Returns dict(loss_dis_i, loss_dis_v, loss_gen [, intermediates when keep=True]).
 
     Ordering quirks reproduced: all four D forwards and the G forward run first with the OLD
@@ -127,15 +130,18 @@ def update_core(model, gen, dis_i, dis_v, opt_g, opt_i, opt_v, x_real, t_real, r
     if model == 'cgan':
         x_real = concat_label_video(x_real, t_real, dim_zl)
     t = rnd['t']
-    y_real_i, c_real_i = net.dis_forward(dis_i, x_real[:, :, t], rnd['noise_i_real'])
-    y_real_v, c_real_v = net.dis_forward(dis_v, x_real, rnd['noise_v_real'])
 
-    x_fake_tn, t_fake, c_gen = net.gen_forward(gen, rnd['gen'], video_len)
+    def kk(name):
+        return None if kinks is None else dict(kinks[name], eps=kinks['eps'])
+    y_real_i, c_real_i = net.dis_forward(dis_i, x_real[:, :, t], rnd['noise_i_real'], kinks=kk('real_i'))
+    y_real_v, c_real_v = net.dis_forward(dis_v, x_real, rnd['noise_v_real'], kinks=kk('real_v'))
+
+    x_fake_tn, t_fake, c_gen = net.gen_forward(gen, rnd['gen'], video_len, kinks=kk('gen'))
     x_fake = x_fake_tn.transpose(1, 2, 0, 3, 4)                   # (T,N,C,H,W) -> (N,C,T,H,W), :102
     if model == 'cgan':
         x_fake = concat_label_video(x_fake, t_fake, dim_zl)
-    y_fake_i, c_fake_i = net.dis_forward(dis_i, x_fake[:, :, t], rnd['noise_i_fake'])
-    y_fake_v, c_fake_v = net.dis_forward(dis_v, x_fake, rnd['noise_v_fake'])
+    y_fake_i, c_fake_i = net.dis_forward(dis_i, x_fake[:, :, t], rnd['noise_i_fake'], kinks=kk('fake_i'))
+    y_fake_v, c_fake_v = net.dis_forward(dis_v, x_fake, rnd['noise_v_fake'], kinks=kk('fake_v'))
 
     out = {}
     # image_dis_optimizer.update(self.loss_dis, image_dis, ...)   :111
@@ -181,6 +187,9 @@ def update_core(model, gen, dis_i, dis_v, opt_g, opt_i, opt_v, x_real, t_real, r
     # single flipped element moves the gradients behind it by O(1e-2).  Parity tests use this number
     # to know whether a step is well conditioned for a tight comparison.
     out['min_margin'] = min(c['min_margin'] for c in (c_real_i, c_real_v, c_fake_i, c_fake_v, c_gen))
+    if kinks is not None:
+        out['kink_forced'] = sum(c.get('kink_forced', 0) for c in (c_real_i, c_real_v, c_fake_i, c_fake_v, c_gen))
+        out['kink_disagree'] = sum(c.get('kink_disagree', 0) for c in (c_real_i, c_real_v, c_fake_i, c_fake_v, c_gen))
     return out
 
 
