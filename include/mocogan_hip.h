@@ -278,7 +278,9 @@ int mcg_tanh_bwd_to_frames(int N, int T, int64_t frame_elems, const float* g_cli
  * [dim_zm][in], then bias[dim_zm]); in = dim_zl + dim_zm for W_*, dim_zm for U_*.
  * h0 [N][dim_zm]; e [T][N][dim_zm]; labels [N] int32 (ignored when dim_zl == 0); zc [N][dim_zc].
  * z [T*N][dim_zc + dim_zm] = concat(tile(zc), zm)  (model/net.py:102-107).
- * saved: [T][N][4*dim_zm] (r, z, h_bar, h_prev) for the backward pass. */
+ * saved: [T][N][4*dim_zm] (r, z, h_bar, h_prev) for the backward pass.
+ * Sizes: dim_zm <= 16 and dim_zm + dim_zl <= 32 (one thread per hidden unit, the weights of its row in registers;
+ * the reference's default is 10 (+ 6 labels)); larger sizes return MCG_ERR_UNSUPPORTED. */
 int mcg_gru_seq_fwd(int N, int T, int dim_zm, int dim_zl, int dim_zc, const float* params,
                     const float* h0, const float* e, const int32_t* labels, const float* zc,
                     float* z, float* saved, void* stream);

@@ -62,6 +62,8 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(link))
     subprocess.run(link, check=True)
+    import ctypes
+    ctypes.CDLL(lib_path(), mode=os.RTLD_NOW)         # every kernel stub must resolve NOW (the HIP runtime binds them at load on the GPU box)
     with open(_stamp_path(), "w") as f:
         f.write(" ".join(extra))
     return lib_path()

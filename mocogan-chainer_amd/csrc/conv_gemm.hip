@@ -254,6 +254,20 @@ struct FpropP {
         else if (kchunk >= K) y[ro + n] = v + (bias ? bias[n] : 0.f);
         else atomicAdd(y + ro + n, v + (bias && zz == 0 ? bias[n] : 0.f));
     }
+    // four / eight consecutive columns n .. of one row (the row-wise store of gemm_bf16_v2_kernel: never split-K)
+    __device__ void store_vec4(long long ro, int n, f32x4 v, bool add_bias) const {
+        if (ro < 0 || n >= g.Co) return;
+        if (add_bias && bias) v += *reinterpret_cast<const f32x4*>(bias + n);
+        *reinterpret_cast<f32x4*>(y + ro + n) = v;
+    }
+    __device__ void store_vec8_bf16(long long ro, int n, f32x4 lo, f32x4 hi, bool add_bias) const {
+        if (ro < 0 || n >= g.Co) return;
+        if (add_bias && bias) { lo += *reinterpret_cast<const f32x4*>(bias + n); hi += *reinterpret_cast<const f32x4*>(bias + n + 4); }
+        typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+        typedef float f32x8_t __attribute__((ext_vector_type(8)));
+        const f32x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        *reinterpret_cast<bf16x8_t*>(reinterpret_cast<__bf16*>(y) + ro + n) = __builtin_convertvector(v, bf16x8_t);
+    }
     // ---- fused epilogue interface ----
     __device__ int out_cols() const { return g.Co; }
     __device__ float* out_ptr() const { return y; }
@@ -435,6 +449,26 @@ struct DgradP {
         if (e.out16) { reinterpret_cast<__bf16*>(x)[o] = (__bf16)v; return; }      // (never with accumulate: conv_dgrad_impl)
         if (accumulate) v += x[o];
         x[o] = v;
+    }
+    __device__ void store_vec4(long long ro, int n, f32x4 v, bool add_bias) const {
+        if (ro < 0 || n >= g.Ci) return;
+        const long long o = ro + n;
+        if (add_bias && bias) v += *reinterpret_cast<const f32x4*>(bias + n);
+        if (act == MCG_ACT_TANH) { v[0] = tanhf(v[0]); v[1] = tanhf(v[1]); v[2] = tanhf(v[2]); v[3] = tanhf(v[3]); }
+        if (accumulate) v += *reinterpret_cast<const f32x4*>(x + o);
+        *reinterpret_cast<f32x4*>(x + o) = v;
+    }
+    __device__ void store_vec8_bf16(long long ro, int n, f32x4 lo, f32x4 hi, bool add_bias) const {      // (never with accumulate)
+        if (ro < 0 || n >= g.Ci) return;
+        if (add_bias && bias) { lo += *reinterpret_cast<const f32x4*>(bias + n); hi += *reinterpret_cast<const f32x4*>(bias + n + 4); }
+        if (act == MCG_ACT_TANH) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { lo[i] = tanhf(lo[i]); hi[i] = tanhf(hi[i]); }
+        }
+        typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+        typedef float f32x8_t __attribute__((ext_vector_type(8)));
+        const f32x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        *reinterpret_cast<bf16x8_t*>(reinterpret_cast<__bf16*>(x) + ro + n) = __builtin_convertvector(v, bf16x8_t);
     }
     // ---- fused epilogue interface (dense x only: make_epi checks) ----
     __device__ int out_cols() const { return g.Ci; }
@@ -644,7 +678,9 @@ __device__ __forceinline__ float epi_act_mask(float v, int act) {
     return 1.f;
 }
 
-template <class P, int BM, int BN, int WM, int WN, int TM, int TN, int EPI, int NT = NTHREADS>
+// STORE = false (gemm_bf16_v2_kernel): the finished values go back into the accumulators instead of to memory -- the caller
+// stores them row-wise through LDS with 16-byte accesses; the sums and masks are produced as usual.
+template <class P, int BM, int BN, int WM, int WN, int TM, int TN, int EPI, int NT = NTHREADS, bool STORE = true>
 __device__ __forceinline__ void fused_epilogue(const P& p, f32x16 (&acc)[TM][TN], int m0, int n0, int bx, int bz,
                                                int tid, float* red) {
     // EPI selects what this instantiation can do (each class has its own register needs; the plain kernel is EPI = 0):
@@ -707,7 +743,8 @@ __device__ __forceinline__ void fused_epilogue(const P& p, f32x16 (&acc)[TM][TN]
                         const u32 wd = ok ? e.mask_in[ri.pix * e.mask_cb + (col >> 5)] : 0xffffffffu;
                         v = ((wd >> (col & 31)) & 1u) ? v : v * EPI_LRELU_SLOPE;
                     }
-                    if (ok) {
+                    if constexpr (!STORE) acc[a][b][4 * q + i] = v;
+                    else if (ok) {
                         if (e.out16) reinterpret_cast<__bf16*>(out)[o] = (__bf16)v;
                         else out[o] = v;
                     }
@@ -1206,6 +1243,9 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
     const __amdgpu_buffer_rsrc_t ar = p.a_rsrc(), br = p.b_rsrc();
     // slot j of this thread is the 16-byte LDS position tid + NT2 * j of its tile: piece (wave, j) starts at wave KiB + 8 j KiB
     auto issue = [&](int k, int buf) {
+#ifdef MCG_PROBE_NOLOADS         // (tools/probe_variant.py: the LDS-read + MFMA + barrier skeleton alone, on whatever LDS holds)
+        return;
+#endif
         unsigned char* sa = smem + buf * STAGE + wave * 1024;
         unsigned char* sb = sa + A_BYTES;
         const bool live = k < kend;
@@ -1216,6 +1256,31 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
         p.each_b(kk, [&](int j, u32 vo, u32 so) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(br, MCG_LDSP(sb + j * 8192), 16, live ? vo : OOB, so, 0, 0);
         });
+    };
+
+    // In the K loop the loads of a step are not issued in one burst (every LDS-DMA instruction holds its wave's issue for ~60-180
+    // cycles, and the waves of a block run in lockstep behind the barrier: a burst leaves the matrix pipes idle) but spread over the
+    // step's four MFMA groups: offsets first (plain VALU), then PIECES / 4 loads in front of each group.
+    static_assert(PIECES <= 8, "offset arrays");
+    u32 dvo[8], dso[8];             // (a dependent bound, u32 dvo[PIECES], made the HOST pass drop the kernel's stub: hipcc 7.2)
+    auto plan = [&](int k) {
+        const bool live = k < kend;
+        const int kk = live ? k : kend - BK;
+        p.each_a(kk, [&](int j, u32 vo, u32 so) { dvo[j] = live ? vo : OOB; dso[j] = so; });
+        p.each_b(kk, [&](int j, u32 vo, u32 so) { dvo[NA + j] = live ? vo : OOB; dso[NA + j] = so; });
+    };
+    auto issue_part = [&](int buf, int part) {                 // pieces [part * PIECES / 4, (part + 1) * PIECES / 4) of the planned step
+#ifdef MCG_PROBE_NOLOADS
+        return;
+#endif
+        unsigned char* sa = smem + buf * STAGE + wave * 1024;
+        unsigned char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int q = 0; q < PIECES; ++q) {
+            if (q * 4 / PIECES != part) continue;              // (compile-time after unrolling: part is a literal at every call)
+            if (q < NA) __builtin_amdgcn_raw_ptr_buffer_load_lds(ar, MCG_LDSP(sa + q * 8192), 16, dvo[q], dso[q], 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(br, MCG_LDSP(sb + (q - NA) * 8192), 16, dvo[q], dso[q], 0, 0);
+        }
     };
 
     // MFMA operand reads.
@@ -1254,14 +1319,15 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
             k_nx[s] = k;
         }
     }
-    int buf = 0;
+    int buf = 0, nbuf = 0;
     while (k_cur < kend) {
         wait_vmcnt<(STAGES - 2) * PIECES>();                     // this wave's pieces of step k_cur have landed
         __builtin_amdgcn_s_barrier();                            // ... and everyone's; everyone has finished reading the previous step
         {
             const int kl = k_nx[STAGES - 2];                     // the step STAGES - 1 ahead: into the buffer read one step ago
             int nb = buf + STAGES - 1; nb = nb >= STAGES ? nb - STAGES : nb;
-            issue(kl, nb);
+            plan(kl);
+            nbuf = nb;
             const int kn = kl < kend ? p.next_valid(kl + BK) : kend;
             k_cur = k_nx[0];                                     // (the MFMA phase below works on `buf`, not on k_cur)
 #pragma unroll
@@ -1304,6 +1370,8 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
             if (kc + 1 < 4) frags(kc + 1, (kc + 1) & 1);
+            issue_part(nbuf, kc);
+            __builtin_amdgcn_sched_barrier(0);                   // (keeps this quarter of the loads in front of this MFMA group)
             if constexpr (F32) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -1325,22 +1393,56 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
     wait_vmcnt<0>();                                             // the (dummy) loads still in flight write LDS: drain them before the
     __syncthreads();                                             // epilogue reuses the buffers
 #ifdef MCG_PROBE_NOEPI           // (tools/probe_variant.py: what a block costs without its epilogue; one element keeps the MFMAs alive)
-    if (acc[0][0][0] == 12345.678f) p.store_probe(acc[0][0][1]);
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asm volatile("" :: "v"(acc[a][b][r]));     // (every accumulator stays live: no MFMA is removed)
     return;
 #endif
 
-    if constexpr (EPI != 0) {
-        fused_epilogue<P, BM, BN, WM, WN, TM, TN, EPI, NT2>(p, acc, m0, n0, bx, bz, tid, reinterpret_cast<float*>(smem));
-        return;
-    }
     if constexpr (P::HAS_ROW_OFF) {
+        // fprop / dgrad: the output leaves row-wise.  In the accumulators a lane holds ONE column of 16 rows (64 stores of 4 or 2
+        // bytes per thread, every one with its own row decode); staged through a wave-private LDS slab of 32 rows x 64 columns a
+        // lane instead owns 16-byte runs of a row: 4x (fp32) / 8x (bf16) fewer store instructions and one row decode per run.
+        // The element-wise part of a fused epilogue (bias, mask multiply, the sums) runs on the accumulators first.
+        constexpr int RED_BYTES = 16384;                          // fused_epilogue's exchange buffer (WM * BN * 4 floats) stays in front
+        if constexpr (EPI != 0) fused_epilogue<P, BM, BN, WM, WN, TM, TN, EPI, NT2, false>(p, acc, m0, n0, bx, bz, tid, reinterpret_cast<float*>(smem));
+        constexpr int CB = TN >= 2 ? 2 : 1, CW = 32 * CB, SLABW = CW + 4;       // column blocks per slab; slab row stride in floats
+        static_assert(RED_BYTES + 8 * 32 * SLABW * 4 <= STAGES * STAGE, "slabs fit the tile buffers");
+        float* slab = reinterpret_cast<float*>(smem + RED_BYTES) + wave * (32 * SLABW);
+        const bool o16 = p.e.out16 != 0;
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long long ro = p.row_off(m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
+            for (int bp = 0; bp < TN / CB; ++bp) {
+                __builtin_amdgcn_wave_barrier();                  // (the previous slab's reads are issued: the LDS serves a wave in order)
 #pragma unroll
-                for (int b = 0; b < TN; ++b) p.store_at(ro, n0 + wn0 + b * 32 + li, acc[a][b][r]);
+                for (int b2 = 0; b2 < CB; ++b2)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        slab[((r & 3) + 8 * (r >> 2) + 4 * lh) * SLABW + b2 * 32 + li] = acc[a][bp * CB + b2][r];
+                __builtin_amdgcn_wave_barrier();
+                const int mrow = m0 + wm0 + a * 32, ncol = n0 + wn0 + bp * CW;
+                if (o16) {
+                    constexpr int CH = CW / 8;                    // 16-byte bf16 runs (8 columns) per row
+#pragma unroll
+                    for (int it = 0; it < 32 * CH / 64; ++it) {
+                        const int idx = lane + 64 * it, row = idx / CH, ch = idx % CH;
+                        const f32x4 lo = *reinterpret_cast<const f32x4*>(&slab[row * SLABW + ch * 8]);
+                        const f32x4 hi = *reinterpret_cast<const f32x4*>(&slab[row * SLABW + ch * 8 + 4]);
+                        p.store_vec8_bf16(p.row_off(mrow + row), ncol + ch * 8, lo, hi, EPI == 0);
+                    }
+                } else {
+                    constexpr int CH = CW / 4;
+#pragma unroll
+                    for (int it = 0; it < 32 * CH / 64; ++it) {
+                        const int idx = lane + 64 * it, row = idx / CH, ch = idx % CH;
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(&slab[row * SLABW + ch * 4]);
+                        p.store_vec4(p.row_off(mrow + row), ncol + ch * 4, v, EPI == 0);
+                    }
+                }
             }
     } else {
 #pragma unroll

@@ -307,7 +307,7 @@ def make_models(model='normal', num_labels=6, channel=3, dim_zc=50, dim_zm=10, n
     return gen, dis_i, dis_v
 
 
-def pretune_and_share_tiles(exchange, model, precision, batch, rank, num_labels=6):
+def pretune_and_share_tiles(exchange, model, precision, batch, rank, **model_kw):
     """Data parallel: make every rank run the SAME GEMM tile codes.  With autotune on, a geometry the shipped table does
     not hold is timed at its first launch -- per rank, so two ranks may keep different winners (results stay identical:
     Adam consumes the all-reduced gradient; but a rank with a slower choice sets the step time).  Here every rank runs ONE
@@ -316,7 +316,8 @@ def pretune_and_share_tiles(exchange, model, precision, batch, rank, num_labels=
     if exchange is None or exchange.world == 1:
         return
     if hl._autotune:
-        gen, di, dv = make_models(model, num_labels=num_labels, seed=0)
+        model_kw.setdefault('num_labels', 6)
+        gen, di, dv = make_models(model, seed=0, **model_kw)           # (same widths / channels as the run: same geometries)
         ts = TrainStep(model, gen, di, dv, seed=0, rank=rank, precision=precision)
         x = torch.zeros((batch, gen.out_channels, gen.video_len, nets.IMG, nets.IMG), device=gen.device)
         t = torch.zeros(batch, dtype=torch.int32, device=gen.device)

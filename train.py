@@ -35,7 +35,10 @@ def parse_args(argv=None):
         (('--log_tensorboard_interval',), int, 10, 'epochs between TensorBoard sample videos'),
         (('--num_gen_samples',), int, 36, 'videos per TensorBoard sample grid (a square number)'),
         (('--dim_zc',), int, 50, 'size of the content code z_c'),
-        (('--dim_zm',), int, 10, 'size of the motion code z_m (GRU state)'),
+        (('--dim_zm',), int, 10, 'size of the motion code z_m (GRU state).  The fused GRU kernels (mcg_gru_seq_fwd / _bwd: 16 steps in '
+                                 'one launch, weights in registers, one thread per hidden unit) cover dim_zm <= 16 and '
+                                 'dim_zm + num_labels <= 32; larger values are refused with MCG_ERR_UNSUPPORTED (the reference, '
+                                 'model/net.py:38-41, accepts any; its default and every BASELINE config use 10)'),
         (('--n_filters_gen',), int, 64, 'base width; as in the reference it is used for all three networks'),
         (('--n_filters_idis',), int, 64, 'accepted and reported, not used (reference quirk)'),
         (('--n_filters_vdis',), int, 64, 'accepted and reported, not used (reference quirk)'),
@@ -111,6 +114,12 @@ def main(argv=None):
         if num_labels == 0:
             raise ValueError("Called cgan model, but dataset has no label.")
         use_label, c_d, out_d = True, channel, 1 + num_labels
+    if exchange is not None and args.autotune:
+        # every rank runs the same GEMM tile codes: geometries the shipped table does not hold are tuned by one local
+        # iteration on throw-away networks, then rank 0's table replaces everyone's (a straggler would set the step time)
+        from mocogan_chainer_amd.step import pretune_and_share_tiles
+        pretune_and_share_tiles(exchange, args.model, args.mfma, args.batchsize, rank, num_labels=num_labels, channel=channel,
+                                dim_zc=args.dim_zc, dim_zm=args.dim_zm, n_filters=nf, video_length=video_length)
     image_gen = ImageGenerator(args.dim_zc, args.dim_zm, num_labels, channel, nf, video_length)
     image_dis = ImageDiscriminator(c_d, out_d, nf, use_noise, noise_sigma)
     video_dis = VideoDiscriminator(c_d, out_d, nf, use_noise, noise_sigma)
