@@ -1407,16 +1407,42 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
         // bytes per thread, every one with its own row decode); staged through a wave-private LDS slab of 32 rows x 64 columns a
         // lane instead owns 16-byte runs of a row: 4x (fp32) / 8x (bf16) fewer store instructions and one row decode per run.
         // The element-wise part of a fused epilogue (bias, mask multiply, the sums) runs on the accumulators first.
-        constexpr int RED_BYTES = 16384;                          // fused_epilogue's exchange buffer (WM * BN * 4 floats) stays in front
-        if constexpr (EPI != 0) fused_epilogue<P, BM, BN, WM, WN, TM, TN, EPI, NT2, false>(p, acc, m0, n0, bx, bz, tid, reinterpret_cast<float*>(smem));
-        constexpr int CB = TN >= 2 ? 2 : 1, CW = 32 * CB, SLABW = CW + 4;       // column blocks per slab; slab row stride in floats
+        constexpr int RED_BYTES = 16384;                          // exchange buffer of the per-channel sums (WM * BN * 4 floats) stays in front
+        constexpr int CB = TN >= 2 ? 2 : 1, CW = 32 * CB, SLABW = CW + 4, NBP = TN / CB;   // column blocks per slab; slab row stride (floats)
         static_assert(RED_BYTES + 8 * 32 * SLABW * 4 <= STAGES * STAGE, "slabs fit the tile buffers");
         float* slab = reinterpret_cast<float*>(smem + RED_BYTES) + wave * (32 * SLABW);
-        const bool o16 = p.e.out16 != 0;
+        const Epi& e = p.e;
+        const bool o16 = e.out16 != 0;
+        // Fused epilogue (class 1: bias, leaky_relu mask multiply, per-channel sums of the stored values) on the row-wise runs: per run
+        // ONE row decode, vector arithmetic, and a lane keeps the sums of ITS columns -- lanes that own the same columns are
+        // combined with shuffles, the WM waves that share them through LDS, one partial per (block tile, group, channel) as in
+        // fused_epilogue (fixed order, no atomics).
+        const int mode = EPI == 1 ? (e.mode & (EPI_STATS | EPI_COL | EPI_MASKMUL)) : 0;
+        f32x4 s0[NBP][2][2], s1[NBP][2][2];                      // [column pair][group][half of an 8-column run]
+#pragma unroll
+        for (int i = 0; i < NBP; ++i)
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) { s0[i][g][h] = f32x4{0.f, 0.f, 0.f, 0.f}; s1[i][g][h] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        const int C = p.out_cols();
+        auto fused = [&](int bp, int h, const RowInfo& ri, int n, f32x4& v) {     // columns n .. n + 3 of row ri
+            if (p.bias && n < C) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+            if (mode & EPI_MASKMUL) {
+                const u32 wd = (ri.ok && n < C) ? e.mask_in[ri.pix * e.mask_cb + (n >> 5)] : 0xffffffffu;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = ((wd >> ((n + k) & 31)) & 1u) ? v[k] : v[k] * EPI_LRELU_SLOPE;
+            }
+            if ((mode & EPI_SUMS) && ri.ok && n < C) {
+                f32x4 vs = v;
+                if (o16) vs = __builtin_convertvector(__builtin_convertvector(v, bf16x4), f32x4);      // the sums are those of the values as STORED
+                if (ri.grp) { s0[bp][1][h] += vs; s1[bp][1][h] += vs * vs; } else { s0[bp][0][h] += vs; s1[bp][0][h] += vs * vs; }
+            }
+        };
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
-            for (int bp = 0; bp < TN / CB; ++bp) {
+            for (int bp = 0; bp < NBP; ++bp) {
                 __builtin_amdgcn_wave_barrier();                  // (the previous slab's reads are issued: the LDS serves a wave in order)
 #pragma unroll
                 for (int b2 = 0; b2 < CB; ++b2)
@@ -1430,20 +1456,66 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
 #pragma unroll
                     for (int it = 0; it < 32 * CH / 64; ++it) {
                         const int idx = lane + 64 * it, row = idx / CH, ch = idx % CH;
-                        const f32x4 lo = *reinterpret_cast<const f32x4*>(&slab[row * SLABW + ch * 8]);
-                        const f32x4 hi = *reinterpret_cast<const f32x4*>(&slab[row * SLABW + ch * 8 + 4]);
-                        p.store_vec8_bf16(p.row_off(mrow + row), ncol + ch * 8, lo, hi, EPI == 0);
+                        f32x4 lo = *reinterpret_cast<const f32x4*>(&slab[row * SLABW + ch * 8]);
+                        f32x4 hi = *reinterpret_cast<const f32x4*>(&slab[row * SLABW + ch * 8 + 4]);
+                        if constexpr (EPI == 1) {
+                            const RowInfo ri = p.row_info(mrow + row);
+                            fused(bp, 0, ri, ncol + ch * 8, lo);
+                            fused(bp, 1, ri, ncol + ch * 8 + 4, hi);
+                            p.store_vec8_bf16(ri.ok ? ri.base : -1, ncol + ch * 8, lo, hi, false);
+                        } else p.store_vec8_bf16(p.row_off(mrow + row), ncol + ch * 8, lo, hi, true);
                     }
                 } else {
                     constexpr int CH = CW / 4;
 #pragma unroll
                     for (int it = 0; it < 32 * CH / 64; ++it) {
                         const int idx = lane + 64 * it, row = idx / CH, ch = idx % CH;
-                        const f32x4 v = *reinterpret_cast<const f32x4*>(&slab[row * SLABW + ch * 4]);
-                        p.store_vec4(p.row_off(mrow + row), ncol + ch * 4, v, EPI == 0);
+                        f32x4 v = *reinterpret_cast<const f32x4*>(&slab[row * SLABW + ch * 4]);
+                        if constexpr (EPI == 1) {
+                            const RowInfo ri = p.row_info(mrow + row);
+                            fused(bp, 0, ri, ncol + ch * 4, v);
+                            p.store_vec4(ri.ok ? ri.base : -1, ncol + ch * 4, v, false);
+                        } else p.store_vec4(p.row_off(mrow + row), ncol + ch * 4, v, true);
                     }
                 }
             }
+        if constexpr (EPI == 1) {
+            if (mode & EPI_SUMS) {
+                float* red = reinterpret_cast<float*>(smem);
+                // a lane's columns: run ch = lane % CH of every slab row it read; lanes lane % CH apart hold the same columns
+                const int W = o16 ? 8 : 4, CHr = CW / W;
+#pragma unroll
+                for (int bp = 0; bp < NBP; ++bp)
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        if (g >= e.groups) continue;             // (block-uniform)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            if (h == 1 && !o16) continue;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                float a0 = s0[bp][g][h][k], a1 = s1[bp][g][h][k];
+                                for (int off = CHr; off < 64; off <<= 1) { a0 += __shfl_xor(a0, off, 64); a1 += __shfl_xor(a1, off, 64); }
+                                if (lane < CHr) {
+                                    const int c = wn0 + bp * CW + lane * W + h * 4 + k;
+                                    float* d = red + (((wave / WN) * BN + c) * 2 + g) * 2;
+                                    d[0] = a0; d[1] = a1;
+                                }
+                            }
+                        }
+                    }
+                __syncthreads();
+                const int slot = p.slot(bx, bz);
+                for (int idx = tid; idx < BN * 4; idx += NT2) {
+                    const int c = idx >> 2, g = (idx >> 1) & 1, w = idx & 1;
+                    if (g >= e.groups || n0 + c >= C) continue;
+                    float t = 0.f;
+#pragma unroll
+                    for (int wm = 0; wm < WM; ++wm) t += red[((wm * BN + c) * 2 + g) * 2 + w];
+                    e.part[(long long)slot * e.slot_stride + (g * 2 + w) * C + n0 + c] = t;
+                }
+            }
+        }
     } else {
 #pragma unroll
         for (int a = 0; a < TM; ++a)

@@ -32,6 +32,25 @@ __device__ __forceinline__ f32x4 load4(const float* in, long long e, int in16) {
     return *reinterpret_cast<const f32x4*>(in + e);
 }
 
+// eight consecutive elements (element offset e, a multiple of 8): bf16 tensors then move 16 bytes per lane and access -- with
+// groups of four a bf16 load is 8 bytes per lane and the bf16 networks' element-wise passes ran at half the bytes in flight
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x8 load8(const float* in, long long e, int in16) {
+    if (in16) return __builtin_convertvector(*reinterpret_cast<const bf16x8_t*>(reinterpret_cast<const __bf16*>(in) + e), f32x8);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(in + e), b = *reinterpret_cast<const f32x4*>(in + e + 4);
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ void store8(float* out, long long e, f32x8 v, int out16) {
+    if (out16) { *reinterpret_cast<bf16x8_t*>(reinterpret_cast<__bf16*>(out) + e) = __builtin_convertvector(v, bf16x8_t); return; }
+    *reinterpret_cast<f32x4*>(out + e) = __builtin_shufflevector(v, v, 0, 1, 2, 3);
+    *reinterpret_cast<f32x4*>(out + e + 4) = __builtin_shufflevector(v, v, 4, 5, 6, 7);
+}
+__device__ __forceinline__ f32x8 cvec8(const float* p, int c8) {          // per-channel constants of channel group c8
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p + c8 * 8), b = *reinterpret_cast<const f32x4*>(p + c8 * 8 + 4);
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
 __device__ __forceinline__ float act_fwd(float v, int act) {
     if (act == MCG_ACT_RELU) return fmaxf(v, 0.f);
     if (act == MCG_ACT_LRELU) return v >= 0.f ? v : v * LRELU_SLOPE;
@@ -108,6 +127,48 @@ __global__ __launch_bounds__(NT) void col_partial_kernel(long long M, int C, lon
         float* p = part + (long long)blockIdx.x * 2 * C;
         *reinterpret_cast<f32x4*>(p + c4 * 4) = s0;
         *reinterpret_cast<f32x4*>(p + C + c4 * 4) = s1;
+    }
+}
+
+// The BatchNorm-backward sums (MODE 1 above) with eight channels per thread, for bf16 networks (C % 8 == 0): part[block][2][C].
+template <int IO>
+__global__ __launch_bounds__(NT) void col_partial8_kernel(long long M, int C, long long rows_per_block, const float* __restrict__ a,
+                                                          const float* __restrict__ y, const float* __restrict__ stats, int act,
+                                                          float* __restrict__ part) {
+    constexpr int io = IO;
+    __shared__ f32x8 red[2][NT];
+    const int C8 = C >> 3;
+    const int c8 = threadIdx.x % C8, rl = threadIdx.x / C8, RL = NT / C8;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    long long r1 = r0 + rows_per_block; if (r1 > M) r1 = M;
+    f32x8 s0 = {0, 0, 0, 0, 0, 0, 0, 0}, s1 = s0;
+    const f32x8 mean = cvec8(stats, c8), istd = cvec8(stats + C, c8), sc = cvec8(stats + 2 * C, c8), sh = cvec8(stats + 3 * C, c8);
+    auto row = [&](long long r, f32x8& t0, f32x8& t1) {
+        const f32x8 v = load8(a, r * C + c8 * 8, io & MCG_IO_G_BF16), yy = load8(y, r * C + c8 * 8, io & MCG_IO_Y_BF16);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float gb = v[i] * act_mask(fmaf(yy[i], sc[i], sh[i]), act);
+            t0[i] = gb; t1[i] = gb * (yy[i] - mean[i]) * istd[i];
+        }
+    };
+    long long r = r0 + rl;
+    for (; r + 3LL * RL < r1; r += 4LL * RL) {               // four rows in flight per thread, summed in a fixed order
+        f32x8 a0, a1, b0, b1, c0, c1, d0, d1;
+        row(r, a0, a1); row(r + RL, b0, b1); row(r + 2LL * RL, c0, c1); row(r + 3LL * RL, d0, d1);
+        s0 += (a0 + b0) + (c0 + d0); s1 += (a1 + b1) + (c1 + d1);
+    }
+    for (; r < r1; r += RL) {
+        f32x8 a0, a1;
+        row(r, a0, a1);
+        s0 += a0; s1 += a1;
+    }
+    red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
+    __syncthreads();
+    if (threadIdx.x < C8) {
+        for (int k = 1; k < RL; ++k) { s0 += red[0][k * C8 + c8]; s1 += red[1][k * C8 + c8]; }
+        float* p = part + (long long)blockIdx.x * 2 * C;
+        store8(p, c8 * 8, s0, 0);
+        store8(p + C, c8 * 8, s1, 0);
     }
 }
 
@@ -346,6 +407,73 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_apply_kernel(long long n4, int 
         const long long i1 = i0 + stride < n4 ? i0 + stride : i0;
         const f32x4 g0 = load4(g, i0 * 4, io & MCG_IO_G_BF16), y0 = load4(y, i0 * 4, io & MCG_IO_Y_BF16);
         const f32x4 g1 = load4(g, i1 * 4, io & MCG_IO_G_BF16), y1 = load4(y, i1 * 4, io & MCG_IO_Y_BF16);
+        finish(i0, g0, y0);
+        if (i1 != i0) finish(i1, g1, y1);
+    }
+}
+
+// The two kernels above with eight channels per thread (bf16 networks, C % 8 == 0, dense y): the same arithmetic per element, 16-byte
+// accesses of the bf16 tensors.  Noise keeps its element order: counters 2 i and 2 i + 1 of the stream for the eight elements of group i.
+template <int IO>
+__global__ __launch_bounds__(NT) void bn_act_fwd8_kernel(long long n8, int C, const float* __restrict__ y, const float* __restrict__ ss, int act,
+                                                         const float* __restrict__ addend, float sigma, uint64_t seed, uint64_t stream_id,
+                                                         float* __restrict__ out) {
+    constexpr int io = IO;
+    const int C8 = C >> 3;
+    const long long stride = (long long)gridDim.x * NT;
+    const bool fixed_c = stride % C8 == 0;
+    f32x8 sc = {1, 1, 1, 1, 1, 1, 1, 1}, sh = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto consts = [&](int c8) { if (ss) { sc = cvec8(ss, c8); sh = cvec8(ss + C, c8); } };
+    consts((int)(((long long)blockIdx.x * NT + threadIdx.x) % C8));
+    auto finish = [&](long long i, f32x8 v) {
+        if (!fixed_c) consts((int)(i % C8));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = act_fwd(ss ? fmaf(v[k], sc[k], sh[k]) : v[k], act);
+        if (addend) v += load8(addend, i * 8, 0);
+        else if (sigma > 0.f) {
+            const f32x4 z0 = randn4((uint64_t)(2 * i), seed, stream_id), z1 = randn4((uint64_t)(2 * i + 1), seed, stream_id);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[k] = fmaf(sigma, z0[k], v[k]); v[4 + k] = fmaf(sigma, z1[k], v[4 + k]); }
+        }
+        store8(out, i * 8, v, io & MCG_IO_OUT_BF16);
+    };
+    for (long long i0 = (long long)blockIdx.x * NT + threadIdx.x; i0 < n8; i0 += 2 * stride) {
+        const long long i1 = i0 + stride < n8 ? i0 + stride : i0;
+        const f32x8 v0 = load8(y, i0 * 8, io & MCG_IO_Y_BF16), v1 = load8(y, i1 * 8, io & MCG_IO_Y_BF16);
+        finish(i0, v0);
+        if (i1 != i0) finish(i1, v1);
+    }
+}
+
+template <int IO>
+__global__ __launch_bounds__(NT) void bn_act_bwd_apply8_kernel(long long n8, int C, const float* __restrict__ g, const float* __restrict__ y,
+                                                               const float* __restrict__ stats, const float* __restrict__ coef, int act,
+                                                               float* __restrict__ gx) {
+    constexpr int io = IO;
+    const int C8 = C >> 3;
+    const long long stride = (long long)gridDim.x * NT;
+    const bool fixed_c = stride % C8 == 0;
+    f32x8 mean, istd, sc, sh, k0, k1, k2;
+    auto consts = [&](int c8) {
+        mean = cvec8(stats, c8); istd = cvec8(stats + C, c8); sc = cvec8(stats + 2 * C, c8); sh = cvec8(stats + 3 * C, c8);
+        k0 = cvec8(coef, c8); k1 = cvec8(coef + C, c8); k2 = cvec8(coef + 2 * C, c8);
+    };
+    consts((int)(((long long)blockIdx.x * NT + threadIdx.x) % C8));
+    auto finish = [&](long long i, const f32x8& gv, const f32x8& yv) {
+        if (!fixed_c) consts((int)(i % C8));
+        f32x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float gb = gv[k] * act_mask(fmaf(yv[k], sc[k], sh[k]), act);
+            const float xh = (yv[k] - mean[k]) * istd[k];
+            o[k] = k0[k] * (gb - xh * k1[k] - k2[k]);
+        }
+        store8(gx, i * 8, o, io & MCG_IO_OUT_BF16);
+    };
+    for (long long i0 = (long long)blockIdx.x * NT + threadIdx.x; i0 < n8; i0 += 2 * stride) {
+        const long long i1 = i0 + stride < n8 ? i0 + stride : i0;
+        const f32x8 g0 = load8(g, i0 * 8, io & MCG_IO_G_BF16), y0 = load8(y, i0 * 8, io & MCG_IO_Y_BF16);
+        const f32x8 g1 = load8(g, i1 * 8, io & MCG_IO_G_BF16), y1 = load8(y, i1 * 8, io & MCG_IO_Y_BF16);
         finish(i0, g0, y0);
         if (i1 != i0) finish(i1, g1, y1);
     }
@@ -895,14 +1023,33 @@ extern "C" int mcg_bn_act_fwd(int64_t M, int C, int c_valid, const float* y, int
 #define MCG_FWD(IO_) hipLaunchKernelGGL(bn_act_fwd_kernel<IO_>, dim3(ew_grid(n4)), dim3(NT), 0, (hipStream_t)stream, n4, C, c_valid, y, \
                        (long long)y_rows_per_item * (C >> 2), (long long)y_item_stride, scale_shift, act,                             \
                        addend, sigma, seed, stream_id, (float*)out)
+    // bf16 networks (C % 8 == 0, dense y, every channel valid, a channel-group count the block size divides): eight channels per thread
+    const bool wide = out_bf16 != 0 && (C & 7) == 0 && y_rows_per_item == 0 && c_valid == C && NT % (C >> 3 < NT ? C >> 3 : NT) == 0 && (C >> 3) <= NT;
+#define MCG_FWD8(IO_) hipLaunchKernelGGL(bn_act_fwd8_kernel<IO_>, dim3(ew_grid(n4 / 2)), dim3(NT), 0, (hipStream_t)stream, n4 / 2, C, y, scale_shift, act, \
+                       addend, sigma, seed, stream_id, (float*)out)
+    if (wide) { switch (out_bf16) { case 1: MCG_FWD8(1); break; case 2: MCG_FWD8(2); break; default: MCG_FWD8(3); } }
+    else
     switch (out_bf16) { case 0: MCG_FWD(0); break; case 1: MCG_FWD(1); break; case 2: MCG_FWD(2); break; default: MCG_FWD(3); }
+#undef MCG_FWD8
 #undef MCG_FWD
     return launch_status();
 }
 
 // launches of the two BatchNorm-backward kernels for a run-time set of MCG_IO_* flags (compile-time in the kernels)
+static bool wide_c(int io, int C) { return (io & 7) != 0 && (C & 7) == 0 && (C >> 3) <= NT && NT % (C >> 3) == 0; }
+
 static void launch_bwd_partial(int io, int blocks, hipStream_t s, long long M, int C, long long rows_per_block, const float* g_out,
                                const float* y, const float* stats, int act, float* part) {
+    if (stats && (io & (MCG_IO_Y_BF16 | MCG_IO_G_BF16)) && wide_c(io, C)) {
+#define MCG_CP8(IO_) hipLaunchKernelGGL((col_partial8_kernel<IO_>), dim3(blocks), dim3(NT), 0, s, M, C, rows_per_block, g_out, y, stats, act, part)
+        switch (io & (MCG_IO_Y_BF16 | MCG_IO_G_BF16)) {
+            case MCG_IO_Y_BF16: MCG_CP8(MCG_IO_Y_BF16); break;
+            case MCG_IO_G_BF16: MCG_CP8(MCG_IO_G_BF16); break;
+            default: MCG_CP8(MCG_IO_Y_BF16 | MCG_IO_G_BF16);
+        }
+#undef MCG_CP8
+        return;
+    }
 #define MCG_CP(IO_) hipLaunchKernelGGL((col_partial_kernel<1, IO_>), dim3(blocks), dim3(NT), 0, s, M, C, rows_per_block, g_out, y, stats, act, part)
     switch (io & (MCG_IO_Y_BF16 | MCG_IO_G_BF16)) {
         case 0: MCG_CP(0); break;
@@ -914,6 +1061,12 @@ static void launch_bwd_partial(int io, int blocks, hipStream_t s, long long M, i
 }
 static void launch_bwd_apply(int io, hipStream_t s, long long n4, int C, const float* g_out, const float* y, const float* stats,
                              const float* coef, int act, float* gx) {
+    if (stats && wide_c(io, C)) {
+#define MCG_AP8(IO_) case IO_: hipLaunchKernelGGL(bn_act_bwd_apply8_kernel<IO_>, dim3(ew_grid(n4 / 2)), dim3(NT), 0, s, n4 / 2, C, g_out, y, stats, coef, act, gx); break
+        switch (io & 7) { MCG_AP8(1); MCG_AP8(2); MCG_AP8(3); MCG_AP8(4); MCG_AP8(5); MCG_AP8(6); default: MCG_AP8(7); }
+#undef MCG_AP8
+        return;
+    }
 #define MCG_AP(IO_) case IO_: hipLaunchKernelGGL(bn_act_bwd_apply_kernel<IO_>, dim3(ew_grid(n4)), dim3(NT), 0, s, n4, C, g_out, y, stats, coef, act, gx); break
     switch (io & 7) { MCG_AP(0); MCG_AP(1); MCG_AP(2); MCG_AP(3); MCG_AP(4); MCG_AP(5); MCG_AP(6); MCG_AP(7); }
 #undef MCG_AP

@@ -316,7 +316,8 @@ def _tuned(kind, g, extra, out_side, run_on):
                 # the LDS-DMA kernels (the library refuses what they do not cover).  fp32 networks can run them too (tile codes
                 # 7 / 8 by request), but measured on the MI355X they do not beat the register-staged fp32 kernels: 110-127
                 # against 128-134 TFLOP/s on the big layers, and one 256-row block per CU quantises badly at batch 32
-                cands = cands + V2_CANDIDATES
+                if not (kind == "dgrad" and g.Ci == 64):        # (64 output columns per parity class: the 256x64 tile never wins)
+                    cands = cands + V2_CANDIDATES
             for cand in cands:
                 gg.tile = cand
                 try:
@@ -445,17 +446,45 @@ def dgrad_c4_mfma_covers(g):
 
 
 def fprop_tile(g, x, w, bias):
-    """the tile code conv_fprop will use for this geometry (tuned now if it has to be): codes >= 1000 split K, and a split
-    launch can neither carry an epilogue nor write a bf16 output -- callers that want either ask before they allocate"""
+    """the tile code the PLAIN conv_fprop uses for this geometry (tuned now if it has to be): codes >= 1000 split K, and a
+    split launch can neither carry an epilogue nor write a bf16 output -- callers that want either ask before they allocate.
+    (bf16 networks: the fused / bf16-output form is tuned separately and only over the tiles that admit it.)"""
     if _autotune and not g.tile:
-        g = _tuned("fprop", g, (), 'y', lambda gg, out: _fprop(gg, x, w, bias, out))
+        probe = torch.empty(0, device='cuda')
+        g = _tuned("fprop", g, _ep_key(g, None, probe), 'y', _tune_run("fprop", g, x, w, bias, probe, None))
     return _with_override(g).tile
 
 
 def dgrad_tile(g, y, w, bias, act=ACT_NONE, accumulate=False):
     if _autotune and not g.tile:
-        g = _tuned("dgrad", g, (act, int(accumulate)), 'x', lambda gg, out: _dgrad(gg, y, w, bias, out, act, accumulate))
+        probe = torch.empty(0, device='cuda')
+        g = _tuned("dgrad", g, (act, int(accumulate)) + _ep_key(g, None, probe), 'x', _tune_run("dgrad", g, y, w, bias, probe, None, act, accumulate))
     return _with_override(g).tile
+
+
+def _ep_key(g, ep, out):
+    """bf16 networks tune a geometry per launch FORM: a fused epilogue / a bf16 output change which tile wins (the LDS-DMA
+    kernels' row-wise epilogue costs differently from the register-staged kernels'), so the form is part of the key and the
+    candidates are timed in it.  fp32 geometries keep their single key (and the shipped table)."""
+    if g.precision != PREC_BF16_STORE:
+        return ()
+    return ('ep', int(ep.sums) if ep is not None else 0, int(bool(ep.mask_in)) if ep is not None else 0, int(out.dtype == torch.bfloat16))
+
+
+def _tune_run(kind, g, a, w, bias, out_like, ep, act=ACT_NONE, accumulate=False):
+    """the launch a tuning candidate is timed with: the caller's form (epilogue, output type) on scratch output"""
+    def run(gg, scratch):
+        out = scratch.view(torch.bfloat16)[:scratch.numel()] if out_like.dtype == torch.bfloat16 else scratch
+        if g.precision == PREC_BF16_STORE and (ep is not None or out_like.dtype == torch.bfloat16) and gg.tile < 1000:
+            e2 = ep if ep is not None else epilogue(out_bf16=True)
+            (_fprop_ex if kind == "fprop" else _dgrad_ex)(gg, a, w, bias, out, e2, split_ok=True)
+        elif out_like.dtype == torch.bfloat16:
+            raise McgError("a split-K tile cannot write a bf16 output")
+        elif kind == "fprop":
+            _fprop(gg, a, w, bias, scratch)
+        else:
+            _dgrad(gg, a, w, bias, scratch, act, accumulate)
+    return run
 
 
 def conv_fprop(g, x, w, bias, y, ep=None, must_fuse=False):
@@ -463,7 +492,7 @@ def conv_fprop(g, x, w, bias, y, ep=None, must_fuse=False):
     geometry splits K (partial tiles cannot carry an epilogue) and must_fuse is off: then the PLAIN convolution ran and
     the caller does the epilogue's work with the stand-alone passes.  must_fuse drops the split instead."""
     if _autotune and not g.tile:
-        g = _tuned("fprop", g, (), 'y', lambda gg, out: _fprop(gg, x, w, bias, out))   # x, w are only read
+        g = _tuned("fprop", g, _ep_key(g, ep, y), 'y', _tune_run("fprop", g, x, w, bias, y, ep))   # x, w are only read
     if ep is not None and (must_fuse or _with_override(g).tile < 1000):
         _launch("fprop", _fprop_ex, g, x, w, bias, y, ep)
         return True
@@ -474,7 +503,7 @@ def conv_fprop(g, x, w, bias, y, ep=None, must_fuse=False):
 def conv_dgrad(g, y, w, bias, x, act=ACT_NONE, accumulate=False, ep=None, must_fuse=False):
     """ep / return value as in conv_fprop (ep needs act == ACT_NONE, no accumulate, dense x)."""
     if _autotune and not g.tile:
-        g = _tuned("dgrad", g, (act, int(accumulate)), 'x', lambda gg, out: _dgrad(gg, y, w, bias, out, act, accumulate))
+        g = _tuned("dgrad", g, (act, int(accumulate)) + _ep_key(g, ep, x), 'x', _tune_run("dgrad", g, y, w, bias, x, ep, act, accumulate))
     if ep is not None and (must_fuse or _with_override(g).tile < 1000):
         assert act == ACT_NONE and not accumulate
         _launch("dgrad", _dgrad_ex, g, y, w, bias, x, ep)

@@ -162,9 +162,12 @@ def test_shipped_tile_table_is_well_formed():
     assert len(table) >= 40
     seen = set()
     for key, code in table:
-        assert key[0] in ('fprop', 'dgrad', 'wgrad') and all(isinstance(v, int) for v in key[1:]), key
-        assert len(key) == (12 if key[0] == 'dgrad' else 10), key          # dgrad keys carry (act, accumulate)
         kind, N, Ti, Hi, Wi, Ci, Co, kt, perm, prec = key[:10]
+        base = 12 if kind == 'dgrad' else 10                                # dgrad keys carry (act, accumulate)
+        # bf16-stored geometries (fprop / dgrad) are tuned per launch form: + ('ep', sums, mask, bf16 output)  (hiplib._ep_key)
+        form = 4 if (prec == 2 and kind != 'wgrad') else 0
+        assert kind in ('fprop', 'dgrad', 'wgrad') and len(key) == base + form, key
+        assert all(isinstance(v, int) for v in key[1:base]) and (not form or (key[base] == 'ep' and all(isinstance(v, int) for v in key[base + 1:]))), key
         assert Hi == Wi and Hi in (8, 16, 32, 64) and kt in (1, 4) and prec in (0, 1, 2) and Ci % 4 == 0 and N > 0
         assert isinstance(code, int) and 0 <= code % 100 <= 8 and (code // 100) % 10 <= 2 and code // 1000 <= 2, code
         assert code % 100 < 7 or (prec == 2 and code in (7, 8)), (key, code)      # the LDS-DMA kernels: bf16-stored operands, no K split

@@ -798,10 +798,14 @@ def test_elementwise_passes_write_bf16_operands(hl):
             for out_dt in (torch.float32, torch.bfloat16):
                 o, dg, db = torch.empty((M, C), device="cuda", dtype=out_dt), torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
                 hl.bn_act_bwd(M, C, g_in, y_in, stats, gamma, hl.ACT_LRELU, o, dg, db, ws)
-                assert torch.equal(o, ref_b.to(out_dt)) and torch.equal(dg, dg_ref) and torch.equal(db, db_ref), (g_in.dtype, y_in.dtype, out_dt)
+                # (with a bf16 input the per-channel sums come from the eight-channels-per-thread kernel: the same addends in
+                #  another tree, so dgamma / dbeta -- and through them every output -- agree to fp32 rounding, not bit for bit)
+                assert torch.allclose(dg, dg_ref, rtol=2e-5, atol=1e-5) and torch.allclose(db, db_ref, rtol=2e-5, atol=1e-5)
+                tol = 2.0 ** -7 if out_dt == torch.bfloat16 else 2e-5
+                assert bool(((o.float() - ref_b).abs() <= tol * ref_b.abs() + 1e-5).all()), (g_in.dtype, y_in.dtype, out_dt)
     gi = gb.clone()
     hl.bn_act_bwd(M, C, gi, yb, stats, gamma, hl.ACT_LRELU, gi, None, None, ws)            # in place, bf16 -> bf16
-    assert torch.equal(gi, ref_b.to(torch.bfloat16))
+    assert bool(((gi.float() - ref_b).abs() <= 2.0 ** -7 * ref_b.abs() + 1e-5).all())
     alias = torch.empty(0, dtype=torch.bfloat16, device="cuda").set_(gr_.untyped_storage(), 0, (M, C), (C, 1))
     assert alias.data_ptr() == gr_.data_ptr()
     with pytest.raises(hl.McgError):                                                       # in place across element types: refused
@@ -917,6 +921,18 @@ def test_lds_dma_kernels_match_the_oracle(hl, case, tile, prec):
     sums = part[:ep.n_slots * ep.slot_stride].view(ep.n_slots, ep.slot_stride).double().sum(0)
     v = gx16.double().view(-1, Ci)
     assert torch.allclose(sums[:Ci], v.sum(0), rtol=1e-5, atol=1e-3)
+    # leaky_relu mask multiply + column sums (what dc2's input gradient carries for D's first layer)
+    bits = torch.randint(0, 2, (N * Ti * H * H, Ci), device="cuda", dtype=torch.int64)
+    words = (bits.view(-1, Ci // 32, 32) << torch.arange(32, device="cuda")).sum(-1)
+    words = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32).contiguous()
+    part = torch.zeros(hl.epilogue_part_floats(g, 'dgrad', 1), device="cuda")
+    ep = hl.epilogue(mask_in=words, sums=hl.SUMS_COL, groups=1, part=part)
+    gxm = torch.empty_like(gxd)
+    assert hl.conv_dgrad(g, gy16, w16, None, gxm, ep=ep, must_fuse=True)
+    want = gxd.view(-1, Ci) * torch.where(bits.bool(), 1.0, 0.2).float()
+    assert torch.equal(gxm.view(-1, Ci), want)
+    sums = part[:ep.n_slots * ep.slot_stride].view(ep.n_slots, ep.slot_stride).double().sum(0)
+    assert torch.allclose(sums[:Ci], want.double().sum(0), rtol=1e-5, atol=1e-3)
     gxa = torch.full((N, Ti, H, H, Ci), 0.5, device="cuda")
     hl.conv_dgrad(g, gy16, w16, dev(rng.randn(Ci) * 0), gxa, accumulate=True)          # accumulate onto x (the frame-t add of the step)
     assert rel_l2(lay.act_from_dev(gxa, Ci), gx_ref + 0.5) < BWD_TOL
