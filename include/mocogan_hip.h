@@ -78,6 +78,9 @@ typedef struct mcg_conv_geom {
                                 * powers of two >= 64; refused elsewhere): 512 threads, operands straight from global
                                 * memory into a ring of LDS tile buffers, block tile 256x128 / 256x256 (fprop, dgrad;
                                 * dgrad with Ci = 64: 256x64) or 128x256 / 256x256 (wgrad); no K split, no +100 / +200;
+                                * 9 = mcg_conv_dgrad only, bf16-stored operands, Ci = 64 and a 16 x 16 small side (D's dc2,
+                                * G's dc4): one block per frame computes all four output-parity classes from a y patch held
+                                * in LDS (each y pixel is loaded once per temporal tap instead of once per class and tap);
                                 * +100 / +200 also fixes the K-step depth to 32 / 64; +1000 / +2000
                                 * makes mcg_conv_fprop / mcg_conv_dgrad split the K range over 2 / 4 blocks per tile
                                 * (partial tiles are added atomically onto a cleared output; for long-K layers with

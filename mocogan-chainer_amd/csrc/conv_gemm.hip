@@ -1155,6 +1155,136 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(P p) {
     }
 }
 
+constexpr int NT2 = 512;
+
+// ------------------------------------------------------------------------------------------
+// Row-wise epilogue of the LDS-DMA kernels (fprop / dgrad policies): accumulators -> wave-private LDS slab -> 16-byte runs of
+// output rows, with the class-1 fused epilogue (bias, leaky_relu mask multiply, per-channel sums) on the runs.
+// WM x WN: the block's wave grid; a wave owns TM x TN accumulator tiles whose first row / column in the block tile are wm0 / wn0.
+// smem: the block's LDS (free by now), lds_bytes of it.
+// ------------------------------------------------------------------------------------------
+template <class P, int BN, int WM, int WN, int TM, int TN, int EPI, int LDS_BYTES>
+__device__ __forceinline__ void rowwise_epilogue(const P& p, f32x16 (&acc)[TM][TN], unsigned char* smem, int m0, int n0, int wm0, int wn0,
+                                                 int bx, int bz, int tid) {
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    {
+        // fprop / dgrad: the output leaves row-wise.  In the accumulators a lane holds ONE column of 16 rows (64 stores of 4 or 2
+        // bytes per thread, every one with its own row decode); staged through a wave-private LDS slab of 32 rows x 64 columns a
+        // lane instead owns 16-byte runs of a row: 4x (fp32) / 8x (bf16) fewer store instructions and one row decode per run.
+        // The element-wise part of a fused epilogue (bias, mask multiply, the sums) runs on the accumulators first.
+        constexpr int RED_BYTES = 16384;                          // exchange buffer of the per-channel sums (WM * BN * 4 floats) stays in front
+        constexpr int CB = TN >= 2 ? 2 : 1, CW = 32 * CB, SLABW = CW + 4, NBP = TN / CB;   // column blocks per slab; slab row stride (floats)
+        static_assert(RED_BYTES + 8 * 32 * SLABW * 4 <= LDS_BYTES, "slabs fit the tile buffers");
+        float* slab = reinterpret_cast<float*>(smem + RED_BYTES) + wave * (32 * SLABW);
+        const Epi& e = p.e;
+        const bool o16 = e.out16 != 0;
+        // Fused epilogue (class 1: bias, leaky_relu mask multiply, per-channel sums of the stored values) on the row-wise runs: per run
+        // ONE row decode, vector arithmetic, and a lane keeps the sums of ITS columns -- lanes that own the same columns are
+        // combined with shuffles, the WM waves that share them through LDS, one partial per (block tile, group, channel) as in
+        // fused_epilogue (fixed order, no atomics).
+        const int mode = EPI == 1 ? (e.mode & (EPI_STATS | EPI_COL | EPI_MASKMUL)) : 0;
+        f32x4 s0[NBP][2][2], s1[NBP][2][2];                      // [column pair][group][half of an 8-column run]
+#pragma unroll
+        for (int i = 0; i < NBP; ++i)
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) { s0[i][g][h] = f32x4{0.f, 0.f, 0.f, 0.f}; s1[i][g][h] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        const int C = p.out_cols();
+        auto fused = [&](int bp, int h, const RowInfo& ri, int n, f32x4& v) {     // columns n .. n + 3 of row ri
+            if (p.bias && n < C) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+            if (mode & EPI_MASKMUL) {
+                const u32 wd = (ri.ok && n < C) ? e.mask_in[ri.pix * e.mask_cb + (n >> 5)] : 0xffffffffu;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = ((wd >> ((n + k) & 31)) & 1u) ? v[k] : v[k] * EPI_LRELU_SLOPE;
+            }
+            if ((mode & EPI_SUMS) && ri.ok && n < C) {
+                f32x4 vs = v;
+                if (o16) vs = __builtin_convertvector(__builtin_convertvector(v, bf16x4), f32x4);      // the sums are those of the values as STORED
+                if (ri.grp) { s0[bp][1][h] += vs; s1[bp][1][h] += vs * vs; } else { s0[bp][0][h] += vs; s1[bp][0][h] += vs * vs; }
+            }
+        };
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int bp = 0; bp < NBP; ++bp) {
+                __builtin_amdgcn_wave_barrier();                  // (the previous slab's reads are issued: the LDS serves a wave in order)
+#pragma unroll
+                for (int b2 = 0; b2 < CB; ++b2)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        slab[((r & 3) + 8 * (r >> 2) + 4 * lh) * SLABW + b2 * 32 + li] = acc[a][bp * CB + b2][r];
+                __builtin_amdgcn_wave_barrier();
+                const int mrow = m0 + wm0 + a * 32, ncol = n0 + wn0 + bp * CW;
+                if (o16) {
+                    constexpr int CH = CW / 8;                    // 16-byte bf16 runs (8 columns) per row
+#pragma unroll
+                    for (int it = 0; it < 32 * CH / 64; ++it) {
+                        const int idx = lane + 64 * it, row = idx / CH, ch = idx % CH;
+                        f32x4 lo = *reinterpret_cast<const f32x4*>(&slab[row * SLABW + ch * 8]);
+                        f32x4 hi = *reinterpret_cast<const f32x4*>(&slab[row * SLABW + ch * 8 + 4]);
+                        if constexpr (EPI == 1) {
+                            const RowInfo ri = p.row_info(mrow + row);
+                            fused(bp, 0, ri, ncol + ch * 8, lo);
+                            fused(bp, 1, ri, ncol + ch * 8 + 4, hi);
+                            p.store_vec8_bf16(ri.ok ? ri.base : -1, ncol + ch * 8, lo, hi, false);
+                        } else p.store_vec8_bf16(p.row_off(mrow + row), ncol + ch * 8, lo, hi, true);
+                    }
+                } else {
+                    constexpr int CH = CW / 4;
+#pragma unroll
+                    for (int it = 0; it < 32 * CH / 64; ++it) {
+                        const int idx = lane + 64 * it, row = idx / CH, ch = idx % CH;
+                        f32x4 v = *reinterpret_cast<const f32x4*>(&slab[row * SLABW + ch * 4]);
+                        if constexpr (EPI == 1) {
+                            const RowInfo ri = p.row_info(mrow + row);
+                            fused(bp, 0, ri, ncol + ch * 4, v);
+                            p.store_vec4(ri.ok ? ri.base : -1, ncol + ch * 4, v, false);
+                        } else p.store_vec4(p.row_off(mrow + row), ncol + ch * 4, v, true);
+                    }
+                }
+            }
+        if constexpr (EPI == 1) {
+            if (mode & EPI_SUMS) {
+                float* red = reinterpret_cast<float*>(smem);
+                // a lane's columns: run ch = lane % CH of every slab row it read; lanes lane % CH apart hold the same columns
+                const int W = o16 ? 8 : 4, CHr = CW / W;
+#pragma unroll
+                for (int bp = 0; bp < NBP; ++bp)
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        if (g >= e.groups) continue;             // (block-uniform)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            if (h == 1 && !o16) continue;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                float a0 = s0[bp][g][h][k], a1 = s1[bp][g][h][k];
+                                for (int off = CHr; off < 64; off <<= 1) { a0 += __shfl_xor(a0, off, 64); a1 += __shfl_xor(a1, off, 64); }
+                                if (lane < CHr) {
+                                    const int c = wn0 + bp * CW + lane * W + h * 4 + k;
+                                    float* d = red + (((wave / WN) * BN + c) * 2 + g) * 2;
+                                    d[0] = a0; d[1] = a1;
+                                }
+                            }
+                        }
+                    }
+                __syncthreads();
+                const int slot = p.slot(bx, bz);
+                for (int idx = tid; idx < BN * 4; idx += NT2) {
+                    const int c = idx >> 2, g = (idx >> 1) & 1, w = idx & 1;
+                    if (g >= e.groups || n0 + c >= C) continue;
+                    float t = 0.f;
+#pragma unroll
+                    for (int wm = 0; wm < WM; ++wm) t += red[((wm * BN + c) * 2 + g) * 2 + w];
+                    e.part[(long long)slot * e.slot_stride + (g * 2 + w) * C + n0 + c] = t;
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // The bf16 GEMM core built for the bf16 matrix pipe (round 3): gemm_bf16_v2_kernel.
 //
@@ -1178,7 +1308,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(P p) {
 // channel counts powers of two >= 64 (v2_ok); everything else stays on gemm_bf16_kernel.
 // ------------------------------------------------------------------------------------------
 #define MCG_LDSP(p) ((__attribute__((address_space(3))) void*)(p))
-constexpr int NT2 = 512;
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
@@ -1403,119 +1532,7 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
 #endif
 
     if constexpr (P::HAS_ROW_OFF) {
-        // fprop / dgrad: the output leaves row-wise.  In the accumulators a lane holds ONE column of 16 rows (64 stores of 4 or 2
-        // bytes per thread, every one with its own row decode); staged through a wave-private LDS slab of 32 rows x 64 columns a
-        // lane instead owns 16-byte runs of a row: 4x (fp32) / 8x (bf16) fewer store instructions and one row decode per run.
-        // The element-wise part of a fused epilogue (bias, mask multiply, the sums) runs on the accumulators first.
-        constexpr int RED_BYTES = 16384;                          // exchange buffer of the per-channel sums (WM * BN * 4 floats) stays in front
-        constexpr int CB = TN >= 2 ? 2 : 1, CW = 32 * CB, SLABW = CW + 4, NBP = TN / CB;   // column blocks per slab; slab row stride (floats)
-        static_assert(RED_BYTES + 8 * 32 * SLABW * 4 <= STAGES * STAGE, "slabs fit the tile buffers");
-        float* slab = reinterpret_cast<float*>(smem + RED_BYTES) + wave * (32 * SLABW);
-        const Epi& e = p.e;
-        const bool o16 = e.out16 != 0;
-        // Fused epilogue (class 1: bias, leaky_relu mask multiply, per-channel sums of the stored values) on the row-wise runs: per run
-        // ONE row decode, vector arithmetic, and a lane keeps the sums of ITS columns -- lanes that own the same columns are
-        // combined with shuffles, the WM waves that share them through LDS, one partial per (block tile, group, channel) as in
-        // fused_epilogue (fixed order, no atomics).
-        const int mode = EPI == 1 ? (e.mode & (EPI_STATS | EPI_COL | EPI_MASKMUL)) : 0;
-        f32x4 s0[NBP][2][2], s1[NBP][2][2];                      // [column pair][group][half of an 8-column run]
-#pragma unroll
-        for (int i = 0; i < NBP; ++i)
-#pragma unroll
-            for (int g = 0; g < 2; ++g)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) { s0[i][g][h] = f32x4{0.f, 0.f, 0.f, 0.f}; s1[i][g][h] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        const int C = p.out_cols();
-        auto fused = [&](int bp, int h, const RowInfo& ri, int n, f32x4& v) {     // columns n .. n + 3 of row ri
-            if (p.bias && n < C) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-            if (mode & EPI_MASKMUL) {
-                const u32 wd = (ri.ok && n < C) ? e.mask_in[ri.pix * e.mask_cb + (n >> 5)] : 0xffffffffu;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = ((wd >> ((n + k) & 31)) & 1u) ? v[k] : v[k] * EPI_LRELU_SLOPE;
-            }
-            if ((mode & EPI_SUMS) && ri.ok && n < C) {
-                f32x4 vs = v;
-                if (o16) vs = __builtin_convertvector(__builtin_convertvector(v, bf16x4), f32x4);      // the sums are those of the values as STORED
-                if (ri.grp) { s0[bp][1][h] += vs; s1[bp][1][h] += vs * vs; } else { s0[bp][0][h] += vs; s1[bp][0][h] += vs * vs; }
-            }
-        };
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int bp = 0; bp < NBP; ++bp) {
-                __builtin_amdgcn_wave_barrier();                  // (the previous slab's reads are issued: the LDS serves a wave in order)
-#pragma unroll
-                for (int b2 = 0; b2 < CB; ++b2)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        slab[((r & 3) + 8 * (r >> 2) + 4 * lh) * SLABW + b2 * 32 + li] = acc[a][bp * CB + b2][r];
-                __builtin_amdgcn_wave_barrier();
-                const int mrow = m0 + wm0 + a * 32, ncol = n0 + wn0 + bp * CW;
-                if (o16) {
-                    constexpr int CH = CW / 8;                    // 16-byte bf16 runs (8 columns) per row
-#pragma unroll
-                    for (int it = 0; it < 32 * CH / 64; ++it) {
-                        const int idx = lane + 64 * it, row = idx / CH, ch = idx % CH;
-                        f32x4 lo = *reinterpret_cast<const f32x4*>(&slab[row * SLABW + ch * 8]);
-                        f32x4 hi = *reinterpret_cast<const f32x4*>(&slab[row * SLABW + ch * 8 + 4]);
-                        if constexpr (EPI == 1) {
-                            const RowInfo ri = p.row_info(mrow + row);
-                            fused(bp, 0, ri, ncol + ch * 8, lo);
-                            fused(bp, 1, ri, ncol + ch * 8 + 4, hi);
-                            p.store_vec8_bf16(ri.ok ? ri.base : -1, ncol + ch * 8, lo, hi, false);
-                        } else p.store_vec8_bf16(p.row_off(mrow + row), ncol + ch * 8, lo, hi, true);
-                    }
-                } else {
-                    constexpr int CH = CW / 4;
-#pragma unroll
-                    for (int it = 0; it < 32 * CH / 64; ++it) {
-                        const int idx = lane + 64 * it, row = idx / CH, ch = idx % CH;
-                        f32x4 v = *reinterpret_cast<const f32x4*>(&slab[row * SLABW + ch * 4]);
-                        if constexpr (EPI == 1) {
-                            const RowInfo ri = p.row_info(mrow + row);
-                            fused(bp, 0, ri, ncol + ch * 4, v);
-                            p.store_vec4(ri.ok ? ri.base : -1, ncol + ch * 4, v, false);
-                        } else p.store_vec4(p.row_off(mrow + row), ncol + ch * 4, v, true);
-                    }
-                }
-            }
-        if constexpr (EPI == 1) {
-            if (mode & EPI_SUMS) {
-                float* red = reinterpret_cast<float*>(smem);
-                // a lane's columns: run ch = lane % CH of every slab row it read; lanes lane % CH apart hold the same columns
-                const int W = o16 ? 8 : 4, CHr = CW / W;
-#pragma unroll
-                for (int bp = 0; bp < NBP; ++bp)
-#pragma unroll
-                    for (int g = 0; g < 2; ++g) {
-                        if (g >= e.groups) continue;             // (block-uniform)
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            if (h == 1 && !o16) continue;
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                float a0 = s0[bp][g][h][k], a1 = s1[bp][g][h][k];
-                                for (int off = CHr; off < 64; off <<= 1) { a0 += __shfl_xor(a0, off, 64); a1 += __shfl_xor(a1, off, 64); }
-                                if (lane < CHr) {
-                                    const int c = wn0 + bp * CW + lane * W + h * 4 + k;
-                                    float* d = red + (((wave / WN) * BN + c) * 2 + g) * 2;
-                                    d[0] = a0; d[1] = a1;
-                                }
-                            }
-                        }
-                    }
-                __syncthreads();
-                const int slot = p.slot(bx, bz);
-                for (int idx = tid; idx < BN * 4; idx += NT2) {
-                    const int c = idx >> 2, g = (idx >> 1) & 1, w = idx & 1;
-                    if (g >= e.groups || n0 + c >= C) continue;
-                    float t = 0.f;
-#pragma unroll
-                    for (int wm = 0; wm < WM; ++wm) t += red[((wm * BN + c) * 2 + g) * 2 + w];
-                    e.part[(long long)slot * e.slot_stride + (g * 2 + w) * C + n0 + c] = t;
-                }
-            }
-        }
+        rowwise_epilogue<P, BN, WM, WN, TM, TN, EPI, STAGES * STAGE>(p, acc, smem, m0, n0, wm0, wn0, bx, bz, tid);
     } else {
 #pragma unroll
         for (int a = 0; a < TM; ++a)
@@ -1525,6 +1542,144 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
                 for (int r = 0; r < 16; ++r)
                     p.store(m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, n0 + wn0 + b * 32 + li, acc[a][b][r]);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Input gradient of the Ci = 64 layers with a 16 x 16 small side (D's dc2: model/net.py:149,190 backwards; G's dc4 forward,
+// model/net.py:113), bf16-stored operands: the FOUR PARITY CLASSES of one frame in one block, the y patch in LDS (tile code 9).
+//
+// As parity-class GEMMs this layer has 64 output columns per class: a 256 x 64 tile moves 40 KB per 2.1 MFLOP, and the four
+// classes of a tile read the same y pixels at 9 distinct shifts (16 class x tap pairs).  Here a block owns ONE frame (t, n) of x
+// = 256 half-resolution positions x 4 classes x 64 channels (512 accumulator registers per lane pair: 8 waves x 32 rows).
+// Per temporal tap a and 64-channel chunk of y ("super-step") it loads the 18 x 18-pixel patch of y frame t - a ONCE (41 KB; the
+// halo and frames outside the tensor are the zeros of the buffer range check) and streams the 16 filter slices w[co chunk][tap][ci]
+// (8 KB each) through a two-stage ring, four slices = one class per stage; the MFMA A operand of class (ph, pw), sub-tap (bh, bw)
+// is the patch read at the shifted pixel (h2 + ph - bh, w2 + pw - bw): no tile of y is loaded twice.  169 KB instead of 640 KB of
+// LDS fills per 33.5 MFLOP.  Patch rows are 128 B (64 bf16), chunk c of patch pixel pr at position c ^ ((pr >> 1) & 7) (the
+// K-contiguous image of gemm_bf16_v2_kernel, indexed by patch pixel); filter slices keep global orientation [co][ci] and are read
+// with ds_read_b64_tr_b16 (sw_cols).  One barrier per stage (32 MFMAs per wave); epilogue per class through rowwise_epilogue.
+// ------------------------------------------------------------------------------------------
+using DgPatchPol = DgradP<256, 64, 64, 8, true, NT2, true>;
+
+template <int EPI>
+__global__ __launch_bounds__(NT2) void dgrad_patch_kernel(DgPatchPol p) {
+    constexpr int PATCH = 48 * 1024, BSTG = 4 * 8192, LDS_TOTAL = 2 * PATCH + 2 * BSTG;
+    constexpr int PW = 18, NPIX = PW * PW;                                  // patch: 18 x 18 pixels of 128 bytes
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const patch = smem;
+    unsigned char* const bst = smem + 2 * PATCH;
+    const Geom& g = p.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    int bx;
+    {   // XCD-aware frame order: every XCD walks a contiguous range of frames
+        const int nwg = gridDim.x, L = blockIdx.x;
+        const int xcd = L & 7, q = nwg >> 3, r = nwg & 7;
+        bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+    }
+    const int t = div_N(g, bx), n = bx - t * g.N;                          // rows are time-major: m = ((t N + n) Ho + h2) Wo + w2
+    const int m0 = bx * 256;
+    p.zsplit = 0; p.kchunk = p.K;
+    const __amdgpu_buffer_rsrc_t yr = make_srd(p.y, g.y_bytes), wr = make_srd(p.w, g.w_bytes);
+
+    // temporal taps whose y frame t - a exists, co chunks: the super-steps
+    const int a_lo = t - (g.To - 1) > 0 ? t - (g.To - 1) : 0, a_hi = t < g.kt - 1 ? t : g.kt - 1;
+    const int CC = g.Co >> 6, S = (a_hi - a_lo + 1) * CC;
+
+    // ---- patch loads: piece (wave, j) = 16-byte chunks (wave + 8 j) * 64 + lane of the patch image
+    u32 poff[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int Lc = (wave + 8 * j) * 64 + lane, pr = Lc >> 3, cp = Lc & 7;
+        const int py = (pr * 57) >> 10, px = pr - py * PW;                  // pr / 18 for pr < 324
+        const int h = py - 1, w_ = px - 1;
+        const bool ok = pr < NPIX && (unsigned)h < (unsigned)g.Ho && (unsigned)w_ < (unsigned)g.Wo;
+        poff[j] = ok ? (u32)(((h * g.Wo + w_) * g.Co + ((cp ^ ((pr >> 1) & 7)) << 3)) * 2) : OOB;
+    }
+    auto issue_patch = [&](int s, int j0, int j1) {
+        const int a = a_lo + s / CC, cc = s - (s / CC) * CC;
+        const u32 so = (u32)(((n * g.To + (t - a)) * g.Ho * g.Wo * g.Co + cc * 64) * 2);
+        unsigned char* dst = patch + (s & 1) * PATCH + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            if (j >= j0 && j < j1) __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, MCG_LDSP(dst + j * 8192), 16, poff[j], so, 0, 0);
+    };
+    // ---- filter slices: thread = (co row tid / 8, chunk tid % 8) of a [64 co][64 ci] slice
+    const u32 boff = (u32)(((tid >> 3) * g.taps * g.Ci + (((tid & 7) ^ sw_cols(tid >> 3, 8)) << 3)) * 2);
+    auto issue_b = [&](int G) {                                  // stage G = 4 s + q: the four slices (bh, bw) of class q = (ph, pw)
+        const int s = G >> 2, q = G & 3, ph = q >> 1, pw = q & 1;
+        const int a = a_lo + s / CC, cc = s - (s / CC) * CC;
+        unsigned char* dst = bst + (G & 1) * BSTG + wave * 1024;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int bh = tt >> 1, bw = tt & 1;
+            const int tap = a * 16 + ((1 - ph) + 2 * bh) * 4 + (1 - pw) + 2 * bw;
+            const u32 so = (u32)(((cc * 64 * g.taps + tap) * g.Ci) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, MCG_LDSP(dst + tt * 8192), 16, boff, so, 0, 0);
+        }
+    };
+
+    f32x16 acc[4][1][2];                                          // [class][1][two 32-column blocks]: this wave's 32 rows
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][0][b][r] = 0.f;
+
+    // MFMA operand addresses
+    const int r_ = wave * 32 + li;
+    const int prow = ((r_ >> 4) + 1) * PW + (r_ & 15) + 1;         // this lane's row of the frame as a patch pixel (shift 0)
+    const int tq = (lane & 15) >> 2, tcl = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);
+    u32 tb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) tb[i] = (u32)((8 * lh + tq) * 128 + (((4 * i + tcl) ^ sw_cols(tq, 8)) << 4) + (lane & 1) * 8);
+
+    issue_patch(0, 0, 6);
+    issue_b(0);
+    const int total = 4 * S;
+    for (int s = 0; s < S; ++s) {
+        const unsigned char* pb = patch + (s & 1) * PATCH;
+        static_for<0, 4>([&](auto q_) {
+            constexpr int q = decltype(q_)::value, ph = q >> 1, pw = q & 1;
+            const int G = 4 * s + q;
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (G + 1 < total) issue_b(G + 1);
+            if (q < 3 && s + 1 < S) issue_patch(s + 1, 2 * q, 2 * q + 2);
+            const unsigned char* bb = bst + (G & 1) * BSTG;
+            int prow_v = prow;
+            asm volatile("" : "+v"(prow_v));                     // (keeps the 64 operand addresses of a super-step from being hoisted out
+                                                                 //  of the loop: they would spill -- the accumulators take 128 registers)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const int bh = tt >> 1, bw = tt & 1;
+                const int pr = prow_v + (ph - bh) * PW + (pw - bw);
+                const unsigned char* ap = pb + pr * 128;
+                const int sw = (pr >> 1) & 7;
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc) {
+                    const bf16x8 fa = *reinterpret_cast<const bf16x8*>(ap + (((2 * kc + lh) ^ sw) << 4));
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const u16* b = reinterpret_cast<const u16*>(bb + tt * 8192 + tb[i] + kc * 16 * 128);
+                        s16x4 lo = lds_tr16(b), hi = lds_tr16(b + 4 * 64);
+                        const bf16x8 fb = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                        acc[q][0][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[q][0][i], 0, 0, 0);
+                    }
+                }
+            }
+        });
+    }
+    wait_vmcnt<0>();
+    // ---- epilogue: class by class through the row-wise store (the policy decodes rows for its parity class)
+    static_for<0, 4>([&](auto q_) {
+        constexpr int q = decltype(q_)::value;
+        __syncthreads();
+        p.ph = q >> 1; p.pw = q & 1;
+        rowwise_epilogue<DgPatchPol, 64, 8, 1, 1, 2, EPI, LDS_TOTAL>(p, acc[q], smem, m0, 0, wave * 32, 0, bx, q, tid);
+    });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2322,7 +2477,7 @@ int make_geom(const mcg_conv_geom* c, Geom& g) {
     if (c->ci_valid < 0 || c->ci_valid > c->Ci) return MCG_ERR_BAD_ARG;
     g.cv = c->ci_valid ? c->ci_valid : c->Ci;
     if (g.prec != MCG_PREC_F32 && g.prec != MCG_PREC_BF16 && g.prec != MCG_PREC_BF16_STORE) return MCG_ERR_BAD_ARG;
-    if (c->tile < 0 || c->tile % 100 > 8 || (c->tile / 100) % 10 > 2 || c->tile / 1000 > 2) return MCG_ERR_BAD_ARG;
+    if (c->tile < 0 || c->tile % 100 > 9 || (c->tile / 100) % 10 > 2 || c->tile / 1000 > 2) return MCG_ERR_BAD_ARG;
     g.tile = c->tile % 100; g.bk = ((c->tile / 100) % 10) * 32; g.ksplit = 1 << (c->tile / 1000);
     g.lgHo = ilog2_exact(g.Ho); g.lgWo = ilog2_exact(g.Wo);
     g.lgCi = ilog2_exact(g.Ci); g.lgCo = ilog2_exact(g.Co);
@@ -2521,6 +2676,26 @@ int launch_wgrad_v2(const Geom& g, const float* x, const float* y, float* dw, hi
     return MCG_OK;
 }
 
+bool dgrad_patch_ok(const Geom& g) {
+    return g.prec == MCG_PREC_BF16_STORE && g.Ci == 64 && g.Ho == 16 && g.Wo == 16 && g.Co >= 64 && (g.Co & 63) == 0 && g.ksplit == 1 &&
+           (long long)g.N * g.Ti < (1ll << 24);
+}
+
+int launch_dgrad_patch(const Geom& g, const float* y, const float* w, const float* bias, float* x, int act, int acc, const Epi& e, mcg_conv_epilogue* ep, hipStream_t s) {
+    DgPatchPol p;
+    p.g = g; p.e = e; p.y = y; p.w = w; p.bias = bias; p.x = x; p.act = act; p.accumulate = acc;
+    p.M = g.N * g.Ti * g.Ho * g.Wo; p.K = g.kt * 4 * g.Co;
+    p.gxm = p.M / 256; p.gyn = 1; p.tiles8 = (p.gxm + 7) / 8;
+    if (ep) { ep->n_slots = 4 * p.gxm; ep->slot_stride = e.slot_stride; }
+    const int cls = e.mode ? epi_class(e.mode) : 0;
+    if (cls > 1) return MCG_ERR_UNSUPPORTED;
+    const dim3 grid(g.N * g.Ti);
+    constexpr size_t lds = 2 * 48 * 1024 + 2 * 4 * 8192;
+    if (cls == 0) MCG_V2_LAUNCH((dgrad_patch_kernel<0>), grid, lds, p);
+    else MCG_V2_LAUNCH((dgrad_patch_kernel<1>), grid, lds, p);
+    return MCG_OK;
+}
+
 // tile / K-depth / MFMA-type dispatch of the launch_* templates
 #ifdef MCG_FAST_BUILD       // compile-time experiments: one tile, one K depth, fp32 only
 #define MCG_TILES(fn, t, BK, BF, ...) do { st = fn<128, 128, 32, 0>(__VA_ARGS__); } while (0)
@@ -2629,7 +2804,7 @@ int conv_fprop_impl(const mcg_conv_geom* c, const float* x, const float* w, cons
         }
         return finish(st);
     }
-    if (t == 6) return MCG_ERR_UNSUPPORTED;
+    if (t == 6 || t == 9) return MCG_ERR_UNSUPPORTED;
     if (t == 7 || t == 8) {                                        // the LDS-DMA kernels (bf16-stored operands, wide layers)
         if (!v2_ok(g, g.Ci) || e.mode & ~(EPI_STATS | EPI_COL | EPI_MASKMUL)) return MCG_ERR_UNSUPPORTED;
         if (g.prec == MCG_PREC_F32)
@@ -2715,6 +2890,10 @@ int conv_dgrad_impl(const mcg_conv_geom* c, const float* y, const float* w, cons
         return finish(st);
     }
     if (t == 6) t = 0;                                           // elsewhere the first-layer code means "the kernel written for it"
+    if (t == 9) {                                                // patch-stationary, four parity classes per block (Ci = 64, 16 x 16)
+        if (!dgrad_patch_ok(g) || (e.mode & ~(EPI_STATS | EPI_COL | EPI_MASKMUL))) return MCG_ERR_UNSUPPORTED;
+        return finish(launch_dgrad_patch(g, y, w, bias, x, act, accumulate, e, ep, s));
+    }
     if (t == 7 || t == 8) {                                      // the LDS-DMA kernels (bf16-stored operands, wide layers)
         const long long frame_ = (long long)g.Ti * g.Hi * g.Wi * g.Ci;
         if (!v2_ok(g, g.Co) || g.Ci < 64 || (g.Ci & (g.Ci - 1)) || (e.mode & ~(EPI_STATS | EPI_COL | EPI_MASKMUL))) return MCG_ERR_UNSUPPORTED;
@@ -2774,7 +2953,7 @@ extern "C" int mcg_conv_wgrad(const mcg_conv_geom* c, const float* x, const floa
         else st = g.Wo == 32 ? launch_wgrad_c4<1, 32>(g, x, y, dw, s) : launch_wgrad_c4<1, 16>(g, x, y, dw, s);
         return finish(st);
     }
-    if (t == 6) return MCG_ERR_UNSUPPORTED;
+    if (t == 6 || t == 9) return MCG_ERR_UNSUPPORTED;
     if (t == 7 || t == 8) {                                      // the LDS-DMA kernels: 128x256 (Co = 128) or 256x256
         if ((g.prec != MCG_PREC_BF16_STORE && g.prec != MCG_PREC_F32) || g.Co < 128 || (g.Co & 63) || g.Ci < 64 || (g.Ci & (g.Ci - 1))) return MCG_ERR_UNSUPPORTED;
         if (g.prec == MCG_PREC_F32) {

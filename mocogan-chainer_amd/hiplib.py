@@ -318,6 +318,8 @@ def _tuned(kind, g, extra, out_side, run_on):
                 # against 128-134 TFLOP/s on the big layers, and one 256-row block per CU quantises badly at batch 32
                 if not (kind == "dgrad" and g.Ci == 64):        # (64 output columns per parity class: the 256x64 tile never wins)
                     cands = cands + V2_CANDIDATES
+                elif g.Ho == 16 and g.Wo == 16:
+                    cands = cands + (9,)                        # ... the patch-stationary kernel, four classes per block, is made for it
             for cand in cands:
                 gg.tile = cand
                 try:

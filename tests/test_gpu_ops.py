@@ -947,3 +947,70 @@ def test_lds_dma_kernels_match_the_oracle(hl, case, tile, prec):
     with pytest.raises(hl.McgError):
         hl.conv_fprop(gn, torch.zeros((2, 5, 16, 16, 16), device="cuda", dtype=odt),
                       torch.zeros((32, 4, 4, 4, 16), device="cuda", dtype=odt), None, torch.zeros((2, 2, 8, 8, 32), device="cuda"))
+
+
+PATCH_CASES = [(2, 7, 32, 64, 128, 4),       # D_V dc2's geometry (two clips)
+               (3, 1, 32, 64, 128, 1),       # D_I dc2 / G dc4 (2-D)
+               (1, 5, 32, 64, 64, 4),        # one y channel chunk
+               (2, 4, 32, 64, 256, 4)]       # To = 1: every frame of x sees exactly one temporal tap
+
+
+@pytest.mark.parametrize("case", PATCH_CASES)
+def test_patch_stationary_input_gradient(hl, case):
+    """mcg_conv_dgrad tile code 9 (bf16-stored operands, Ci = 64, 16 x 16 small side): the four parity classes of a frame in one
+    block, y patch in LDS.  Against the float64 oracle and, bit for bit, against the per-class kernels' result for the same K
+    order is not required -- the sum order differs -- so: oracle at the fp32 tolerance; every launch form the step uses."""
+    N, Ti, H, Ci, Co, kt = case
+    rng = np.random.RandomState(9100 + PATCH_CASES.index(case))
+    lay = L()
+    x, W = _bf16_round(rng.uniform(-1, 1, (N, Ci, Ti, H, H))), _bf16_round(rng.randn(Co, Ci, kt, 4, 4) * 0.1)
+    gy = _bf16_round(rng.randn(N, Co, Ti - kt + 1, H // 2, H // 2))
+    gx_ref, _, _ = F.conv3d_bwd(x, W, gy, (1, 2, 2), (0, 1, 1))
+    wd, gyd = lay.conv_w_to_dev(dev(W)), lay.act_to_dev(dev(gy))
+    w16, gy16 = wd.to(torch.bfloat16), gyd.to(torch.bfloat16)
+    g = hl.make_geom(N, Ti, H, H, Ci, Co, kt, precision='bf16s')
+    g.tile = 9
+    gxd = torch.full((N, Ti, H, H, Ci), 7.0, device="cuda")
+    hl.conv_dgrad(g, gy16, w16, None, gxd)
+    assert rel_l2(lay.act_from_dev(gxd, Ci), gx_ref) < BWD_TOL
+    # bias + statistics + bf16 output (the generator's dc4 forward: model/net.py:113)
+    b = dev(rng.randn(Ci))
+    gx16 = torch.empty_like(gxd, dtype=torch.bfloat16)
+    part = torch.zeros(hl.epilogue_part_floats(g, 'dgrad', 1), device="cuda")
+    ep = hl.epilogue(sums=hl.SUMS_STATS, groups=1, part=part, out_bf16=True)
+    assert hl.conv_dgrad(g, gy16, w16, b, gx16, ep=ep, must_fuse=True)
+    assert torch.equal(gx16, (gxd + b).to(torch.bfloat16))
+    sums = part[:ep.n_slots * ep.slot_stride].view(ep.n_slots, ep.slot_stride).double().sum(0)
+    v = gx16.double().view(-1, Ci)
+    assert torch.allclose(sums[:Ci], v.sum(0), rtol=1e-5, atol=1e-3) and torch.allclose(sums[Ci:2 * Ci], (v * v).sum(0), rtol=1e-5, atol=1e-3)
+    # two groups (real | fake halves of the batch) when N is even
+    if N % 2 == 0:
+        part2 = torch.zeros(hl.epilogue_part_floats(g, 'dgrad', 2), device="cuda")
+        ep2 = hl.epilogue(sums=hl.SUMS_STATS, groups=2, part=part2)
+        gx2 = torch.empty_like(gxd)
+        assert hl.conv_dgrad(g, gy16, w16, None, gx2, ep=ep2, must_fuse=True) and torch.equal(gx2, gxd)
+        s2 = part2[:ep2.n_slots * ep2.slot_stride].view(ep2.n_slots, ep2.slot_stride).double().sum(0)
+        half = gxd.double().view(N, -1, Ci)
+        assert torch.allclose(s2[:Ci], half[:N // 2].reshape(-1, Ci).sum(0), rtol=1e-5, atol=1e-3)
+        assert torch.allclose(s2[2 * Ci:3 * Ci], half[N // 2:].reshape(-1, Ci).sum(0), rtol=1e-5, atol=1e-3)
+    # leaky_relu mask multiply + column sums (D's dc2 input gradient)
+    bits = torch.randint(0, 2, (N * Ti * H * H, Ci), device="cuda", dtype=torch.int64)
+    words = (bits.view(-1, Ci // 32, 32) << torch.arange(32, device="cuda")).sum(-1)
+    words = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32).contiguous()
+    part = torch.zeros(hl.epilogue_part_floats(g, 'dgrad', 1), device="cuda")
+    ep = hl.epilogue(mask_in=words, sums=hl.SUMS_COL, groups=1, part=part)
+    gxm = torch.empty_like(gxd)
+    assert hl.conv_dgrad(g, gy16, w16, None, gxm, ep=ep, must_fuse=True)
+    want = gxd.view(-1, Ci) * torch.where(bits.bool(), 1.0, 0.2).float()
+    assert torch.equal(gxm.view(-1, Ci), want)
+    sums = part[:ep.n_slots * ep.slot_stride].view(ep.n_slots, ep.slot_stride).double().sum(0)
+    assert torch.allclose(sums[:Ci], want.double().sum(0), rtol=1e-5, atol=1e-3)
+    # accumulate onto x; a geometry it does not cover is refused
+    gxa = torch.full((N, Ti, H, H, Ci), 0.5, device="cuda")
+    hl.conv_dgrad(g, gy16, w16, None, gxa, accumulate=True)
+    assert rel_l2(lay.act_from_dev(gxa, Ci), gx_ref + 0.5) < BWD_TOL
+    gn = hl.make_geom(2, 5, 16, 16, 64, 128, 4, precision='bf16s')
+    gn.tile = 9
+    with pytest.raises(hl.McgError):
+        hl.conv_dgrad(gn, torch.zeros((2, 2, 8, 8, 128), device="cuda", dtype=torch.bfloat16),
+                      torch.zeros((128, 4, 4, 4, 64), device="cuda", dtype=torch.bfloat16), None, torch.zeros((2, 5, 16, 16, 64), device="cuda"))

@@ -60,7 +60,7 @@ def is_pre_bn_bias(key, net_kind):
     return (l in (2, 3, 4)) if net_kind == 'dis' else (l in (1, 2, 3, 4))
 
 
-def check_params(got, ref, net_kind, tol, what, grads=None):
+def check_params(got, ref, net_kind, tol, what, grads=None, gtol=0.0):
     """grads: the oracle's gradients of this iteration.  Adam with beta1 = 5e-5 (train.py:99-101) moves every parameter by
     ~alpha * sign(g): an element whose gradient (incl. the weight-decay term) is within the device / oracle difference of
     zero -- |g| below 1e-3 of the tensor's rms -- may step the other way on either side, an O(alpha) difference of one
@@ -76,8 +76,10 @@ def check_params(got, ref, net_kind, tol, what, grads=None):
         g, r = np.asarray(got[k], F64), np.asarray(v, F64)
         if grads is not None and k in grads:
             gt = grads[k] + 1e-5 * r                                   # WeightDecay(1e-5) hook (train.py:96)
-            keep = np.abs(gt) > 1e-3 * np.sqrt(np.mean(gt * gt))
-            assert keep.mean() > 0.5, (what, k, keep.mean())     # (GRU columns of labels that do not occur have g = wd * p only)
+            # (gtol: the bound the gradients themselves are held to -- 0.15 on an iteration with an activation on its kink:
+            #  an element smaller than twice that share of the tensor's rms may change sign within the bound)
+            keep = np.abs(gt) > max(1e-3, 2 * gtol) * np.sqrt(np.mean(gt * gt))
+            assert keep.mean() > 0.3, (what, k, keep.mean())     # (GRU columns of labels that do not occur have g = wd * p only)
             g, r = g[keep], r[keep]
         err = np.linalg.norm(g - r) / max(np.linalg.norm(r), 1e-30)
         assert err < tol, (what, k, err)
@@ -283,9 +285,9 @@ def _run_steps(pkg, model, dim_zl, nf, n, steps, seed, min_tight_steps=1, overla
                     # compare -- held to an absolute bound where the relative one is below that floor)
                     tiny = refg[k].size <= 8 and np.abs(np.asarray(got[k], F64) - refg[k]).max() < 5e-7
                     assert tiny or rel_l2(got[k], refg[k]) < gtol, (s, name, k, ref['min_margin'])
-        check_params(DI.export_reference_params(), di, 'dis', ptol, 'D_I step %d' % s, ref['grads_dis_i'])
-        check_params(DV.export_reference_params(), dv, 'dis', ptol, 'D_V step %d' % s, ref['grads_dis_v'])
-        check_params(G.export_reference_params(), gen, 'gen', ptol, 'G step %d' % s, ref['grads_gen'])
+        check_params(DI.export_reference_params(), di, 'dis', ptol, 'D_I step %d' % s, ref['grads_dis_i'], 0.0 if tight else gtol)
+        check_params(DV.export_reference_params(), dv, 'dis', ptol, 'D_V step %d' % s, ref['grads_dis_v'], 0.0 if tight else gtol)
+        check_params(G.export_reference_params(), gen, 'gen', ptol, 'G step %d' % s, ref['grads_gen'], 0.0 if tight else gtol)
         assert G.t == DI.t == DV.t == s + 1
     assert tight_steps >= min_tight_steps, "seed no longer yields a well-conditioned iteration"
 
