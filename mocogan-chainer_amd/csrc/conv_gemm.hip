@@ -1005,6 +1005,24 @@ __device__ __forceinline__ s16x4 lds_tr16(const u16* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p);
 }
 
+// The transposing read as inline asm, for kernels with LDS-DMA loads in flight.  hipcc (ROCm 7.2) cannot tell the builtin's LDS
+// access from the pending LDS-DMA writes and puts s_waitcnt vmcnt(0) in front of every group of them -- each k chunk then waits
+// for the loads issued a moment ago and the ring of tile buffers buys nothing (found in the .s of the first LDS-DMA dgrad /
+// wgrad kernels).  An asm load is invisible to that pass; its completion is OUR business: tr16_wait<N> before the first use,
+// N = asm reads issued after the ones needed (LDS returns in order; the compiler's own counted waits stay valid: extra younger
+// operations only make them wait longer).  EXEC must be all ones (the gather crosses lanes).
+__device__ __forceinline__ u32 lds_addr(const void* p) { return (u32)(size_t)(const __attribute__((address_space(3))) void*)p; }
+template <int OFF0, int OFF1>
+__device__ __forceinline__ void tr16_issue(s16x4& lo, s16x4& hi, u32 addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4" : "=&v"(lo), "=&v"(hi) : "v"(addr), "n"(OFF0), "n"(OFF1));
+}
+template <int N>
+__device__ __forceinline__ bf16x8 tr16_wait(s16x4& lo, s16x4& hi) {
+    static_assert(N >= 0 && N < 16, "lgkmcnt is a 4-bit field");
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(lo), "+v"(hi) : "n"(N));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
 template <class P, int BM, int BN, int BK, int EPI = 0>
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(P p) {
     // wave grid: 2 x 2, except for the long tiles 256x64 (4 x 1) and 64x256 (1 x 4) whose waves keep 64x64 outputs
@@ -1163,9 +1181,13 @@ constexpr int NT2 = 512;
 // WM x WN: the block's wave grid; a wave owns TM x TN accumulator tiles whose first row / column in the block tile are wm0 / wn0.
 // smem: the block's LDS (free by now), lds_bytes of it.
 // ------------------------------------------------------------------------------------------
-template <class P, int BN, int WM, int WN, int TM, int TN, int EPI, int LDS_BYTES>
+// GROUPS > 1 (dgrad_patch_kernel): the block's waves form GROUPS independent sets of WM * WN waves, each with its own policy object /
+// output (a parity class); `tid` is then the thread's index inside its set and `grp` the set -- the sets run this function side
+// by side (the barrier inside is the block's).
+template <class P, int BN, int WM, int WN, int TM, int TN, int EPI, int LDS_BYTES, int GROUPS = 1>
 __device__ __forceinline__ void rowwise_epilogue(const P& p, f32x16 (&acc)[TM][TN], unsigned char* smem, int m0, int n0, int wm0, int wn0,
-                                                 int bx, int bz, int tid) {
+                                                 int bx, int bz, int tid, int grp = 0) {
+    constexpr int NTG = WM * WN * 64;                             // threads of one set
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
     {
@@ -1175,8 +1197,8 @@ __device__ __forceinline__ void rowwise_epilogue(const P& p, f32x16 (&acc)[TM][T
         // The element-wise part of a fused epilogue (bias, mask multiply, the sums) runs on the accumulators first.
         constexpr int RED_BYTES = 16384;                          // exchange buffer of the per-channel sums (WM * BN * 4 floats) stays in front
         constexpr int CB = TN >= 2 ? 2 : 1, CW = 32 * CB, SLABW = CW + 4, NBP = TN / CB;   // column blocks per slab; slab row stride (floats)
-        static_assert(RED_BYTES + 8 * 32 * SLABW * 4 <= LDS_BYTES, "slabs fit the tile buffers");
-        float* slab = reinterpret_cast<float*>(smem + RED_BYTES) + wave * (32 * SLABW);
+        static_assert(GROUPS * WM * BN * 16 <= RED_BYTES && RED_BYTES + 8 * 32 * SLABW * 4 <= LDS_BYTES, "exchange buffer and slabs fit the tile buffers");
+        float* slab = reinterpret_cast<float*>(smem + RED_BYTES) + (grp * WM * WN + wave) * (32 * SLABW);
         const Epi& e = p.e;
         const bool o16 = e.out16 != 0;
         // Fused epilogue (class 1: bias, leaky_relu mask multiply, per-channel sums of the stored values) on the row-wise runs: per run
@@ -1247,7 +1269,7 @@ __device__ __forceinline__ void rowwise_epilogue(const P& p, f32x16 (&acc)[TM][T
             }
         if constexpr (EPI == 1) {
             if (mode & EPI_SUMS) {
-                float* red = reinterpret_cast<float*>(smem);
+                float* red = reinterpret_cast<float*>(smem) + grp * (WM * BN * 4);
                 // a lane's columns: run ch = lane % CH of every slab row it read; lanes lane % CH apart hold the same columns
                 const int W = o16 ? 8 : 4, CHr = CW / W;
 #pragma unroll
@@ -1272,7 +1294,7 @@ __device__ __forceinline__ void rowwise_epilogue(const P& p, f32x16 (&acc)[TM][T
                     }
                 __syncthreads();
                 const int slot = p.slot(bx, bz);
-                for (int idx = tid; idx < BN * 4; idx += NT2) {
+                for (int idx = tid; idx < BN * 4; idx += NTG) {
                     const int c = idx >> 2, g = (idx >> 1) & 1, w = idx & 1;
                     if (g >= e.groups || n0 + c >= C) continue;
                     float t = 0.f;
@@ -1466,8 +1488,13 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
         const unsigned char* sbase = smem + buf * STAGE;
         // operand fragments two deep: the reads of k chunk kc + 1 are in flight under the MFMAs of chunk kc
         typedef typename std::conditional<F32, f32x4, bf16x8>::type frag_t;
+        constexpr bool TRA = !P::A_KC && !F32, TRB = !P::B_KC && !F32;          // operands read with the transposing read (inline asm)
+        constexpr int NTR = 2 * ((TRA ? TM : 0) + (TRB ? TN : 0));             // asm reads per k chunk
         frag_t fa[2][TM], fb[2][TN];
-        auto frags = [&](int kc, int slot) {
+        s16x4 alo[2][TM], ahi[2][TM], blo[2][TN], bhi[2][TN];
+        const u32 sb32 = lds_addr(sbase);
+        auto frags = [&](auto kc_) {
+            constexpr int kc = decltype(kc_)::value, slot = kc & 1;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 if constexpr (P::A_KC) fa[slot][i] = *reinterpret_cast<const frag_t*>(sbase + a_row + xo[kc] + i * 4096);
@@ -1475,11 +1502,7 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
                     const float* b = reinterpret_cast<const float*>(sbase) + (kc * 8 + 4 * lh) * BM + wm0 + i * 32 + li;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) fa[slot][i][j] = b[j * BM];
-                } else {
-                    const u16* b = reinterpret_cast<const u16*>(sbase + ta[i] + kc * 16 * (BM * 2));
-                    s16x4 lo = lds_tr16(b), hi = lds_tr16(b + 4 * BM);
-                    fa[slot][i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-                }
+                } else tr16_issue<kc * 16 * (BM * 2), kc * 16 * (BM * 2) + 4 * (BM * 2)>(alo[slot][i], ahi[slot][i], sb32 + ta[i]);
             }
 #pragma unroll
             for (int i = 0; i < TN; ++i) {
@@ -1488,19 +1511,24 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
                     const float* b = reinterpret_cast<const float*>(sbase + A_BYTES) + (kc * 8 + 4 * lh) * BN + wn0 + i * 32 + li;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) fb[slot][i][j] = b[j * BN];
-                } else {
-                    const u16* b = reinterpret_cast<const u16*>(sbase + tb[i] + kc * 16 * (BN * 2));
-                    s16x4 lo = lds_tr16(b), hi = lds_tr16(b + 4 * BN);
-                    fb[slot][i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-                }
+                } else tr16_issue<kc * 16 * (BN * 2), kc * 16 * (BN * 2) + 4 * (BN * 2)>(blo[slot][i], bhi[slot][i], sb32 + tb[i]);
             }
         };
-        frags(0, 0);
-#pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {
-            if (kc + 1 < 4) frags(kc + 1, (kc + 1) & 1);
+        frags(std::integral_constant<int, 0>{});
+        static_for<0, 4>([&](auto kc_) {
+            constexpr int kc = decltype(kc_)::value;
+            if constexpr (kc + 1 < 4) frags(std::integral_constant<int, kc + 1>{});
             issue_part(nbuf, kc);
             __builtin_amdgcn_sched_barrier(0);                   // (keeps this quarter of the loads in front of this MFMA group)
+            constexpr int YOUNGER = kc + 1 < 4 ? NTR : 0;         // asm reads of chunk kc + 1, issued after the ones used now
+            if constexpr (TRA) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[kc & 1][i] = tr16_wait<YOUNGER>(alo[kc & 1][i], ahi[kc & 1][i]);
+            }
+            if constexpr (TRB) {
+#pragma unroll
+                for (int i = 0; i < TN; ++i) fb[kc & 1][i] = tr16_wait<YOUNGER>(blo[kc & 1][i], bhi[kc & 1][i]);
+            }
             if constexpr (F32) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -1516,7 +1544,7 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
                     for (int b = 0; b < TN; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kc & 1][a], fb[kc & 1][b], acc[a][b], 0, 0, 0);
             }
-        }
+        });
         buf = buf + 1 == STAGES ? 0 : buf + 1;
     }
     wait_vmcnt<0>();                                             // the (dummy) loads still in flight write LDS: drain them before the
@@ -1563,7 +1591,7 @@ using DgPatchPol = DgradP<256, 64, 64, 8, true, NT2, true>;
 
 template <int EPI>
 __global__ __launch_bounds__(NT2) void dgrad_patch_kernel(DgPatchPol p) {
-    constexpr int PATCH = 48 * 1024, BSTG = 4 * 8192, LDS_TOTAL = 2 * PATCH + 2 * BSTG;
+    constexpr int PATCH = 48 * 1024, BSTG = 2 * 8192, LDS_TOTAL = 2 * PATCH + 4 * BSTG;      // two patches, a ring of four filter stages
     constexpr int PW = 18, NPIX = PW * PW;                                  // patch: 18 x 18 pixels of 128 bytes
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const patch = smem;
@@ -1607,78 +1635,98 @@ __global__ __launch_bounds__(NT2) void dgrad_patch_kernel(DgPatchPol p) {
     };
     // ---- filter slices: thread = (co row tid / 8, chunk tid % 8) of a [64 co][64 ci] slice
     const u32 boff = (u32)(((tid >> 3) * g.taps * g.Ci + (((tid & 7) ^ sw_cols(tid >> 3, 8)) << 3)) * 2);
-    auto issue_b = [&](int G) {                                  // stage G = 4 s + q: the four slices (bh, bw) of class q = (ph, pw)
-        const int s = G >> 2, q = G & 3, ph = q >> 1, pw = q & 1;
+    auto issue_b = [&](int G) {                                  // stage G = 8 s + q, q = (pw, bh, bw): the two slices ph = 0, 1
+        const int s = G >> 3, q = G & 7, pw = q >> 2, bh = (q >> 1) & 1, bw = q & 1;
         const int a = a_lo + s / CC, cc = s - (s / CC) * CC;
-        unsigned char* dst = bst + (G & 1) * BSTG + wave * 1024;
+        unsigned char* dst = bst + (G & 3) * BSTG + wave * 1024;
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-            const int bh = tt >> 1, bw = tt & 1;
+        for (int ph = 0; ph < 2; ++ph) {
             const int tap = a * 16 + ((1 - ph) + 2 * bh) * 4 + (1 - pw) + 2 * bw;
             const u32 so = (u32)(((cc * 64 * g.taps + tap) * g.Ci) * 2);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, MCG_LDSP(dst + tt * 8192), 16, boff, so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, MCG_LDSP(dst + ph * 8192), 16, boff, so, 0, 0);
         }
     };
 
-    f32x16 acc[4][1][2];                                          // [class][1][two 32-column blocks]: this wave's 32 rows
+    // Waves: two sets of four.  Set cg = wave >> 2 computes the classes with ph = cg (q = 2 cg + pw), its wave wr = wave & 3 the rows
+    // 64 wr .. 64 wr + 63 of the frame: a wave owns 64 x 64 outputs of each of its two classes -- two A fragments feed two B
+    // fragments (1 KB of LDS reads per MFMA; with 32 x 64 per wave and every wave on the same class the LDS was the bound).
+    // A stage holds two slices (bh, bw) of the two classes that share pw: stage q2 = (pw, bh) of a super-step; slice tt = 2 cg' + bw.
+    const int cg = wave >> 2, wr_ = wave & 3;
+    f32x16 acc[2][2][2];                                          // [pw][row block][column block] of class (ph = cg, pw)
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[c][0][b][r] = 0.f;
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[c][a][b][r] = 0.f;
 
     // MFMA operand addresses
-    const int r_ = wave * 32 + li;
-    const int prow = ((r_ >> 4) + 1) * PW + (r_ & 15) + 1;         // this lane's row of the frame as a patch pixel (shift 0)
+    int prow[2];                                                  // this lane's two rows of the frame as patch pixels (shift 0)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int r_ = wr_ * 64 + i * 32 + li; prow[i] = ((r_ >> 4) + 1) * PW + (r_ & 15) + 1; }
     const int tq = (lane & 15) >> 2, tcl = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);
     u32 tb[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) tb[i] = (u32)((8 * lh + tq) * 128 + (((4 * i + tcl) ^ sw_cols(tq, 8)) << 4) + (lane & 1) * 8);
 
+    // Pipeline: a stage = one (pw, bh, bw) of a super-step = one filter slice per wave set, 16 MFMAs per wave.  The filter stages run
+    // THREE ahead in a ring of four (counted vmcnt: a wave issues 2 filter pieces per stage, plus one of the next patch's six pieces
+    // in stages 0..5 -- waiting until at most 4 loads are outstanding retires everything but the two youngest stages' filter pieces).
     issue_patch(0, 0, 6);
+    const int total = 8 * S;
     issue_b(0);
-    const int total = 4 * S;
+    if (1 < total) issue_b(1); else { issue_b(0); }               // (the count of outstanding loads must not depend on S)
+    if (2 < total) issue_b(2); else { issue_b(0); }
     for (int s = 0; s < S; ++s) {
         const unsigned char* pb = patch + (s & 1) * PATCH;
-        static_for<0, 4>([&](auto q_) {
-            constexpr int q = decltype(q_)::value, ph = q >> 1, pw = q & 1;
-            const int G = 4 * s + q;
-            wait_vmcnt<0>();
+        static_for<0, 8>([&](auto q_) {
+            constexpr int q = decltype(q_)::value, pw = q >> 2, bh = (q >> 1) & 1, bw = q & 1;
+            const int G = 8 * s + q;
+            wait_vmcnt<4>();
             __builtin_amdgcn_s_barrier();
-            if (G + 1 < total) issue_b(G + 1);
-            if (q < 3 && s + 1 < S) issue_patch(s + 1, 2 * q, 2 * q + 2);
-            const unsigned char* bb = bst + (G & 1) * BSTG;
-            int prow_v = prow;
-            asm volatile("" : "+v"(prow_v));                     // (keeps the 64 operand addresses of a super-step from being hoisted out
-                                                                 //  of the loop: they would spill -- the accumulators take 128 registers)
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) {
-                const int bh = tt >> 1, bw = tt & 1;
-                const int pr = prow_v + (ph - bh) * PW + (pw - bw);
-                const unsigned char* ap = pb + pr * 128;
-                const int sw = (pr >> 1) & 7;
-#pragma unroll
-                for (int kc = 0; kc < 4; ++kc) {
-                    const bf16x8 fa = *reinterpret_cast<const bf16x8*>(ap + (((2 * kc + lh) ^ sw) << 4));
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const u16* b = reinterpret_cast<const u16*>(bb + tt * 8192 + tb[i] + kc * 16 * 128);
-                        s16x4 lo = lds_tr16(b), hi = lds_tr16(b + 4 * 64);
-                        const bf16x8 fb = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-                        acc[q][0][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[q][0][i], 0, 0, 0);
-                    }
+            if (q < 6 && s + 1 < S) issue_patch(s + 1, q, q + 1);
+            issue_b(G + 3 < total ? G + 3 : G);                   // (past the end: a harmless reload into the slot read one stage ago)
+            const unsigned char* bb = bst + (G & 3) * BSTG + cg * 8192;       // this set's slice (ph = cg)
+            int p0 = prow[0], p1 = prow[1];
+            asm volatile("" : "+v"(p0), "+v"(p1));               // (keeps the operand addresses of a super-step from being hoisted out of
+                                                                 //  the loop: they would spill -- the accumulators take 128 registers)
+            const int shift = (cg - bh) * PW + (pw - bw);         // ph = cg
+            const int pr0 = p0 + shift, pr1 = p1 + shift;
+            const unsigned char* ap0 = pb + pr0 * 128; const unsigned char* ap1 = pb + pr1 * 128;
+            const int sw0 = (pr0 >> 1) & 7, sw1 = (pr1 >> 1) & 7;
+            // (the filter fragments through the asm form of the transposing read: see tr16_issue; two k chunks in flight)
+            const u32 bb32 = lds_addr(bb);
+            s16x4 blo[2][2], bhi[2][2];
+            tr16_issue<0, 4 * 128>(blo[0][0], bhi[0][0], bb32 + tb[0]);
+            tr16_issue<0, 4 * 128>(blo[0][1], bhi[0][1], bb32 + tb[1]);
+            static_for<0, 4>([&](auto kc_) {
+                constexpr int kc = decltype(kc_)::value;
+                bf16x8 fa[2], fb[2];
+                fa[0] = *reinterpret_cast<const bf16x8*>(ap0 + (((2 * kc + lh) ^ sw0) << 4));
+                fa[1] = *reinterpret_cast<const bf16x8*>(ap1 + (((2 * kc + lh) ^ sw1) << 4));
+                if constexpr (kc + 1 < 4) {
+                    tr16_issue<(kc + 1) * 16 * 128, (kc + 1) * 16 * 128 + 4 * 128>(blo[(kc + 1) & 1][0], bhi[(kc + 1) & 1][0], bb32 + tb[0]);
+                    tr16_issue<(kc + 1) * 16 * 128, (kc + 1) * 16 * 128 + 4 * 128>(blo[(kc + 1) & 1][1], bhi[(kc + 1) & 1][1], bb32 + tb[1]);
                 }
-            }
+                fb[0] = tr16_wait<(kc + 1 < 4 ? 4 : 0)>(blo[kc & 1][0], bhi[kc & 1][0]);
+                fb[1] = tr16_wait<(kc + 1 < 4 ? 4 : 0)>(blo[kc & 1][1], bhi[kc & 1][1]);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        acc[pw][a][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[i], acc[pw][a][i], 0, 0, 0);
+            });
         });
     }
     wait_vmcnt<0>();
-    // ---- epilogue: class by class through the row-wise store (the policy decodes rows for its parity class)
-    static_for<0, 4>([&](auto q_) {
-        constexpr int q = decltype(q_)::value;
+    // ---- epilogue: the two sets store their class (ph = cg, pw) side by side through the row-wise store
+    static_for<0, 2>([&](auto pw_) {
+        constexpr int pw = decltype(pw_)::value;
         __syncthreads();
-        p.ph = q >> 1; p.pw = q & 1;
-        rowwise_epilogue<DgPatchPol, 64, 8, 1, 1, 2, EPI, LDS_TOTAL>(p, acc[q], smem, m0, 0, wave * 32, 0, bx, q, tid);
+        p.ph = cg; p.pw = pw;
+        rowwise_epilogue<DgPatchPol, 64, 4, 1, 2, 2, EPI, LDS_TOTAL, 2>(p, acc[pw], smem, m0, 0, wr_ * 64, 0, bx, 2 * cg + pw, tid & 255, cg);
     });
 }
 
@@ -2690,7 +2738,7 @@ int launch_dgrad_patch(const Geom& g, const float* y, const float* w, const floa
     const int cls = e.mode ? epi_class(e.mode) : 0;
     if (cls > 1) return MCG_ERR_UNSUPPORTED;
     const dim3 grid(g.N * g.Ti);
-    constexpr size_t lds = 2 * 48 * 1024 + 2 * 4 * 8192;
+    constexpr size_t lds = 2 * 48 * 1024 + 4 * 2 * 8192;
     if (cls == 0) MCG_V2_LAUNCH((dgrad_patch_kernel<0>), grid, lds, p);
     else MCG_V2_LAUNCH((dgrad_patch_kernel<1>), grid, lds, p);
     return MCG_OK;
