@@ -13,7 +13,7 @@ import sys
 
 
 def per_dispatch(path, counter):
-    rows = [r for r in csv.DictReader(open(path)) if r['Counter_Name'] == counter and any(s in r['Kernel_Name'] for s in ('gemm_kernel', 'dgrad_c4', 'fprop_c4'))]
+    rows = [r for r in csv.DictReader(open(path)) if r['Counter_Name'] == counter and any(s in r['Kernel_Name'] for s in ('gemm_kernel', 'gemm_bf16', 'dgrad_c4', 'fprop_c4', 'wgrad_c4', 'dgrad_patch'))]
     rows.sort(key=lambda r: int(r['Dispatch_Id']))
     return [(r['Kernel_Name'], int(r['Grid_Size']), float(r['Counter_Value'])) for r in rows]
 
