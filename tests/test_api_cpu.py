@@ -169,8 +169,9 @@ def test_shipped_tile_table_is_well_formed():
         assert kind in ('fprop', 'dgrad', 'wgrad') and len(key) == base + form, key
         assert all(isinstance(v, int) for v in key[1:base]) and (not form or (key[base] == 'ep' and all(isinstance(v, int) for v in key[base + 1:]))), key
         assert Hi == Wi and Hi in (8, 16, 32, 64) and kt in (1, 4) and prec in (0, 1, 2) and Ci % 4 == 0 and N > 0
-        assert isinstance(code, int) and 0 <= code % 100 <= 8 and (code // 100) % 10 <= 2 and code // 1000 <= 2, code
-        assert code % 100 < 7 or (prec == 2 and code in (7, 8)), (key, code)      # the LDS-DMA kernels: bf16-stored operands, no K split
+        assert isinstance(code, int) and 0 <= code % 100 <= 9 and (code // 100) % 10 <= 2 and code // 1000 <= 2, code
+        assert code % 100 < 7 or (prec == 2 and code in (7, 8)) or (prec == 2 and code == 9 and kind == 'dgrad' and Ci == 64 and Hi == 32), (key, code)
+        # (7 / 8: the LDS-DMA kernels, 9: the patch-stationary input gradient -- bf16-stored operands, no K split)
         assert tuple(key) not in seen
         seen.add(tuple(key))
 
