@@ -196,7 +196,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=32, help='clips per GPU (BASELINE config C2: 32)')
     ap.add_argument('--model', default='normal', choices=['normal', 'cgan', 'infogan'])
-    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16', 'f32x3'],
                     help="MFMA operand type of the conv GEMMs: f32 = BASELINE configs[1] (the headline); "
                          "bf16 = configs[2] (use with --batch 256), fp32 accumulation / parameters / Adam")
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -338,8 +338,8 @@ def main():
             gflop = 2.0 * N_ * (T_ - kt_ + 1) * (H_ // 2) ** 2 * kt_ * 16 * min(Ci_, 3 if Ci_ == 4 else Ci_) * Co_ / 1e9
             by_layer[k] = {"launches_per_step": n_l / steps, "ms_per_launch": ms / n_l,
                            "tflops": gflop * n_l / ms if ms > 0 else 0.0}
-        traffic, traffic_src = pmc_traffic(B, dtype)
-        peak = PEAK_FP32_MFMA_TFLOPS if dtype == 'f32' else PEAK_BF16_MFMA_TFLOPS
+        traffic, traffic_src = pmc_traffic(B, dtype) if dtype != 'f32x3' else (None, None)
+        peak = PEAK_BF16_MFMA_TFLOPS if dtype == 'bf16' else PEAK_FP32_MFMA_TFLOPS
         cfg_name = "configs[2]" if (dtype == 'bf16' and B == 256 and model == 'normal') else \
             "configs[1]" if (dtype == 'f32' and B == 32 and model == 'normal') else \
             "configs[3]" if (dtype == 'f32' and B == 32 and model == 'infogan') else \

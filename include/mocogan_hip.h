@@ -53,7 +53,16 @@ enum { MCG_PREC_F32 = 0, MCG_PREC_BF16 = 1,
        /* as MCG_PREC_BF16, with the INPUT operands of the call (x and w for fprop, y and w for dgrad, x and y for wgrad)
         * already bf16 in memory (uint16_t, round-to-nearest-even of the fp32 values): they are loaded and staged as they
         * are -- half the operand traffic, no conversion in the K loop.  Outputs stay fp32.  Ci, Co multiples of 8. */
-       MCG_PREC_BF16_STORE = 2 };
+       MCG_PREC_BF16_STORE = 2,
+       /* fp32 arithmetic on the bf16 matrix pipe: an fp32 value v is held as the three bf16 terms hi = bf16(v),
+        * mid = bf16(v - hi), lo = bf16(v - hi - mid) (v == hi + mid + lo exactly) and a product is the sum of the six bf16
+        * products hi.hi + hi.mid + mid.hi + hi.lo + mid.mid + lo.hi, accumulated in fp32: what is dropped is below 2^-24 of
+        * |a||b|, i.e. below the rounding of an fp32 accumulation.  The INPUT operands of the call are in the split layout
+        * mcg_split_planes writes: along the channel dimension that the GEMM sums over (Ci of x and w for fprop, Co of y and
+        * w for dgrad) groups of 16 channels x 4 planes (hi, mid, lo, 0) of bf16, i.e. 4 * C uint16_t per pixel / filter row
+        * (for dgrad's w: 16 filters x 4 planes, see mcg_split_planes).
+        * Outputs stay fp32.  LDS-DMA kernels only (tile 0, 7 or 8); channel counts along the sum powers of two >= 16. */
+       MCG_PREC_SPLIT = 3 };
 
 /* Geometry of one 4x4(x4) stride-(1,2,2) pad-(0,1,1) convolution, i.e. every strided layer of
  * the reference: L.ConvolutionND / L.Convolution2D dc1..dc4 (model/net.py:133-136,174-177) and,
@@ -315,6 +324,13 @@ int mcg_randn(int64_t n, float sigma, uint64_t seed, uint64_t stream_id, float* 
 /* out[M][C] = sigma * N(0,1) in the element order of the fused first-layer epilogue (mcg_conv_epilogue.sigma):
  * element (m, c) is normal m & 3 of Philox counter (m >> 2) * C + c.  M % 4 == 0. */
 int mcg_randn_rowquad(int64_t M, int C, float sigma, uint64_t seed, uint64_t stream_id, float* out, void* stream);
+/* The split layout of MCG_PREC_SPLIT.  src is n fp32 values seen as consecutive runs of `run` values (run a multiple of 16,
+ * n a multiple of run); dst gets, per run, four runs of bf16: hi, mid, lo (as above) and zeros -- 4 * n uint16_t in all.
+ *   run = 16                 : channels-last tensors [.. pixels][C] -> [.. pixels][C/16][4][16]   (the summed dimension of
+ *                              x / y, and of w = [Co][taps][Ci] as fprop reads it);
+ *   run = 16 * taps * Ci     : w as dgrad reads it -> [Co/16][4][16][taps][Ci] (the planes of 16 filters, filter by filter). */
+int mcg_split_planes(int64_t n, int64_t run, const float* src, void* dst, void* stream);
+
 /* out[i] = word (i & 3) of Philox counter (i >> 2) of the stream, modulo `modulus`: the generator's label draw
  * xp.random.randint(dim_zl, size=batchsize) (model/net.py:91-92) from the same keyed generator as the normals. */
 int mcg_randint(int64_t n, int modulus, uint64_t seed, uint64_t stream_id, int32_t* out, void* stream);

@@ -488,7 +488,10 @@ struct DgradP {
 };
 
 // ---------------- wgrad (blockIdx.z = pixel split) ----------------
-template <int BM, int BN, int BK, int E_ = 4, int NT = NTHREADS, bool SW = false>
+// SPL (MCG_PREC_SPLIT, LDS-DMA kernels): x and y are in the split layout [pixel][C/16][4 planes][16]; the 64 k rows of a K-step are
+// 16 PIXELS x 4 planes (k row r = plane r >> 4 of pixel r & 15 of the step), so that k chunk kc of a tile is plane kc of the same
+// 16 pixels and the kernel's SPLIT phase forms the six products; k counts quarter pixels (K-steps of 64 = 16 pixels).
+template <int BM, int BN, int BK, int E_ = 4, int NT = NTHREADS, bool SW = false, bool SPL = false>
 struct WgradP {
     static constexpr bool HAS_EPI = false;
     static constexpr bool HAS_ROW_OFF = false;
@@ -507,13 +510,14 @@ struct WgradP {
         constexpr int AC4 = BM / E, BC4 = BN / E;
         xr = make_srd(x, g.x_bytes); yr = make_srd(y, g.y_bytes);
         int aco = m0 + (SW && E == 8 ? ((tid % AC4) ^ sw_cols(tid / AC4, AC4)) : tid % AC4) * E;
-        aoff = aco < g.Co ? (u32)aco * (u32)ESZ : OOB;
+        aoff = aco < g.Co ? (SPL ? (u32)((aco >> 4) * 64 + (aco & 8)) * 2u : (u32)aco * (u32)ESZ) : OOB;
 #pragma unroll
         for (int j = 0; j < NA; ++j) akrow[j] = tid / AC4 + (NT / AC4) * j;
         int bkf = n0 + (SW && E == 8 ? ((tid % BC4) ^ sw_cols(tid / BC4, BC4)) : tid % BC4) * E;
         bok = bkf < Kf;
         int kk = bok ? bkf : 0, tap;
         divmod_c(kk, g.Ci, g.lgCi, tap, bci);
+        if constexpr (SPL) bci = (bci >> 4) * 64 + (bci & 8);      // the channel's place in its pixel's groups of 4 planes x 16
         bt = tap >> 4; bkh = (tap >> 2) & 3; bkw = tap & 3;
 #pragma unroll
         for (int j = 0; j < NB; ++j) bkrow[j] = tid / BC4 + (NT / BC4) * j;
@@ -524,13 +528,29 @@ struct WgradP {
     __device__ void store_probe(float v) const { dw[0] = v; }
     template <class F> __device__ void each_a(int k0, F&& f) const {
 #pragma unroll
-        for (int j = 0; j < NA; ++j) f(j, aoff + (u32)((k0 + akrow[j]) * g.Co) * (u32)ESZ, 0u);
+        for (int j = 0; j < NA; ++j) {
+            if constexpr (SPL) {
+                const int plane = akrow[j] >> 4, pix = (k0 >> 2) + (akrow[j] & 15);
+                f(j, plane < 3 ? aoff + (u32)(pix * 4 * g.Co + plane * 16) * 2u : OOB, 0u);       // (pixels beyond Mpix: beyond the buffer)
+            } else f(j, aoff + (u32)((k0 + akrow[j]) * g.Co) * (u32)ESZ, 0u);
+        }
     }
     template <class F> __device__ void each_b(int k0, F&& f) const {
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            int pix = k0 + bkrow[j];
+            int pix = SPL ? (k0 >> 2) + (bkrow[j] & 15) : k0 + bkrow[j];
             bool ok = bok && pix < Mpix;
+            if constexpr (SPL) {
+                const int plane = bkrow[j] >> 4;
+                const int wo = pix & (g.Wo - 1), ho = (pix >> g.lgWo) & (g.Ho - 1), q = pix >> (g.lgWo + g.lgHo);
+                const int n = div_To(g, q), to = q - n * g.To;
+                const int hi = 2 * ho - 1 + bkh, wi = 2 * wo - 1 + bkw;
+                ok = ok && plane < 3 && (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)g.Wi;
+                const int base = g.perm_n ? (int)x_batch_off(g, n) : n * (int)g.xs0;
+                const u32 vo = (u32)(4 * (base + (((to + bt) * g.Hi + hi) * g.Wi + wi) * g.Ci) + bci + plane * 16) * 2u;
+                f(j, ok ? vo : OOB, 0u);
+                continue;
+            }
             int wo = pix & (g.Wo - 1), ho = (pix >> g.lgWo) & (g.Ho - 1), q = pix >> (g.lgWo + g.lgHo);
             int n = div_To(g, q), to = q - n * g.To;
             int hi = 2 * ho - 1 + bkh, wi = 2 * wo - 1 + bkw;
@@ -540,8 +560,8 @@ struct WgradP {
             f(j, ok ? vo : OOB, 0u);
         }
     }
-    __device__ int k_begin(int z) const { return z * chunk; }
-    __device__ int k_end(int z) const { int e = (z + 1) * chunk; return e < Mpix ? e : Mpix; }
+    __device__ int k_begin(int z) const { return z * chunk * (SPL ? 4 : 1); }
+    __device__ int k_end(int z) const { int e = (z + 1) * chunk; return (e < Mpix ? e : Mpix) * (SPL ? 4 : 1); }
     __device__ int next_valid(int k0) const { return k0; }
     __device__ void load_a(int k0, f32x4 (&r)[NA]) const {
         // rows beyond Mpix fall outside the buffer: the range check returns zeros
@@ -1336,7 +1356,11 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
 }
 
-template <class P, int BM, int BN, int STAGES, int EPI = 0>
+// SPLIT (MCG_PREC_SPLIT: fp32 values as three bf16 terms, see mcg_split_planes): the operands' K dimension holds groups of 16
+// channels x 4 planes (hi, mid, lo, 0), i.e. the 128-byte K-step of a tile row is ONE group -- k chunk kc of the row is plane kc.
+// The MFMA phase then forms the six products hi.hi, hi.mid, mid.hi, hi.lo, mid.mid, lo.hi of a group (everything down to 2^-24
+// of the fp32 product) instead of the four chunk-by-chunk products of a bf16 K-step.  Loads, ring, images, epilogue: unchanged.
+template <class P, int BM, int BN, int STAGES, int EPI = 0, int SPLIT = 0>
 __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
     // P::E == 8: bf16 operands, BK = 64, v_mfma_f32_32x32x16_bf16.  P::E == 4: fp32 operands, BK = 32, v_mfma_f32_32x32x2_f32 --
     // the same tile bytes, the same LDS images (a K-contiguous row is 128 bytes either way), the same ring; tiles in global
@@ -1492,6 +1516,8 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
         constexpr int NTR = 2 * ((TRA ? TM : 0) + (TRB ? TN : 0));             // asm reads per k chunk
         frag_t fa[2][TM], fb[2][TN];
         s16x4 alo[2][TM], ahi[2][TM], blo[2][TN], bhi[2][TN];
+        frag_t sfa[SPLIT ? 3 : 1][TM], sfb[SPLIT ? 3 : 1][TN];
+        s16x4 salo[SPLIT ? 3 : 1][TM], sahi[SPLIT ? 3 : 1][TM], sblo[SPLIT ? 3 : 1][TN], sbhi[SPLIT ? 3 : 1][TN];
         const u32 sb32 = lds_addr(sbase);
         auto frags = [&](auto kc_) {
             constexpr int kc = decltype(kc_)::value, slot = kc & 1;
@@ -1514,6 +1540,46 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
                 } else tr16_issue<kc * 16 * (BN * 2), kc * 16 * (BN * 2) + 4 * (BN * 2)>(blo[slot][i], bhi[slot][i], sb32 + tb[i]);
             }
         };
+        if constexpr (SPLIT) {
+            static_assert(!F32, "split operands are bf16 planes");
+            // all three planes of both operands, then the six products; the step's loads in front of the first four groups
+            static_for<0, 3>([&](auto pl_) {
+                constexpr int pl = decltype(pl_)::value;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    if constexpr (P::A_KC) sfa[pl][i] = *reinterpret_cast<const frag_t*>(sbase + a_row + xo[pl] + i * 4096);
+                    else tr16_issue<pl * 16 * (BM * 2), pl * 16 * (BM * 2) + 4 * (BM * 2)>(salo[pl][i], sahi[pl][i], sb32 + ta[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < TN; ++i) {
+                    if constexpr (P::B_KC) sfb[pl][i] = *reinterpret_cast<const frag_t*>(sbase + b_row + xo[pl] + i * 4096);
+                    else tr16_issue<pl * 16 * (BN * 2), pl * 16 * (BN * 2) + 4 * (BN * 2)>(sblo[pl][i], sbhi[pl][i], sb32 + tb[i]);
+                }
+            });
+            static_for<0, 3>([&](auto pl_) {                     // (asm reads: completion counted by hand; plane pl has 2 - pl planes behind it)
+                constexpr int pl = decltype(pl_)::value;
+                constexpr int PER = 2 * ((TRA ? TM : 0) + (TRB ? TN : 0));
+                if constexpr (TRA) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) sfa[pl][i] = tr16_wait<((2 - pl) * PER < 15 ? (2 - pl) * PER : 15)>(salo[pl][i], sahi[pl][i]);
+                }
+                if constexpr (TRB) {
+#pragma unroll
+                    for (int i = 0; i < TN; ++i) sfb[pl][i] = tr16_wait<((2 - pl) * PER < 15 ? (2 - pl) * PER : 15)>(sblo[pl][i], sbhi[pl][i]);
+                }
+            });
+            static_for<0, 6>([&](auto c_) {
+                constexpr int c = decltype(c_)::value;
+                constexpr int pa = (c == 0 || c == 1 || c == 3) ? 0 : (c == 2 || c == 4) ? 1 : 2;
+                constexpr int pb = (c == 0 || c == 2 || c == 5) ? 0 : (c == 1 || c == 4) ? 1 : 2;
+                if constexpr (c < 4) { issue_part(nbuf, c); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sfa[pa][a], sfb[pb][b], acc[a][b], 0, 0, 0);
+            });
+        } else {
         frags(std::integral_constant<int, 0>{});
         static_for<0, 4>([&](auto kc_) {
             constexpr int kc = decltype(kc_)::value;
@@ -1545,6 +1611,7 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kc & 1][a], fb[kc & 1][b], acc[a][b], 0, 0, 0);
             }
         });
+        }
         buf = buf + 1 == STAGES ? 0 : buf + 1;
     }
     wait_vmcnt<0>();                                             // the (dummy) loads still in flight write LDS: drain them before the
@@ -2524,7 +2591,7 @@ int make_geom(const mcg_conv_geom* c, Geom& g) {
     g.prec = c->precision;
     if (c->ci_valid < 0 || c->ci_valid > c->Ci) return MCG_ERR_BAD_ARG;
     g.cv = c->ci_valid ? c->ci_valid : c->Ci;
-    if (g.prec != MCG_PREC_F32 && g.prec != MCG_PREC_BF16 && g.prec != MCG_PREC_BF16_STORE) return MCG_ERR_BAD_ARG;
+    if (g.prec != MCG_PREC_F32 && g.prec != MCG_PREC_BF16 && g.prec != MCG_PREC_BF16_STORE && g.prec != MCG_PREC_SPLIT) return MCG_ERR_BAD_ARG;
     if (c->tile < 0 || c->tile % 100 > 9 || (c->tile / 100) % 10 > 2 || c->tile / 1000 > 2) return MCG_ERR_BAD_ARG;
     g.tile = c->tile % 100; g.bk = ((c->tile / 100) % 10) * 32; g.ksplit = 1 << (c->tile / 1000);
     g.lgHo = ilog2_exact(g.Ho); g.lgWo = ilog2_exact(g.Wo);
@@ -2654,6 +2721,31 @@ bool v2_ok(const Geom& g, int kdim /* channel count along K: Ci (fprop), Co (dgr
     return (g.prec == MCG_PREC_BF16_STORE || g.prec == MCG_PREC_F32) && kdim >= 64 && (kdim & (kdim - 1)) == 0 && g.ksplit == 1;
 }
 
+// MCG_PREC_SPLIT: the launch is that of a bf16-stored layer with FOUR TIMES the channels along the summed dimension (16 channels x
+// 4 planes per group, mcg_split_planes); the kernel's SPLIT flag turns a group's K-step into the six products.
+Geom split_geom(const Geom& g, bool on_ci) {
+    Geom h = g;
+    h.prec = MCG_PREC_BF16_STORE;
+    const long long frame = (long long)g.Ti * g.Hi * g.Wi * g.Ci;
+    const long long x_elems = (g.perm_n ? (long long)(g.perm_n - 1) * g.xs0 + (long long)(g.N / g.perm_n - 1) * g.xs1
+                                        : (long long)(g.N - 1) * g.xs0) + frame;
+    const long long y_elems = (long long)g.N * g.To * g.Ho * g.Wo * g.Co;
+    const long long w_elems = (long long)g.Co * g.taps * g.Ci;
+    if (on_ci) { h.Ci = 4 * g.Ci; h.lgCi = g.lgCi + 2; h.cv = h.Ci; h.xs0 = 4 * g.xs0; h.xs1 = 4 * g.xs1; h.x_bytes = (u32)(x_elems * 8); }
+    else { h.Co = 4 * g.Co; h.lgCo = g.lgCo + 2; h.y_bytes = (u32)(y_elems * 8); }
+    h.w_bytes = (u32)(w_elems * 8);
+    return h;
+}
+bool split_ok(const Geom& g, bool on_ci) {
+    const int c = on_ci ? g.Ci : g.Co;
+    const long long frame = (long long)g.Ti * g.Hi * g.Wi * g.Ci;
+    const long long x_elems = (g.perm_n ? (long long)(g.perm_n - 1) * g.xs0 + (long long)(g.N / g.perm_n - 1) * g.xs1
+                                        : (long long)(g.N - 1) * g.xs0) + frame;
+    const long long y_elems = (long long)g.N * g.To * g.Ho * g.Wo * g.Co;
+    const long long w_elems = (long long)g.Co * g.taps * g.Ci;
+    return c >= 16 && (c & (c - 1)) == 0 && g.ksplit == 1 && (on_ci ? x_elems : y_elems) * 8 < (1ll << 31) && w_elems * 8 < (1ll << 31);
+}
+
 template <class K> int v2_set_lds(K kernel, size_t lds, std::once_flag& once) {
     hipError_t attr = hipSuccess;
     std::call_once(once, [&] { attr = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
@@ -2667,7 +2759,7 @@ template <class K> int v2_set_lds(K kernel, size_t lds, std::once_flag& once) {
     } while (0)
 
 // PM as in launch_fprop: 0 = fp32 operands (fp32 MFMA), 2 = bf16-stored operands
-template <int BM, int BN, int STAGES, int PM>
+template <int BM, int BN, int STAGES, int PM, int SPLIT = 0>
 int launch_fprop_v2(const Geom& g, const float* x, const float* w, const float* bias, float* y, const Epi& e, mcg_conv_epilogue* ep, hipStream_t s) {
     using Pol = FpropP<BM, BN, PM ? 64 : 32, PM ? 8 : 4, true, NT2, true>;
     Pol p;
@@ -2679,12 +2771,12 @@ int launch_fprop_v2(const Geom& g, const float* x, const float* w, const float* 
     if (cls > 1) return MCG_ERR_UNSUPPORTED;
     const dim3 grid((p.M + BM - 1) / BM, (g.Co + BN - 1) / BN, 1);
     constexpr size_t lds = (size_t)STAGES * (BM + BN) * 128;
-    if (cls == 0) MCG_V2_LAUNCH((gemm_bf16_v2_kernel<Pol, BM, BN, STAGES, 0>), grid, lds, p);
-    else MCG_V2_LAUNCH((gemm_bf16_v2_kernel<Pol, BM, BN, STAGES, 1>), grid, lds, p);
+    if (cls == 0) MCG_V2_LAUNCH((gemm_bf16_v2_kernel<Pol, BM, BN, STAGES, 0, SPLIT>), grid, lds, p);
+    else MCG_V2_LAUNCH((gemm_bf16_v2_kernel<Pol, BM, BN, STAGES, 1, SPLIT>), grid, lds, p);
     return MCG_OK;
 }
 
-template <int BM, int BN, int STAGES, int PM>
+template <int BM, int BN, int STAGES, int PM, int SPLIT = 0>
 int launch_dgrad_v2(const Geom& g, const float* y, const float* w, const float* bias, float* x, int act, int acc, const Epi& e, mcg_conv_epilogue* ep, hipStream_t s) {
     using Pol = DgradP<BM, BN, PM ? 64 : 32, PM ? 8 : 4, true, NT2, true>;
     Pol p;
@@ -2697,15 +2789,15 @@ int launch_dgrad_v2(const Geom& g, const float* y, const float* w, const float* 
     const int cls = e.mode ? epi_class(e.mode) : 0;
     if (cls > 1) return MCG_ERR_UNSUPPORTED;
     constexpr size_t lds = (size_t)STAGES * (BM + BN) * 128;
-    if (cls == 0) MCG_V2_LAUNCH((gemm_bf16_v2_kernel<Pol, BM, BN, STAGES, 0>), grid, lds, p);
-    else MCG_V2_LAUNCH((gemm_bf16_v2_kernel<Pol, BM, BN, STAGES, 1>), grid, lds, p);
+    if (cls == 0) MCG_V2_LAUNCH((gemm_bf16_v2_kernel<Pol, BM, BN, STAGES, 0, SPLIT>), grid, lds, p);
+    else MCG_V2_LAUNCH((gemm_bf16_v2_kernel<Pol, BM, BN, STAGES, 1, SPLIT>), grid, lds, p);
     return MCG_OK;
 }
 
-template <int BM, int BN, int STAGES, int PM>
+template <int BM, int BN, int STAGES, int PM, int SPLIT = 0>
 int launch_wgrad_v2(const Geom& g, const float* x, const float* y, float* dw, hipStream_t s) {
-    constexpr int BK = PM ? 64 : 32;
-    using Pol = WgradP<BM, BN, BK, PM ? 8 : 4, NT2, true>;
+    constexpr int BK = PM ? (SPLIT ? 16 : 64) : 32;              // PIXELS per K-step (split: 16 pixels x 4 planes = 64 k rows)
+    using Pol = WgradP<BM, BN, PM ? 64 : 32, PM ? 8 : 4, NT2, true, SPLIT != 0>;
     Pol p;
     p.g = g; p.x = x; p.y = y; p.dw = dw;
     p.Mpix = g.N * g.To * g.Ho * g.Wo; p.Kf = g.taps * g.Ci;
@@ -2714,13 +2806,14 @@ int launch_wgrad_v2(const Geom& g, const float* x, const float* y, float* dw, hi
     // one block per CU at a time (LDS): aim at 2 rounds of blocks; every block ends in BM x BN float atomics, so fewer, longer
     // blocks than the register-staged kernel's
     int splits = (512 + tiles - 1) / tiles;
-    if (splits > ksteps / 8) splits = ksteps / 8;        // keep >= 8 K-steps per block
+    constexpr int MINSTEPS = SPLIT ? 32 : 8;             // keep >= 512 pixels per block
+    if (splits > ksteps / MINSTEPS) splits = ksteps / MINSTEPS;
     if (splits < 1) splits = 1;
     p.chunk = ((ksteps + splits - 1) / splits) * BK;
     splits = (p.Mpix + p.chunk - 1) / p.chunk;
     const dim3 grid((g.Co + BM - 1) / BM, (p.Kf + BN - 1) / BN, splits);
     constexpr size_t lds = (size_t)STAGES * (BM + BN) * 128;
-    MCG_V2_LAUNCH((gemm_bf16_v2_kernel<Pol, BM, BN, STAGES, 0>), grid, lds, p);
+    MCG_V2_LAUNCH((gemm_bf16_v2_kernel<Pol, BM, BN, STAGES, 0, SPLIT>), grid, lds, p);
     return MCG_OK;
 }
 
@@ -2841,6 +2934,12 @@ int conv_fprop_impl(const mcg_conv_geom* c, const float* x, const float* w, cons
     // that the last partial round of blocks does not matter, else 128x64, else 64x64 to fill 256 CUs.
     int t = g.tile;
     const int bk = g.bk;
+    if (g.prec == MCG_PREC_SPLIT) {                                // fp32 values as three bf16 terms: the LDS-DMA kernels only
+        if ((t != 0 && t != 7 && t != 8) || !split_ok(g, true) || (e.mode & ~(EPI_STATS | EPI_COL | EPI_MASKMUL)) || e.out16) return MCG_ERR_UNSUPPORTED;
+        const Geom h = split_geom(g, true);
+        st = (t == 8 && g.Co >= 256) ? launch_fprop_v2<256, 256, 2, 2, 1>(h, x, w, bias, y, e, ep, s) : launch_fprop_v2<256, 128, 3, 2, 1>(h, x, w, bias, y, e, ep, s);
+        return finish(st);
+    }
     if ((t == 0 || t == 6) && c4_fprop_ok(g, e)) {                 // the 3-channel clip padded to 4: weight-stationary kernel
         if (ep) { ep->n_slots = 0; ep->slot_stride = e.slot_stride; }
         if (g.prec == MCG_PREC_BF16) {
@@ -2927,6 +3026,14 @@ int conv_dgrad_impl(const mcg_conv_geom* c, const float* y, const float* w, cons
     long long M = (long long)g.N * g.Ti * g.Ho * g.Wo;
     int t = g.tile;
     const int bk = g.bk;
+    if (g.prec == MCG_PREC_SPLIT) {                              // fp32 values as three bf16 terms: the LDS-DMA kernels only
+        if ((t != 0 && t != 7 && t != 8) || !split_ok(g, false) || g.Ci < 64 || (g.Ci & (g.Ci - 1)) || (e.mode & ~(EPI_STATS | EPI_COL | EPI_MASKMUL)) || e.out16)
+            return MCG_ERR_UNSUPPORTED;
+        const Geom h = split_geom(g, false);
+        if (g.Ci == 64) st = launch_dgrad_v2<256, 64, 3, 2, 1>(h, y, w, bias, x, act, accumulate, e, ep, s);
+        else st = launch_dgrad_v2<256, 128, 3, 2, 1>(h, y, w, bias, x, act, accumulate, e, ep, s);     // (256x256 with three planes of fragments spills)
+        return finish(st);
+    }
     if ((t == 0 || t == 6) && g.prec != MCG_PREC_BF16_STORE && c4_dgrad_mfma_ok(g, e, bias, act, accumulate)) {      // (computes in fp32)
         if (g.prec == MCG_PREC_BF16) {                           // bf16 networks: the same kernel on the bf16 MFMA
             if (g.kt == 4) st = g.Wo == 32 ? launch_dgrad_c4_mfma<4, 32, true>(g, y, w, x, s) : launch_dgrad_c4_mfma<4, 16, true>(g, y, w, x, s);
@@ -2989,6 +3096,18 @@ extern "C" int mcg_conv_wgrad(const mcg_conv_geom* c, const float* x, const floa
     int st = make_geom(c, g);
     if (st) return st;
     if (!x || !dw || !y) return MCG_ERR_BAD_ARG;
+    if (g.prec == MCG_PREC_SPLIT) {                              // x and y in the split layout: 16 pixels x 4 planes per K-step
+        const long long x_el = (g.perm_n ? (long long)(g.perm_n - 1) * g.xs0 + (long long)(g.N / g.perm_n - 1) * g.xs1 : (long long)(g.N - 1) * g.xs0) +
+                               (long long)g.Ti * g.Hi * g.Wi * g.Ci;
+        const long long y_el = (long long)g.N * g.To * g.Ho * g.Wo * g.Co;
+        if ((g.tile != 0 && g.tile != 7 && g.tile != 8) || g.Co < 128 || (g.Co & 63) || g.Ci < 64 || (g.Ci & (g.Ci - 1)) || g.ksplit != 1 ||
+            x_el * 8 >= (1ll << 31) || y_el * 8 >= (1ll << 31) || (y_el / g.Co) % 16) return MCG_ERR_UNSUPPORTED;
+        Geom h = g;
+        h.prec = MCG_PREC_BF16_STORE; h.x_bytes = (u32)(x_el * 8); h.y_bytes = (u32)(y_el * 8);
+        st = (g.Co == 128 || g.tile != 8) ? launch_wgrad_v2<128, 256, 3, 2, 1>(h, x, y, dw, (hipStream_t)stream)
+                                          : launch_wgrad_v2<256, 256, 2, 2, 1>(h, x, y, dw, (hipStream_t)stream);
+        return finish(st);
+    }
     hipStream_t s = (hipStream_t)stream;
     int Kf = g.taps * g.Ci;
     int t = g.tile;

@@ -979,6 +979,32 @@ Folded fold_slots(const float* part, int n_slots, int slot_stride, int C, float*
 // C must be 4 * 2^k, k <= 8 (every width the reference can produce from a power-of-two n_filters)
 bool unsupported_c(int C) { return (C >> 2) > NT || (NT % (C >> 2)) != 0; }
 
+
+// fp32 -> the three bf16 terms of MCG_PREC_SPLIT (include/mocogan_hip.h): hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid);
+// the differences are exact in fp32 and v == hi + mid + lo.  One thread: 8 consecutive values of a run -> one 16-byte piece of each
+// of the run's four planes (the fourth is zero).
+__device__ __forceinline__ void split3(f32x8 v, bf16x8_t& hi, bf16x8_t& mid, bf16x8_t& lo) {
+    hi = __builtin_convertvector(v, bf16x8_t);
+    const f32x8 r1 = v - __builtin_convertvector(hi, f32x8);
+    mid = __builtin_convertvector(r1, bf16x8_t);
+    const f32x8 r2 = r1 - __builtin_convertvector(mid, f32x8);
+    lo = __builtin_convertvector(r2, bf16x8_t);
+}
+__device__ __forceinline__ void store_split8(__bf16* dst, long long e, long long run, f32x8 v) {      // e: index of the first of 8 source values
+    bf16x8_t hi, mid, lo;
+    split3(v, hi, mid, lo);
+    const long long r = e / run, o = e - r * run;
+    __bf16* d = dst + r * 4 * run + o;
+    *reinterpret_cast<bf16x8_t*>(d) = hi;
+    *reinterpret_cast<bf16x8_t*>(d + run) = mid;
+    *reinterpret_cast<bf16x8_t*>(d + 2 * run) = lo;
+    *reinterpret_cast<f32x4*>(d + 3 * run) = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+__global__ __launch_bounds__(NT) void split_planes_kernel(long long n8, long long run, const float* __restrict__ src, __bf16* __restrict__ dst) {
+    for (long long i = blockIdx.x * (long long)NT + threadIdx.x; i < n8; i += (long long)gridDim.x * NT)
+        store_split8(dst, i * 8, run, load8(src, i * 8, 0));
+}
+
 }  // namespace
 
 extern "C" int mcg_version(void) { return MCG_ABI_VERSION; }
@@ -1283,6 +1309,12 @@ extern "C" int mcg_adam_wd(int64_t n, float* p, const float* g, float* m, float*
     // hyper-parameters arrive as doubles so that (1 - beta) is rounded to fp32 once, like Chainer's python-float arithmetic
     hipLaunchKernelGGL(adam_wd_kernel, dim3(ew_grid(n)), dim3(NT), 0, (hipStream_t)stream, (long long)n, p, g, m, v, (float)lr_t,
                        (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)wd, (float)grad_scale, (__bf16*)p_bf16);
+    return launch_status();
+}
+
+extern "C" int mcg_split_planes(int64_t n, int64_t run, const float* src, void* dst, void* stream) {
+    if (!src || !dst || n <= 0 || run < 16 || (run & 15) || n % run) return MCG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(split_planes_kernel, dim3(ew_grid(n / 8)), dim3(NT), 0, (hipStream_t)stream, (long long)(n / 8), (long long)run, src, (__bf16*)dst);
     return launch_status();
 }
 

@@ -83,6 +83,7 @@ SIGNATURES = {
     "mcg_adam_wd": (_I, [_I64, _P, _P, _P, _P, _D, _D, _D, _D, _D, _D, _P, _P]),
     "mcg_randn": (_I, [_I64, _F, _U64, _U64, _P, _P]),
     "mcg_randint": (_I, [_I64, _I, _U64, _U64, _P, _P]),
+    "mcg_split_planes": (_I, [_I64, _I64, _P, _P, _P]),
 }
 
 ABI_VERSION = 3          # MCG_ABI_VERSION of include/mocogan_hip.h these prototypes were written against
@@ -160,15 +161,16 @@ def _dense(t):
     return t
 
 
-PREC_F32, PREC_BF16, PREC_BF16_STORE = 0, 1, 2
-# 'bf16': bf16 MFMA on fp32 tensors (rounded in the kernel); 'bf16s': bf16 MFMA on operands that are bf16 in memory
-PRECISIONS = {"f32": PREC_F32, "fp32": PREC_F32, "bf16": PREC_BF16, "bf16s": PREC_BF16_STORE,
-              PREC_F32: PREC_F32, PREC_BF16: PREC_BF16, PREC_BF16_STORE: PREC_BF16_STORE}
+PREC_F32, PREC_BF16, PREC_BF16_STORE, PREC_SPLIT = 0, 1, 2, 3
+# 'bf16': bf16 MFMA on fp32 tensors (rounded in the kernel); 'bf16s': bf16 MFMA on operands that are bf16 in memory;
+# 'f32x3': fp32 values as three bf16 terms (split_planes), six bf16 products per fp32 product -- fp32 results on the bf16 pipe
+PRECISIONS = {"f32": PREC_F32, "fp32": PREC_F32, "bf16": PREC_BF16, "bf16s": PREC_BF16_STORE, "f32x3": PREC_SPLIT,
+              PREC_F32: PREC_F32, PREC_BF16: PREC_BF16, PREC_BF16_STORE: PREC_BF16_STORE, PREC_SPLIT: PREC_SPLIT}
 
 
 def _pin(g, t):
     """device pointer of an INPUT operand of a conv launch: bf16 tensors for MCG_PREC_BF16_STORE geometries"""
-    return _p(t, torch.bfloat16 if g.precision == PREC_BF16_STORE else torch.float32)
+    return _p(t, torch.bfloat16 if g.precision in (PREC_BF16_STORE, PREC_SPLIT) else torch.float32)
 
 
 def _pany(t):
@@ -219,7 +221,13 @@ def timing_end():
     return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in (t or {}).items()}
 
 
+split_launches = 0          # conv launches in the MCG_PREC_SPLIT form so far (tests assert that the form really ran)
+
+
 def _launch(kind, fn, *args):
+    if args[0].precision == PREC_SPLIT:
+        global split_launches
+        split_launches += 1
     if _timing is None:
         return fn(*args)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -281,6 +289,66 @@ def load_tile_choices(path):
         _tile_cache[tuple(k)] = int(v)
 
 
+def with_precision(g, precision):
+    """a copy of the geometry for another operand form of the same layer (its tile is chosen afresh)"""
+    h = ConvGeom.from_buffer_copy(g)
+    h.precision = PRECISIONS[precision]
+    h.tile = 0
+    return h
+
+
+def split_covers(kind, g):
+    """does the MCG_PREC_SPLIT form of this pass exist for the geometry (the library's own condition, restated for callers)?
+    kind 'fprop': the sum runs over Ci; 'dgrad': over Co, and the LDS-DMA input-gradient tiles need >= 64 output columns;
+    'wgrad': the sum runs over pixels, x and y both in the split layout."""
+    def p2(c, lo):
+        return c >= lo and c & (c - 1) == 0
+    x_el = max((g.N - 1) * g.x_stride0, 0) + g.Ti * g.Hi * g.Wi * g.Ci if not g.x_perm_n else None
+    y_el = g.N * g.To * g.Ho * g.Wo * g.Co
+    w_el = g.Co * g.kt * 16 * g.Ci
+    if w_el * 8 >= 1 << 31:
+        return False
+    if kind == 'fprop':
+        return p2(g.Ci, 16) and x_el is not None and x_el * 8 < 1 << 31
+    if kind == 'wgrad':                                             # both operands split; the LDS-DMA weight-gradient tiles' own limits
+        return (g.Co >= 128 and g.Co % 64 == 0 and p2(g.Ci, 64) and x_el is not None and x_el * 8 < 1 << 31 and y_el * 8 < 1 << 31
+                and (y_el // g.Co) % 16 == 0)
+    return p2(g.Co, 16) and p2(g.Ci, 64) and y_el * 8 < 1 << 31
+
+
+def split_pays(kind, g, run_plain, run_split):
+    """Which of the two forms of a launch is faster for this geometry -- the fp32-MFMA kernels on fp32 operands (run_plain) or the
+    split form on the bf16 pipe (run_split, INCLUDING whatever it takes to produce the split operands)?  Timed once per (pass,
+    geometry) like the tile candidates and kept in the same table (key 'split-<pass>', value 1 = split); MCG_SPLIT=always / never
+    overrides (tests, A/B timing).  Both forms write the same output; the caller launches the winner afterwards."""
+    mode = os.environ.get('MCG_SPLIT', 'auto')
+    if mode != 'auto':
+        return mode == 'always'
+    key = _geom_key('split-' + kind, g)
+    c = _tile_cache.get(key)
+    if c is None:
+        global _timing
+        saved, _timing = _timing, None
+        try:
+            best = {}
+            for name, fn in (('plain', run_plain), ('split', run_split)):
+                fn()
+                for _ in range(3):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    fn()
+                    fn()
+                    e1.record()
+                    e1.synchronize()
+                    ms = e0.elapsed_time(e1)
+                    best[name] = ms if name not in best else min(best[name], ms)
+            c = int(best['split'] < 0.97 * best['plain'])
+        finally:
+            _timing = saved
+        _tile_cache[key] = c
+    return bool(c)
+
+
 def _geom_key(kind, g, extra=()):
     return (kind, g.N, g.Ti, g.Hi, g.Wi, g.Ci, g.Co, g.kt, g.x_perm_n, g.precision) + tuple(extra)
 
@@ -320,6 +388,8 @@ def _tuned(kind, g, extra, out_side, run_on):
                     cands = cands + V2_CANDIDATES
                 elif g.Ho == 16 and g.Wo == 16:
                     cands = cands + (9,)                        # ... the patch-stationary kernel, four classes per block, is made for it
+            if g.precision == PREC_SPLIT:
+                cands = V2_CANDIDATES                           # (the LDS-DMA kernels are the only ones that multiply split operands)
             for cand in cands:
                 gg.tile = cand
                 try:
@@ -654,6 +724,18 @@ def adam_wd(p, g, m, v, lr_t, beta1, beta2, eps, wd, grad_scale=1.0, p16=None):
 def randint(out, modulus, seed, stream_id):
     """out (int32)[i] = Philox word i of the stream, modulo `modulus` (oracle.philox.randint states the same draw)"""
     _check(load().mcg_randint(out.numel(), int(modulus), seed, stream_id, _p(_dense(out), torch.int32), _stream()), "mcg_randint")
+
+
+def split_planes(src, run=16, out=None):
+    """fp32 tensor -> its MCG_PREC_SPLIT form (include/mocogan_hip.h: mcg_split_planes): per run of `run` values four runs of
+    bf16 (hi, mid, lo, zeros).  run = 16: channels-last tensors (last dimension a multiple of 16) -> last dimension x 4."""
+    src = _dense(src)
+    n = src.numel()
+    if out is None:
+        out = torch.empty(src.shape[:-1] + (4 * src.shape[-1],), device=src.device, dtype=torch.bfloat16)
+    assert out.numel() == 4 * n and out.dtype == torch.bfloat16
+    _check(load().mcg_split_planes(n, int(run), _p(src), _p(out, torch.bfloat16), _stream()), "mcg_split_planes")
+    return out
 
 
 def randn(out, sigma, seed, stream_id):

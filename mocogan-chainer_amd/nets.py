@@ -59,6 +59,10 @@ class FlatParams:
         self.m = torch.zeros_like(self.p)
         self.v = torch.zeros_like(self.p)
         self.p16 = None                 # bf16 copy of p (same offsets): the weight operand of the bf16-storage GEMMs
+        self.version = 0                # bumped by whatever writes p (touch): derived copies (the split filters of 'f32x3') follow it
+
+    def touch(self):
+        self.version += 1
 
     def _view(self, buf, name):
         o, s = self.offsets[name], self.shapes[name]
@@ -107,11 +111,91 @@ class _Net:
     # Layers whose channel counts are not multiples of 8 (the 4-channel clip side) keep fp32 tensors ('bf16' launches).
     precision = 'f32'
 
+    # 'f32x3': fp32 networks whose wide convolutions may run on the bf16 matrix pipe with fp32 accuracy -- operands split into
+    # three bf16 terms, six bf16 products per fp32 product (hl PREC_SPLIT, include/mocogan_hip.h).  Every tensor stays fp32; a
+    # launch that pays for it (hl.split_pays: timed once per geometry) splits its two operands on the way in.
     def set_precision(self, precision):
-        assert precision in ('f32', 'bf16')
+        assert precision in ('f32', 'bf16', 'f32x3')
         self.precision = precision
         if precision == 'bf16':
             self.fp.refresh16()
+
+    @property
+    def gemm_precision(self):
+        """what the geometries of this network's launches carry ('f32x3' launches are fp32 launches that MAY take the split form)"""
+        return 'f32' if self.precision == 'f32x3' else self.precision
+
+    def _wsplit(self, name, form):
+        """the split form of a filter: 'f' as the forward GEMM of a convolution reads it (groups of 16 input channels), 'd' as the
+        input-gradient GEMM does (planes of 16 filters).  Rebuilt when the parameters have changed since (FlatParams.version)."""
+        cache = self.__dict__.setdefault('_wsplits', {})
+        ent = cache.get((name, form))
+        if ent is None or ent[0] != self.fp.version:
+            w = self.fp.param(name)
+            run = 16 if form == 'f' else 16 * (w.numel() // w.shape[0])
+            cache[(name, form)] = ent = (self.fp.version, hl.split_planes(w, run=run, out=ent[1] if ent else None))
+        return ent[1]
+
+    def _cfprop(self, g, x, wname, w, b, y, ep=None, must_fuse=False, xs=None):
+        """hl.conv_fprop of this network (w = the filter operand the caller would pass; xs: callable returning the split form of x)"""
+        if self.precision == 'f32x3' and hl.split_covers('fprop', g):
+            gs = hl.with_precision(g, 'f32x3')
+
+            def plain():
+                return hl.conv_fprop(g, x, w, b, y, ep=ep, must_fuse=must_fuse)
+
+            def split():
+                return hl.conv_fprop(gs, xs() if xs else hl.split_planes(x), self._wsplit(wname, 'f'), b, y, ep=ep, must_fuse=True)
+            if hl.split_pays('fprop', g, plain, split):
+                return split()
+        return hl.conv_fprop(g, x, w, b, y, ep=ep, must_fuse=must_fuse)
+
+    @staticmethod
+    def _sp(store, key, t):
+        """the split form of tensor t, made once per (store, key): forward keeps what the weight gradient reads again"""
+        if store is None:
+            return hl.split_planes(t)
+        s = store.get(key)
+        if s is None:
+            s = store[key] = hl.split_planes(t)
+        return s
+
+    def _cwgrad(self, g, x, y, dw, xs=None, ys=None):
+        """self._wgrad (dw += ...); xs / ys: callables returning the split form of x / y"""
+        if self.precision == 'f32x3' and hl.split_covers('wgrad', g):
+            gs = hl.with_precision(g, 'f32x3')
+            xs = xs or (lambda: hl.split_planes(x))
+            ys = ys or (lambda: hl.split_planes(y))
+
+            def plain(out=None):
+                hl.conv_wgrad(g, x, y, self._wg_scratch(dw))
+
+            def split():
+                hl.conv_wgrad(gs, xs(), ys(), self._wg_scratch(dw))
+            if hl.split_pays('wgrad', g, plain, split):
+                return self._wgrad(gs, xs(), ys(), dw)
+        return self._wgrad(g, x, y, dw)
+
+    def _wg_scratch(self, dw):
+        """a stand-in for dw while the two forms of a weight gradient are timed (the launch ADDS into its output)"""
+        sc = self.__dict__.get('_wgs')
+        if sc is None or sc.numel() < dw.numel():
+            sc = self.__dict__['_wgs'] = torch.zeros(dw.numel(), device=dw.device)
+        return sc[:dw.numel()].view(dw.shape)
+
+    def _cdgrad(self, g, y, wname, w, b, x, ep=None, must_fuse=False, ys=None):
+        """hl.conv_dgrad of this network (no activation, not accumulating: the launches that have a split form)"""
+        if self.precision == 'f32x3' and hl.split_covers('dgrad', g):
+            gs = hl.with_precision(g, 'f32x3')
+
+            def plain():
+                return hl.conv_dgrad(g, y, w, b, x, ep=ep, must_fuse=must_fuse)
+
+            def split():
+                return hl.conv_dgrad(gs, ys() if ys else hl.split_planes(y), self._wsplit(wname, 'd'), b, x, ep=ep, must_fuse=True)
+            if hl.split_pays('dgrad', g, plain, split):
+                return split()
+        return hl.conv_dgrad(g, y, w, b, x, ep=ep, must_fuse=must_fuse)
 
     def _stored16(self, ci, co):
         """does a layer with these channel counts run on bf16-stored operands?"""
@@ -178,6 +262,7 @@ class _Net:
             v = _np_to(params[key], self.device)
             assert tuple(v.shape) == tuple(self.ref_shapes[key]), (key, v.shape, self.ref_shapes[key])
             self._set_from_ref(key, v)
+        self.fp.touch()
         if self.precision == 'bf16':
             self.fp.refresh16()
 
@@ -219,6 +304,8 @@ class _Net:
             setattr(self.fp, b, getattr(self.fp, b).to(device))
         if self.fp.p16 is not None:
             self.fp.p16 = self.fp.p16.to(device)
+        self.fp.touch()
+        self.__dict__.pop('_wsplits', None)
         self.running = {k: v.to(device) for k, v in self.running.items()}
         self.ws = self.ws.to(device)
         self._part = None
@@ -284,6 +371,7 @@ class DisNet(_Net):
             self._set_from_ref('dc%d/W' % l, _np_to(rng.normal(0, std, size=shape), self.device))
 
     def _set_from_ref(self, key, v, buf='p'):
+        self.fp.touch()
         if key.endswith('/W'):
             self.fp.view(buf, key).copy_(lay.conv_w_to_dev(v))
         elif key in self.running:
@@ -311,7 +399,7 @@ class DisNet(_Net):
     def _geom(self, l, n, x_stride0=None):
         t, h = self._extents(l)
         return hl.make_geom(n, t, h, h, lay.pad4(self.chans[l - 1]), self.chans[l], self.kt, x_stride0=x_stride0,
-                            precision='bf16s' if self._s16(l) else self.precision, ci_valid=self.chans[l - 1])
+                            precision='bf16s' if self._s16(l) else self.gemm_precision, ci_valid=self.chans[l - 1])
 
     # ---- forward ---------------------------------------------------------------------------
     def forward(self, n, first_input, noise=None, rng=None, update_stats=True):
@@ -347,7 +435,7 @@ class DisNet(_Net):
 
         fuse_stats = train and 'stats' in FUSE and self.sync_bn is None
         fuse_dc1 = 'dc1' in FUSE
-        saved = {'n': n, 'G': G, 'a': {}, 'y': {}, 'stats': {}, 'mask1': None}
+        saved = {'n': n, 'G': G, 'a': {}, 'y': {}, 'stats': {}, 'mask1': None, 'split': {}}
         t, h = self._extents(1)
         a = torch.empty((N, t, h, h, self.cp0), device=dev)
         for gi, grp in enumerate(groups):
@@ -386,10 +474,10 @@ class DisNet(_Net):
             if l >= 2 and fuse_stats:
                 part = self._part_buf(g, 'fprop', G)
                 ep = hl.epilogue(sums=hl.SUMS_STATS, groups=G, part=part, out_bf16=y16)
-                if not hl.conv_fprop(g, a, w, b, y, ep=ep):
+                if not self._cfprop(g, a, 'dc%d/W' % l, w, b, y, ep=ep, xs=lambda: self._sp(saved['split'], l, saved['a'][l])):
                     ep = None                                    # split-K tile: the stand-alone statistics pass below
             else:
-                hl.conv_fprop(g, a, w, b, y)
+                self._cfprop(g, a, 'dc%d/W' % l, w, b, y, xs=lambda: self._sp(saved['split'], l, saved['a'][l]))
             saved['y'][l] = y
             a = torch.empty_like(y, dtype=adt)
             if l >= 2:
@@ -496,6 +584,10 @@ class DisNet(_Net):
                     gg, yg = g[gi * n:(gi + 1) * n], y[gi * n:(gi + 1) * n]
                     hl.bn_act_bwd(m, co, gg, yg, None, None, hl.ACT_LRELU, gg, None, None, self.ws)
             # (l == 1 with a stored mask: dc2's input-gradient GEMM applied leaky_relu's backward in its epilogue)
+            gsp = {}                                             # 'f32x3': the split form of g, shared by the two GEMMs that read it
+
+            def gys():
+                return self._sp(gsp, 0, g)
             if param_grads:
                 if l == 1:
                     if pending is not None:
@@ -503,7 +595,7 @@ class DisNet(_Net):
                     else:
                         hl.colsum_acc(m * G, co, g, fp.grad('dc1/b'), self.ws)
                 # dc2..dc4 feed BatchNorm: sum_m gx == 0 exactly (see _Net.BIAS_NOTE), nothing to add
-                self._wgrad(geom, saved['a'][l], g, fp.grad('dc%d/W' % l))
+                self._cwgrad(geom, saved['a'][l], g, fp.grad('dc%d/W' % l), xs=lambda: self._sp(saved.get('split'), l, saved['a'][l]), ys=gys)
                 if l == 4 and on_late_bucket is not None:
                     self._after_wgrads(on_late_bucket)
             pending = None
@@ -516,16 +608,16 @@ class DisNet(_Net):
                 if l == 2 and mask1 is not None:
                     part = self._part_buf(geom, 'dgrad', 1) if param_grads else None
                     ep = hl.epilogue(mask_in=mask1, sums=hl.SUMS_COL if param_grads else hl.SUMS_NONE, groups=1, part=part)
-                    hl.conv_dgrad(geom, g, w, None, ga, ep=ep, must_fuse=True)
+                    self._cdgrad(geom, g, 'dc%d/W' % l, w, None, ga, ep=ep, must_fuse=True, ys=gys)
                     pending = (ep, part) if param_grads else None
                 elif l > 2 and fuse_bwd and not s16:
                     part = self._part_buf(geom, 'dgrad', G)
                     ep = hl.epilogue(sums=hl.SUMS_BN_BWD, groups=G, part=part, bn_y=saved['y'][l - 1], bn_stats=saved['stats'][l - 1],
                                      bn_act=hl.ACT_LRELU)
-                    if hl.conv_dgrad(geom, g, w, None, ga, ep=ep):
+                    if self._cdgrad(geom, g, 'dc%d/W' % l, w, None, ga, ep=ep, ys=gys):
                         pending = (ep, part)
                 else:
-                    hl.conv_dgrad(geom, g, w, None, ga)
+                    self._cdgrad(geom, g, 'dc%d/W' % l, w, None, ga, ys=gys)
                 g = ga
             elif gx is not None:
                 hl.conv_dgrad(gx_geom if gx_geom is not None else geom, g, fp.param('dc1/W'), None, gx,
@@ -593,6 +685,7 @@ class GenNet(_Net):
         return lay.gru_from_dev(self.fp.view(buf, 'g0'), self.dim_zm, self.dim_zl)
 
     def _set_from_ref(self, key, v, buf='p'):
+        self.fp.touch()
         if key.startswith('g0/'):
             self._gru_views(buf)[key].copy_(v)
         elif key.endswith('/W'):
@@ -622,7 +715,7 @@ class GenNet(_Net):
         clip n, time t): the (T,N)->(N,T) transpose of model/updater.py:102 costs nothing."""
         h = 4 << (l - 1)
         ci = lay.pad4(self.chans[l])
-        prec = 'bf16s' if self._s16(l) else self.precision
+        prec = 'bf16s' if self._s16(l) else self.gemm_precision
         if clip_order_n:
             T = frames // clip_order_n
             return hl.make_geom(frames, 1, h, h, ci, self.chans[l - 1], 1, x_stride0=T * h * h * ci,
@@ -661,7 +754,7 @@ class GenNet(_Net):
         fp = self.fp
         train = config.train
         hl.set_tag('G')
-        saved = {'n': n, 'draw': draw, 'y': {}, 'a': {}, 'stats': {}}
+        saved = {'n': n, 'draw': draw, 'y': {}, 'a': {}, 'stats': {}, 'split': {}}
         z = torch.empty((frames, dc + dz), device=dev)
         gsaved = torch.empty((T, n, 4 * dz), device=dev)
         hl.gru_seq_fwd(n, T, dz, dl, dc, fp.param('g0'), draw['h0'], draw['e'], draw['labels'], draw['zc'], z, gsaved)
@@ -712,10 +805,10 @@ class GenNet(_Net):
                 if fuse_stats:
                     part = self._part_buf(geom, 'dgrad', 1)
                     ep = hl.epilogue(sums=hl.SUMS_STATS, groups=1, part=part, out_bf16=y16)
-                    if hl.conv_dgrad(geom, a, w, b, y, ep=ep):
+                    if self._cdgrad(geom, a, 'dc%d/W' % (l + 1), w, b, y, ep=ep, ys=lambda: self._sp(saved['split'], l + 1, saved['a'][l + 1])):
                         pending = (ep, part)
                 else:
-                    hl.conv_dgrad(geom, a, w, b, y)
+                    self._cdgrad(geom, a, 'dc%d/W' % (l + 1), w, b, y, ys=lambda: self._sp(saved['split'], l + 1, saved['a'][l + 1]))
         x = torch.empty((n, T, IMG, IMG, self.cp_out), device=dev)
         g5 = self._geom(5, frames, clip_order_n=n)
         if hl.dgrad_c4_mfma_covers(g5):
@@ -768,7 +861,11 @@ class GenNet(_Net):
                 g = gy
             if l == 5:
                 hl.colsum_acc(m, ci, g, fp.grad('dc5/b'), self.ws)         # dc1..dc4 feed BatchNorm: exact zero
-            self._wgrad(geom, g, saved['a'][l], fp.grad('dc%d/W' % l))
+            gsp = {}                                             # 'f32x3': the split form of g, shared by the two GEMMs that read it
+
+            def gxs():
+                return self._sp(gsp, 0, g)
+            self._cwgrad(geom, g, saved['a'][l], fp.grad('dc%d/W' % l), xs=gxs, ys=lambda: self._sp(saved.get('split'), l, saved['a'][l]))
             if l == 2 and on_late_bucket is not None:
                 self._after_wgrads(on_late_bucket)
             wl = self._w('dc%d/W' % l, s16)
@@ -780,10 +877,10 @@ class GenNet(_Net):
                 part = self._part_buf(geom, 'fprop', 1)
                 ep = hl.epilogue(sums=hl.SUMS_BN_BWD, groups=1, part=part, bn_y=saved['y'][l - 1], bn_stats=[saved['stats'][l - 1]],
                                  bn_act=hl.ACT_RELU)
-                if hl.conv_fprop(geom, g, wl, None, ga, ep=ep):
+                if self._cfprop(geom, g, 'dc%d/W' % l, wl, None, ga, ep=ep, xs=gxs):
                     pending = (ep, part)
             else:
-                hl.conv_fprop(geom, g, wl, None, ga)
+                self._cfprop(geom, g, 'dc%d/W' % l, wl, None, ga, xs=gxs)
             g = ga
         c1 = self.chans[1]
         k1 = 16 * c1

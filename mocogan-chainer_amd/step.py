@@ -36,6 +36,7 @@ def adam_update(net, hyper, grad_scale=1.0):
     fp = net.fp
     hl.adam_wd(fp.p, fp.g, fp.m, fp.v, hyper.lr(net.t), hyper.beta1, hyper.beta2, hyper.eps, hyper.weight_decay, grad_scale,
                p16=fp.p16 if net.precision == 'bf16' else None)
+    fp.touch()
 
 
 class GradExchange:
@@ -86,7 +87,7 @@ class TrainStep:
         assert model in ('normal', 'cgan', 'infogan')
         self.model, self.gen, self.dis_i, self.dis_v = model, gen, dis_i, dis_v
         if precision is not None:                                 # 'f32' | 'bf16': MFMA operand type of every conv GEMM
-            assert precision in ('f32', 'bf16')
+            assert precision in ('f32', 'bf16', 'f32x3')
             for net in (gen, dis_i, dis_v):
                 net.set_precision(precision)
         self.hyper = hyper or {'image_gen': AdamHyper(), 'image_dis': AdamHyper(), 'video_dis': AdamHyper()}
@@ -265,7 +266,7 @@ class TrainStep:
             gx[:, t].add_(gxi[:, 0])                                 # the same two addends as the accumulating launch below
         else:
             dv.backward(s_fake_v, gv, False, gx=gx)                  # new D_V weights, old activations (Q5)
-            gi_geom = hl.make_geom(n, 1, H, W, cp, di.chans[1], 1, x_stride0=T * hw * cp, precision=di.precision, ci_valid=di.chans[0])
+            gi_geom = hl.make_geom(n, 1, H, W, cp, di.chans[1], 1, x_stride0=T * hw * cp, precision=di.gemm_precision, ci_valid=di.chans[0])
             di.backward(s_fake_i, gi, False, gx=gx[:, t], gx_geom=gi_geom, gx_accumulate=True)
         if cgan:
             gxg = torch.zeros_like(x_fake)

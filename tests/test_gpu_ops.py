@@ -949,6 +949,95 @@ def test_lds_dma_kernels_match_the_oracle(hl, case, tile, prec):
                       torch.zeros((32, 4, 4, 4, 16), device="cuda", dtype=odt), None, torch.zeros((2, 2, 8, 8, 32), device="cuda"))
 
 
+SPLIT_CASES = [(2, 7, 16, 64, 128, 4),      # 3-D, Ci = 64 (dgrad: the 256 x 64 tile)
+               (3, 1, 16, 128, 64, 1),      # ragged 256-row tile; Co = 64
+               (1, 5, 8, 256, 256, 4),      # long K, the 256 x 256 tile when asked for
+               (2, 1, 32, 16, 32, 1),       # the narrowest layer the split form admits (one group of 16 channels)
+               (5, 1, 8, 128, 512, 1)]
+
+
+def test_split_planes_are_an_exact_expansion(hl):
+    """mcg_split_planes: hi + mid + lo == v exactly (three bf16 terms carry the 24 bits of an fp32), each term the bf16 rounding of
+    what the terms before it left; both run lengths (channels-last groups of 16, planes of 16 filters)."""
+    torch.manual_seed(5)
+    v = torch.randn((37, 5, 48), device="cuda") * torch.logspace(-6, 6, 48, device="cuda")
+    v[0, 0, :4] = torch.tensor([0.0, -0.0, 1.0, -3.0e-39], device="cuda")
+    for run, shape in ((16, (37, 5, 3, 4, 16)), (16 * 5 * 3, None)):
+        s = hl.split_planes(v.view(37, 5 * 48) if shape is None else v, run=run)
+        if shape is None:
+            pl = s.view(37 * 240 // run, 4, run)                    # [run index][plane][position]
+            src = v.view(-1, run)
+            hi, mid, lo, z = (pl[:, i] for i in range(4))
+        else:
+            pl = s.view(shape)
+            src = v.view(37, 5, 3, 16)
+            hi, mid, lo, z = (pl[:, :, :, i] for i in range(4))
+        assert torch.equal(hi, src.to(torch.bfloat16))
+        r1 = src - hi.float()
+        assert torch.equal(mid, r1.to(torch.bfloat16))
+        r2 = r1 - mid.float()
+        assert torch.equal(lo, r2.to(torch.bfloat16)) and not z.float().any()
+        big = src.abs() > 1e-30                                      # (bf16 keeps fp32's exponent range: only subnormal leftovers are lost)
+        assert torch.equal((hi.double() + mid.double() + lo.double())[big], src.double()[big])
+
+
+@pytest.mark.parametrize("case", SPLIT_CASES)
+@pytest.mark.parametrize("tile", [0, 8])
+def test_split_fp32_products_match_the_oracle(hl, case, tile):
+    """MCG_PREC_SPLIT: fp32 operands as three bf16 terms, six bf16 products per fp32 product on the bf16 MFMA, fp32 accumulation --
+    forward, input gradient and weight gradient on full-mantissa fp32 inputs against the float64 oracle at the fp32 tolerances, and no worse than the
+    fp32-MFMA kernels on the same inputs (the dropped products are below 2^-24 of |a||b|)."""
+    N, Ti, H, Ci, Co, kt = case
+    rng = np.random.RandomState(9100 + SPLIT_CASES.index(case))
+    lay = L()
+    x = rng.uniform(-1, 1, (N, Ci, Ti, H, H)).astype(np.float32).astype(np.float64)
+    W = (rng.randn(Co, Ci, kt, 4, 4) * 0.1).astype(np.float32).astype(np.float64)
+    b = rng.randn(Co).astype(np.float32).astype(np.float64)
+    gy = rng.randn(N, Co, Ti - kt + 1, H // 2, H // 2).astype(np.float32).astype(np.float64)
+    y_ref = F.conv3d_fwd(x, W, b, (1, 2, 2), (0, 1, 1))
+    gx_ref, _, _ = F.conv3d_bwd(x, W, gy, (1, 2, 2), (0, 1, 1))
+    xd, wd, bd, gyd = lay.act_to_dev(dev(x)), lay.conv_w_to_dev(dev(W)), dev(b), lay.act_to_dev(dev(gy))
+    g = hl.make_geom(N, Ti, H, H, Ci, Co, kt, precision='f32x3')
+    g.tile = tile
+    g32 = hl.make_geom(N, Ti, H, H, Ci, Co, kt)
+    xs, ws, gys = hl.split_planes(xd), hl.split_planes(wd), hl.split_planes(gyd)
+    wsd = hl.split_planes(wd, run=16 * kt * 16 * Ci)
+    assert xs.shape[-1] == 4 * Ci and ws.shape[-1] == 4 * Ci and gys.shape[-1] == 4 * Co
+    yd = torch.full((N, g.To, g.Ho, g.Wo, Co), 3.0, device="cuda")
+    hl.conv_fprop(g, xs, ws, bd, yd)
+    y32 = torch.empty_like(yd)
+    hl.conv_fprop(g32, xd, wd, bd, y32)
+    err, err32 = rel_l2(lay.act_from_dev(yd, Co), y_ref), rel_l2(lay.act_from_dev(y32, Co), y_ref)
+    assert err < 2e-6 and err < 2 * err32 + 1e-7, (err, err32)
+    # statistics epilogue: the same output, the sums of it
+    part = torch.zeros(hl.epilogue_part_floats(g, 'fprop', 1), device="cuda")
+    ep = hl.epilogue(sums=hl.SUMS_STATS, groups=1, part=part)
+    y2 = torch.empty_like(yd)
+    assert hl.conv_fprop(g, xs, ws, bd, y2, ep=ep, must_fuse=True)
+    assert torch.equal(y2, yd)
+    sums = part[:ep.n_slots * ep.slot_stride].view(ep.n_slots, ep.slot_stride).double().sum(0)
+    v = y2.double().view(-1, Co)
+    assert torch.allclose(sums[:Co], v.sum(0), rtol=1e-5, atol=1e-3) and torch.allclose(sums[Co:2 * Co], (v * v).sum(0), rtol=1e-5, atol=1e-3)
+    if Ci >= 64:                                                    # input gradient: the LDS-DMA dgrad tiles need >= 64 output columns
+        gxd = torch.full((N, Ti, H, H, Ci), 7.0, device="cuda")
+        hl.conv_dgrad(g, gys, wsd, None, gxd)
+        gx32 = torch.empty_like(gxd)
+        hl.conv_dgrad(g32, gyd, wd, None, gx32)
+        err, err32 = rel_l2(lay.act_from_dev(gxd, Ci), gx_ref), rel_l2(lay.act_from_dev(gx32, Ci), gx_ref)
+        assert err < 2e-6 and err < 2 * err32 + 1e-7, (err, err32)
+    # weight gradient: the sum runs over pixels -- 16 pixels x 4 planes per K-step from the same split tensors; added onto dw
+    if Co >= 128 and Ci >= 64:
+        _, gW_ref, _ = F.conv3d_bwd(x, W, gy, (1, 2, 2), (0, 1, 1))
+        dwd, dw32 = torch.ones_like(wd), torch.ones_like(wd)
+        hl.conv_wgrad(g, xs, gys, dwd)
+        hl.conv_wgrad(g32, xd, gyd, dw32)
+        err, err32 = rel_l2(lay.conv_w_from_dev(dwd, Ci, 3), gW_ref + 1), rel_l2(lay.conv_w_from_dev(dw32, Ci, 3), gW_ref + 1)
+        assert err < 2e-6 and err < 2 * err32 + 1e-7, (err, err32)
+    else:
+        with pytest.raises(hl.McgError):                            # narrower layers keep the fp32 kernels
+            hl.conv_wgrad(g, xs, gys, torch.zeros_like(wd))
+
+
 PATCH_CASES = [(2, 7, 32, 64, 128, 4),       # D_V dc2's geometry (two clips)
                (3, 1, 32, 64, 128, 1),       # D_I dc2 / G dc4 (2-D)
                (1, 5, 32, 64, 64, 4),        # one y channel chunk

@@ -214,7 +214,7 @@ def perf_mode_stream_ids(it, rank):
     return [base + 8 * k + j for k in (0, 1, 3, 4) for j in range(4)] + [base + 16 + j for j in range(4)]
 
 
-def _run_steps(pkg, model, dim_zl, nf, n, steps, seed, min_tight_steps=1, overlap=False, perf=None):
+def _run_steps(pkg, model, dim_zl, nf, n, steps, seed, min_tight_steps=1, overlap=False, perf=None, precision=None):
     """Teacher-forced multi-step parity: before every iteration the device state (parameters, Adam
     moments and step counters, BN running statistics) is loaded from the oracle, so each iteration
     is compared on identical inputs and errors cannot compound through Adam's sign-like early steps.
@@ -236,7 +236,7 @@ def _run_steps(pkg, model, dim_zl, nf, n, steps, seed, min_tight_steps=1, overla
     G = nets.GenNet(dim_zl=dim_zl, n_filters=nf)
     DI = nets.DisNet(2, c_d, out_c, nf, use_noise=True)
     DV = nets.DisNet(3, c_d, out_c, nf, use_noise=True)
-    ts = step.TrainStep(model, G, DI, DV, overlap=overlap, **({'seed': perf[0], 'rank': perf[1]} if perf else {}))
+    ts = step.TrainStep(model, G, DI, DV, overlap=overlap, precision=precision, **({'seed': perf[0], 'rank': perf[1]} if perf else {}))
     og, oi, ov = (oupd.new_adam_state(q) for q in (gen, di, dv))
     tight_steps = 0
     for s in range(steps):
@@ -302,6 +302,18 @@ def test_update_core_with_side_streams(pkg):
     the same teacher-forced parity must hold."""
     _run_steps(pkg, "infogan", 6, nf=4, n=2, steps=3, seed=313, overlap=True)
     _run_steps(pkg, "normal", 6, nf=16, n=3, steps=2, seed=77, min_tight_steps=0, overlap=True)
+
+
+def test_update_core_with_split_fp32_convolutions(pkg, monkeypatch):
+    """precision 'f32x3': the wide convolutions' forward and input-gradient GEMMs on the bf16 matrix pipe, operands as three bf16
+    terms (six bf16 products per fp32 product, fp32 accumulation) -- an fp32 computation, held to the SAME tolerances as the
+    fp32-MFMA iteration.  MCG_SPLIT=always: every launch that has a split form takes it (no timing decides)."""
+    hl = pkg[0]
+    monkeypatch.setenv('MCG_SPLIT', 'always')
+    before = hl.split_launches
+    _run_steps(pkg, "normal", 6, nf=16, n=3, steps=2, seed=77, min_tight_steps=0, precision='f32x3')
+    _run_steps(pkg, "infogan", 6, nf=16, n=3, steps=2, seed=78, min_tight_steps=0, overlap=True, precision='f32x3')
+    assert hl.split_launches - before >= 2 * 2 * 8, "the split form did not run"
 
 
 PERF_CASES = [("normal", 0, 1303), ("normal", 6, 1311), ("infogan", 6, 1313), ("cgan", 6, 1320)]
@@ -371,7 +383,8 @@ def device_decisions(out, G, DI, DV):
 KINK_BAND = 1e-4     # |pre-activation| below which the device's branch is taken over (its own error there is ~1e-6)
 
 
-def test_update_core_full_width_with_the_devices_activation_decisions(pkg):
+@pytest.mark.parametrize("precision", ['f32', 'f32x3'])
+def test_update_core_full_width_with_the_devices_activation_decisions(pkg, precision, monkeypatch):
     """One iteration at the reference's width (n_filters = 64: the 128x128 tiles, the split-K weight gradients, K = 4096 ..
     16384) held to the TIGHT tolerances.  With ~2e7 pre-activations some always lie within fp32 rounding of their kink, where
     an fp32 implementation may take the other branch than float64 -- no seed avoids that (expected count within 2e-6 of a kink:
@@ -385,7 +398,9 @@ def test_update_core_full_width_with_the_devices_activation_decisions(pkg):
     di = _f64(onet.init_discriminator(rng, 2, 3, 7, nf))
     dv = _f64(onet.init_discriminator(rng, 3, 3, 7, nf))
     G, DI, DV = nets.GenNet(dim_zl=dim_zl, n_filters=nf), nets.DisNet(2, 3, 7, nf, use_noise=True), nets.DisNet(3, 3, 7, nf, use_noise=True)
-    ts = step.TrainStep(model, G, DI, DV)
+    monkeypatch.setenv('MCG_SPLIT', 'always')                      # ('f32x3': every launch that has a split form takes it)
+    split_before = hl.split_launches
+    ts = step.TrainStep(model, G, DI, DV, precision=precision)
     og, oi, ov = (oupd.new_adam_state(q) for q in (gen, di, dv))
     for net, p, st in ((G, gen, og), (DI, di, oi), (DV, dv, ov)):
         net.load_reference_params(p)
@@ -398,6 +413,7 @@ def test_update_core_full_width_with_the_devices_activation_decisions(pkg):
         inject[k] = noise_to_dev(lay, rnd[k])
     out = ts.run(dev(x_real), dev(t_real, torch.int32), inject)
     losses = ts.losses()
+    assert (hl.split_launches - split_before >= 24) == (precision == 'f32x3')
     kinks = device_decisions(out, G, DI, DV)
     kinks['eps'] = KINK_BAND
     ref = oupd.update_core(model, gen, di, dv, og, oi, ov, x_real, t_real, rnd, dim_zl=dim_zl, keep=True, kinks=kinks)

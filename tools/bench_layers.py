@@ -48,7 +48,8 @@ def main():
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--tile', type=int, default=0)
     ap.add_argument('--only', default='')
-    ap.add_argument('--precision', default='f32', choices=['f32', 'bf16', 'bf16s'])
+    ap.add_argument('--precision', default='f32', choices=['f32', 'bf16', 'bf16s', 'f32x3'])
+    ap.add_argument('--check', action='store_true', help='f32x3: also print the error of each pass against an fp64 convolution of a few output rows')
     ap.add_argument('--net', default='', help='restrict to layers whose name starts with this (e.g. D_V)')
     ap.add_argument('--layer', default='', help='restrict to layers whose name contains this (e.g. dc1)')
     ap.add_argument('--autotune', action='store_true', help='time the tile candidates per geometry first')
@@ -77,11 +78,19 @@ def main():
             if Ci % 8 or Co % 8:
                 continue
             xi, yi, wi = x.to(torch.bfloat16), y.to(torch.bfloat16), w.to(torch.bfloat16)
+        elif args.precision == 'f32x3':                     # fp32 values as three bf16 terms (fprop / dgrad; the split of the operands is not timed)
+            if Ci % 16 or Co % 16:
+                continue
+            xi, yi, wi = hl.split_planes(x), hl.split_planes(y), hl.split_planes(w)
+            wd = hl.split_planes(w, run=16 * kt * 16 * Ci)      # the filter as dgrad reads it: planes of 16 filters
         else:
             xi, yi, wi = x, y, w
-        for p, fn in (('fprop', lambda: hl.conv_fprop(g, xi, wi, None, y)),
-                      ('dgrad', lambda: hl.conv_dgrad(g, yi, wi, None, x)),
-                      ('wgrad', lambda: hl.conv_wgrad(g, xi, yi, dw))):
+        passes = [('fprop', lambda: hl.conv_fprop(g, xi, wi, None, y)),
+                  ('dgrad', lambda: hl.conv_dgrad(g, yi, wi, None, x)),
+                  ('wgrad', lambda: hl.conv_wgrad(g, xi, yi, dw))]
+        if args.precision == 'f32x3':
+            passes = [passes[0], ('dgrad', lambda: hl.conv_dgrad(g, yi, wd, None, x)), passes[2]]
+        for p, fn in passes:
             if args.only and p != args.only:
                 continue
             try:

@@ -182,6 +182,7 @@ def main(argv=None):
             net.t = int(cnt[0])
             for k, v in zip(names, cnt[1:]):
                 net.bn_count[k] = int(v)
+            net.fp.touch()
             if net.precision == 'bf16':
                 net.fp.refresh16()
 
