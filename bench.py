@@ -198,7 +198,9 @@ def main():
     ap.add_argument('--model', default='normal', choices=['normal', 'cgan', 'infogan'])
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16', 'f32x3'],
                     help="MFMA operand type of the conv GEMMs: f32 = BASELINE configs[1] (the headline); "
-                         "bf16 = configs[2] (use with --batch 256), fp32 accumulation / parameters / Adam")
+                         "bf16 = configs[2] (use with --batch 256), fp32 accumulation / parameters / Adam; "
+                         "f32x3 = configs[1] with the wide convolutions' fp32 products formed on the bf16 matrix pipe "
+                         "(operands as three bf16 terms, six bf16 products each: fp32 results)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--autotune', type=int, default=1,
                     help='1 (default): the first launch of each conv geometry times the 7 tile candidates once (warm-up)')
@@ -320,7 +322,8 @@ def main():
         value = B * world * steps / dt_best
         tot, f_fwd, f_wg, f_dg = dv_conv_flops_per_step(B)
         dv_ms = {k: timing.get('D_V.' + k, (0, 0.0)) for k in ('fprop', 'wgrad', 'dgrad')}
-        dv_total_ms = sum(v[1] for v in dv_ms.values()) / steps
+        dv_split_ms = timing.get('D_V.split', (0, 0.0))[1] / steps      # 'f32x3': the passes that split the GEMM operands count as GEMM time
+        dv_total_ms = sum(v[1] for v in dv_ms.values()) / steps + dv_split_ms
         achieved = tot / (dv_total_ms * 1e-3) / 1e12 if dv_total_ms > 0 else 0.0
         kern = {}
         for k, fl in (('fprop', f_fwd), ('wgrad', f_wg), ('dgrad', f_dg)):
@@ -342,6 +345,7 @@ def main():
         peak = PEAK_BF16_MFMA_TFLOPS if dtype == 'bf16' else PEAK_FP32_MFMA_TFLOPS
         cfg_name = "configs[2]" if (dtype == 'bf16' and B == 256 and model == 'normal') else \
             "configs[1]" if (dtype == 'f32' and B == 32 and model == 'normal') else \
+            "configs[1], fp32 products on the bf16 pipe" if (dtype == 'f32x3' and B == 32 and model == 'normal') else \
             "configs[3]" if (dtype == 'f32' and B == 32 and model == 'infogan') else \
             "configs[4]" if (B == 128 and world == 8 and model == 'normal') else "off-list variant of configs[1]"
         per_rank_ms = sorted(t / steps * 1e3 for t in per_rank)
@@ -361,9 +365,14 @@ def main():
                          "traffic_source": traffic_src,
                          "traffic_measured_in_run": False,      # PMC counters need rocprofv3 around the process: see traffic_source
                          "kernel": "VideoDiscriminator Conv3d implicit-GEMM family (%s<FpropP|DgradP|WgradP>), "
-                                   % ("gemm_kernel" if dtype == 'f32' else "gemm_bf16_kernel") +
+                                   % ("gemm_kernel" if dtype == 'f32' else "gemm_bf16_v2_kernel SPLIT / gemm_kernel" if dtype == 'f32x3' else "gemm_bf16_kernel") +
                                    "dc1..dc4, all launches of one step",
                          "algorithmic_gflop_per_step": tot / 1e9, "kernel_ms_per_step": dv_total_ms, "by_pass": kern,
+                         **({"operand_split_ms_per_step": dv_split_ms,
+                             "note": "fp32 products on the bf16 matrix pipe: operands as three bf16 terms, six bf16 MFMA products per "
+                                     "fp32 product (DESIGN.md); `peak` stays the fp32 MFMA peak for comparison with the f32 line -- "
+                                     "against the bf16 pipe the split launches execute 6x the algorithmic FLOPs",
+                             "frac_of_bf16_mfma_peak_executed": 6.0 * achieved / PEAK_BF16_MFMA_TFLOPS} if dtype == 'f32x3' else {}),
                          "all_conv_kernels_ms_per_step": all_conv_ms, "by_layer": by_layer,
                          "measured": "HIP events around every launch of the family during %d one-stream iterations "
                                      "(%.3f ms/step with the event records); the headline pass %s"
@@ -389,6 +398,8 @@ def main():
         if world == 1:
             secondary.append(measure('normal', 'bf16', 256, args.secondary_steps, 3, default_overlap('bf16', 256)))
             secondary.append(measure('infogan', 'f32', 32, args.secondary_steps, 3, default_overlap('f32', 32)))
+            # configs[1] again with the wide convolutions' fp32 products formed on the bf16 matrix pipe (three-term operands)
+            secondary.append(measure('normal', 'f32x3', 32, args.secondary_steps, 3, default_overlap('f32x3', 32)))
         elif world == 8:
             secondary.append(measure('normal', 'f32', 128, args.secondary_steps, 3, default_overlap('f32', 128)))
     if rank == 0 and args.save_tiles:

@@ -61,6 +61,8 @@ struct Geom {
     int tile, bk;      // caller's choice (mcg_conv_geom.tile): tile 0 = library heuristic, 1/2/3; bk 0 = heuristic, 32/64
     int ksplit;        // fprop / dgrad: number of K splits (1, 2 or 4) from mcg_conv_geom.tile / 1000
     int cv;            // channels of x that carry data (mcg_conv_geom.ci_valid; == Ci when unspecified)
+    int split;         // MCG_PREC_SPLIT launch (split_geom): every fourth 16-channel plane of the K dimension is zero and never
+                       // multiplied -- the LDS-DMA loaders leave its slots out of range instead of fetching zeros
 };
 
 // Fused epilogue of fprop / dgrad (mcg_conv_epilogue on the device side).  mode == 0: the plain store.
@@ -199,6 +201,12 @@ struct FpropP {
             int co = n0 + tid / KC4 + RSTEP * j;
             bbase[j] = co < g.Co ? (u32)(co * K + ak) * (u32)ESZ : OOB;
         }
+        if (E == 8 && g.split && (ak >> 4) == 3) {               // this thread's slots are the zero plane of a split operand
+#pragma unroll
+            for (int j = 0; j < NA; ++j) amask[j] = 0u;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) bbase[j] = OOB;
+        }
     }
     __device__ int k_begin(int z) const { return z * kchunk; }
     __device__ int k_end(int z) const { int e = (z + 1) * kchunk; return e < K ? e : K; }
@@ -254,10 +262,15 @@ struct FpropP {
         else if (kchunk >= K) y[ro + n] = v + (bias ? bias[n] : 0.f);
         else atomicAdd(y + ro + n, v + (bias && zz == 0 ? bias[n] : 0.f));
     }
-    // four / eight consecutive columns n .. of one row (the row-wise store of gemm_bf16_v2_kernel: never split-K)
+    // four / eight consecutive columns n .. of one row (the row-wise store of gemm_bf16_v2_kernel; split-K: added onto the cleared y)
     __device__ void store_vec4(long long ro, int n, f32x4 v, bool add_bias) const {
         if (ro < 0 || n >= g.Co) return;
-        if (add_bias && bias) v += *reinterpret_cast<const f32x4*>(bias + n);
+        if (add_bias && bias && (kchunk >= K || zz == 0)) v += *reinterpret_cast<const f32x4*>(bias + n);
+        if (kchunk < K) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) atomicAdd(y + ro + n + i, v[i]);
+            return;
+        }
         *reinterpret_cast<f32x4*>(y + ro + n) = v;
     }
     __device__ void store_vec8_bf16(long long ro, int n, f32x4 lo, f32x4 hi, bool add_bias) const {
@@ -349,6 +362,11 @@ struct DgradP {
         for (int j = 0; j < NB; ++j) {
             bkrow[j] = tid / C4 + (NT / C4) * j;
             bfast[j] = bok ? (u32)(bkrow[j] * g.taps * g.Ci + bci) * (u32)ESZ : OOB;
+            if (E == 8 && g.split && (bkrow[j] >> 4) == 3) bfast[j] = OOB;       // the zero plane of a split filter
+        }
+        if (E == 8 && g.split && (ak >> 4) == 3) {               // ... and of the split y rows
+#pragma unroll
+            for (int j = 0; j < NA; ++j) amask[j] = 0u;
         }
     }
     // LDS-DMA kernels (as FpropP::each_a / each_b; layers with Co a power of two and a multiple of BK)
@@ -453,6 +471,12 @@ struct DgradP {
     __device__ void store_vec4(long long ro, int n, f32x4 v, bool add_bias) const {
         if (ro < 0 || n >= g.Ci) return;
         const long long o = ro + n;
+        if (kchunk < K) {                          // split-K, as store_at
+            if (add_bias && bias && zsplit == 0) v += *reinterpret_cast<const f32x4*>(bias + n);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) atomicAdd(x + o + i, v[i]);
+            return;
+        }
         if (add_bias && bias) v += *reinterpret_cast<const f32x4*>(bias + n);
         if (act == MCG_ACT_TANH) { v[0] = tanhf(v[0]); v[1] = tanhf(v[1]); v[2] = tanhf(v[2]); v[3] = tanhf(v[3]); }
         if (accumulate) v += *reinterpret_cast<const f32x4*>(x + o);
@@ -1656,7 +1680,9 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
 // ------------------------------------------------------------------------------------------
 using DgPatchPol = DgradP<256, 64, 64, 8, true, NT2, true>;
 
-template <int EPI>
+// SPLIT: as gemm_bf16_v2_kernel -- y and the filter in the split layout (g.Co counts 4 x the channels: a 64-slot chunk of the patch is
+// 16 channels x 4 planes, a filter slice 4 planes x 16 filters), six products per chunk instead of four.
+template <int EPI, int SPLIT = 0>
 __global__ __launch_bounds__(NT2) void dgrad_patch_kernel(DgPatchPol p) {
     constexpr int PATCH = 48 * 1024, BSTG = 2 * 8192, LDS_TOTAL = 2 * PATCH + 4 * BSTG;      // two patches, a ring of four filter stages
     constexpr int PW = 18, NPIX = PW * PW;                                  // patch: 18 x 18 pixels of 128 bytes
@@ -1691,6 +1717,7 @@ __global__ __launch_bounds__(NT2) void dgrad_patch_kernel(DgPatchPol p) {
         const int h = py - 1, w_ = px - 1;
         const bool ok = pr < NPIX && (unsigned)h < (unsigned)g.Ho && (unsigned)w_ < (unsigned)g.Wo;
         poff[j] = ok ? (u32)(((h * g.Wo + w_) * g.Co + ((cp ^ ((pr >> 1) & 7)) << 3)) * 2) : OOB;
+        if (SPLIT && ((cp ^ ((pr >> 1) & 7)) >> 1) == 3) poff[j] = OOB;      // the zero plane: not fetched, never multiplied
     }
     auto issue_patch = [&](int s, int j0, int j1) {
         const int a = a_lo + s / CC, cc = s - (s / CC) * CC;
@@ -1701,7 +1728,7 @@ __global__ __launch_bounds__(NT2) void dgrad_patch_kernel(DgPatchPol p) {
             if (j >= j0 && j < j1) __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, MCG_LDSP(dst + j * 8192), 16, poff[j], so, 0, 0);
     };
     // ---- filter slices: thread = (co row tid / 8, chunk tid % 8) of a [64 co][64 ci] slice
-    const u32 boff = (u32)(((tid >> 3) * g.taps * g.Ci + (((tid & 7) ^ sw_cols(tid >> 3, 8)) << 3)) * 2);
+    const u32 boff = (SPLIT && (tid >> 7) == 3) ? OOB : (u32)(((tid >> 3) * g.taps * g.Ci + (((tid & 7) ^ sw_cols(tid >> 3, 8)) << 3)) * 2);
     auto issue_b = [&](int G) {                                  // stage G = 8 s + q, q = (pw, bh, bw): the two slices ph = 0, 1
         const int s = G >> 3, q = G & 7, pw = q >> 2, bh = (q >> 1) & 1, bw = q & 1;
         const int a = a_lo + s / CC, cc = s - (s / CC) * CC;
@@ -1765,6 +1792,33 @@ __global__ __launch_bounds__(NT2) void dgrad_patch_kernel(DgPatchPol p) {
             const int sw0 = (pr0 >> 1) & 7, sw1 = (pr1 >> 1) & 7;
             // (the filter fragments through the asm form of the transposing read: see tr16_issue; two k chunks in flight)
             const u32 bb32 = lds_addr(bb);
+            if constexpr (SPLIT) {
+                s16x4 slo[3][2], shi[3][2];
+                bf16x8 sa[3][2], sb[3][2];
+                static_for<0, 3>([&](auto pl_) {
+                    constexpr int pl = decltype(pl_)::value;
+                    sa[pl][0] = *reinterpret_cast<const bf16x8*>(ap0 + (((2 * pl + lh) ^ sw0) << 4));
+                    sa[pl][1] = *reinterpret_cast<const bf16x8*>(ap1 + (((2 * pl + lh) ^ sw1) << 4));
+                    tr16_issue<pl * 16 * 128, pl * 16 * 128 + 4 * 128>(slo[pl][0], shi[pl][0], bb32 + tb[0]);
+                    tr16_issue<pl * 16 * 128, pl * 16 * 128 + 4 * 128>(slo[pl][1], shi[pl][1], bb32 + tb[1]);
+                });
+                static_for<0, 3>([&](auto pl_) {
+                    constexpr int pl = decltype(pl_)::value;
+                    sb[pl][0] = tr16_wait<(2 - pl) * 4>(slo[pl][0], shi[pl][0]);
+                    sb[pl][1] = tr16_wait<(2 - pl) * 4>(slo[pl][1], shi[pl][1]);
+                });
+                static_for<0, 6>([&](auto c_) {
+                    constexpr int c = decltype(c_)::value;
+                    constexpr int pa = (c == 0 || c == 1 || c == 3) ? 0 : (c == 2 || c == 4) ? 1 : 2;
+                    constexpr int pb_ = (c == 0 || c == 2 || c == 5) ? 0 : (c == 1 || c == 4) ? 1 : 2;
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+                            acc[pw][a][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[pa][a], sb[pb_][i], acc[pw][a][i], 0, 0, 0);
+                });
+                return;
+            }
             s16x4 blo[2][2], bhi[2][2];
             tr16_issue<0, 4 * 128>(blo[0][0], bhi[0][0], bb32 + tb[0]);
             tr16_issue<0, 4 * 128>(blo[0][1], bhi[0][1], bb32 + tb[1]);
@@ -2589,6 +2643,7 @@ int make_geom(const mcg_conv_geom* c, Geom& g) {
     g.perm_n = c->x_perm_n; g.xs0 = c->x_stride0; g.xs1 = c->x_stride1;
     g.taps = c->kt * 16;
     g.prec = c->precision;
+    g.split = 0;
     if (c->ci_valid < 0 || c->ci_valid > c->Ci) return MCG_ERR_BAD_ARG;
     g.cv = c->ci_valid ? c->ci_valid : c->Ci;
     if (g.prec != MCG_PREC_F32 && g.prec != MCG_PREC_BF16 && g.prec != MCG_PREC_BF16_STORE && g.prec != MCG_PREC_SPLIT) return MCG_ERR_BAD_ARG;
@@ -2726,6 +2781,7 @@ bool v2_ok(const Geom& g, int kdim /* channel count along K: Ci (fprop), Co (dgr
 Geom split_geom(const Geom& g, bool on_ci) {
     Geom h = g;
     h.prec = MCG_PREC_BF16_STORE;
+    h.split = 1;
     const long long frame = (long long)g.Ti * g.Hi * g.Wi * g.Ci;
     const long long x_elems = (g.perm_n ? (long long)(g.perm_n - 1) * g.xs0 + (long long)(g.N / g.perm_n - 1) * g.xs1
                                         : (long long)(g.N - 1) * g.xs0) + frame;
@@ -2743,7 +2799,7 @@ bool split_ok(const Geom& g, bool on_ci) {
                                         : (long long)(g.N - 1) * g.xs0) + frame;
     const long long y_elems = (long long)g.N * g.To * g.Ho * g.Wo * g.Co;
     const long long w_elems = (long long)g.Co * g.taps * g.Ci;
-    return c >= 16 && (c & (c - 1)) == 0 && g.ksplit == 1 && (on_ci ? x_elems : y_elems) * 8 < (1ll << 31) && w_elems * 8 < (1ll << 31);
+    return c >= 16 && (c & (c - 1)) == 0 && (on_ci ? x_elems : y_elems) * 8 < (1ll << 31) && w_elems * 8 < (1ll << 31);
 }
 
 template <class K> int v2_set_lds(K kernel, size_t lds, std::once_flag& once) {
@@ -2765,11 +2821,20 @@ int launch_fprop_v2(const Geom& g, const float* x, const float* w, const float* 
     Pol p;
     p.g = g; p.e = e; p.x = x; p.w = w; p.bias = bias; p.y = y;
     p.M = g.N * g.To * g.Ho * g.Wo; p.K = g.taps * g.Ci;
-    p.kchunk = p.K;
+    // split-K (tile codes + 1000 / + 2000, plain launches only): the few tiles of a late layer on more CUs; partial tiles are added
+    // onto a cleared y
+    int splits = (e.mode || e.out16) ? 1 : g.ksplit;
+    const int ksteps = p.K / 64;
+    if (splits > ksteps / 16) splits = ksteps / 16;
+    if (splits < 1) splits = 1;
+    p.kchunk = ((ksteps + splits - 1) / splits) * 64;
+    splits = (p.K + p.kchunk - 1) / p.kchunk;
+    if (splits == 1) p.kchunk = p.K;
+    else if (hipMemsetAsync(y, 0, (size_t)p.M * g.Co * sizeof(float), s) != hipSuccess) return MCG_ERR_LAUNCH;
     if (ep) { ep->n_slots = (p.M + BM - 1) / BM; ep->slot_stride = e.slot_stride; }
     const int cls = e.mode ? epi_class(e.mode) : 0;
     if (cls > 1) return MCG_ERR_UNSUPPORTED;
-    const dim3 grid((p.M + BM - 1) / BM, (g.Co + BN - 1) / BN, 1);
+    const dim3 grid((p.M + BM - 1) / BM, (g.Co + BN - 1) / BN, splits);
     constexpr size_t lds = (size_t)STAGES * (BM + BN) * 128;
     if (cls == 0) MCG_V2_LAUNCH((gemm_bf16_v2_kernel<Pol, BM, BN, STAGES, 0, SPLIT>), grid, lds, p);
     else MCG_V2_LAUNCH((gemm_bf16_v2_kernel<Pol, BM, BN, STAGES, 1, SPLIT>), grid, lds, p);
@@ -2782,10 +2847,19 @@ int launch_dgrad_v2(const Geom& g, const float* y, const float* w, const float* 
     Pol p;
     p.g = g; p.e = e; p.y = y; p.w = w; p.bias = bias; p.x = x; p.act = act; p.accumulate = acc;
     p.M = g.N * g.Ti * g.Ho * g.Wo; p.K = g.kt * 4 * g.Co;
-    p.kchunk = p.K;
+    const long long frame = (long long)g.Ti * g.Hi * g.Wi * g.Ci;
+    const bool dense_x = !g.perm_n && g.xs0 == frame;
+    int splits = (act == MCG_ACT_NONE && (acc || dense_x) && !e.mode && !e.out16) ? g.ksplit : 1;       // (as launch_dgrad)
+    const int ksteps = p.K / 64;
+    if (splits > ksteps / 16) splits = ksteps / 16;
+    if (splits < 1) splits = 1;
+    p.kchunk = ((ksteps + splits - 1) / splits) * 64;
+    splits = (p.K + p.kchunk - 1) / p.kchunk;
+    if (splits == 1) p.kchunk = p.K;
+    else if (!acc && hipMemsetAsync(x, 0, (size_t)g.N * frame * sizeof(float), s) != hipSuccess) return MCG_ERR_LAUNCH;
     if (ep) { ep->n_slots = 4 * ((p.M + BM - 1) / BM); ep->slot_stride = e.slot_stride; }
     p.gxm = (p.M + BM - 1) / BM; p.gyn = (g.Ci + BN - 1) / BN; p.tiles8 = (p.gxm * p.gyn + 7) / 8;
-    const dim3 grid(8 * p.tiles8 * 4, 1, 1);
+    const dim3 grid(8 * p.tiles8 * 4 * splits, 1, 1);
     const int cls = e.mode ? epi_class(e.mode) : 0;
     if (cls > 1) return MCG_ERR_UNSUPPORTED;
     constexpr size_t lds = (size_t)STAGES * (BM + BN) * 128;
@@ -2822,6 +2896,7 @@ bool dgrad_patch_ok(const Geom& g) {
            (long long)g.N * g.Ti < (1ll << 24);
 }
 
+template <int SPLIT = 0>
 int launch_dgrad_patch(const Geom& g, const float* y, const float* w, const float* bias, float* x, int act, int acc, const Epi& e, mcg_conv_epilogue* ep, hipStream_t s) {
     DgPatchPol p;
     p.g = g; p.e = e; p.y = y; p.w = w; p.bias = bias; p.x = x; p.act = act; p.accumulate = acc;
@@ -2832,8 +2907,8 @@ int launch_dgrad_patch(const Geom& g, const float* y, const float* w, const floa
     if (cls > 1) return MCG_ERR_UNSUPPORTED;
     const dim3 grid(g.N * g.Ti);
     constexpr size_t lds = 2 * 48 * 1024 + 4 * 2 * 8192;
-    if (cls == 0) MCG_V2_LAUNCH((dgrad_patch_kernel<0>), grid, lds, p);
-    else MCG_V2_LAUNCH((dgrad_patch_kernel<1>), grid, lds, p);
+    if (cls == 0) MCG_V2_LAUNCH((dgrad_patch_kernel<0, SPLIT>), grid, lds, p);
+    else MCG_V2_LAUNCH((dgrad_patch_kernel<1, SPLIT>), grid, lds, p);
     return MCG_OK;
 }
 
@@ -3027,9 +3102,13 @@ int conv_dgrad_impl(const mcg_conv_geom* c, const float* y, const float* w, cons
     int t = g.tile;
     const int bk = g.bk;
     if (g.prec == MCG_PREC_SPLIT) {                              // fp32 values as three bf16 terms: the LDS-DMA kernels only
-        if ((t != 0 && t != 7 && t != 8) || !split_ok(g, false) || g.Ci < 64 || (g.Ci & (g.Ci - 1)) || (e.mode & ~(EPI_STATS | EPI_COL | EPI_MASKMUL)) || e.out16)
+        if ((t != 0 && t != 7 && t != 8 && t != 9) || !split_ok(g, false) || g.Ci < 64 || (g.Ci & (g.Ci - 1)) || (e.mode & ~(EPI_STATS | EPI_COL | EPI_MASKMUL)) || e.out16)
             return MCG_ERR_UNSUPPORTED;
         const Geom h = split_geom(g, false);
+        if (t == 9) {                                            // patch-stationary, four parity classes per block
+            if (!dgrad_patch_ok(h)) return MCG_ERR_UNSUPPORTED;
+            return finish(launch_dgrad_patch<1>(h, y, w, bias, x, act, accumulate, e, ep, s));
+        }
         if (g.Ci == 64) st = launch_dgrad_v2<256, 64, 3, 2, 1>(h, y, w, bias, x, act, accumulate, e, ep, s);
         else st = launch_dgrad_v2<256, 128, 3, 2, 1>(h, y, w, bias, x, act, accumulate, e, ep, s);     // (256x256 with three planes of fragments spills)
         return finish(st);

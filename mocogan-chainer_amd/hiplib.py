@@ -389,7 +389,10 @@ def _tuned(kind, g, extra, out_side, run_on):
                 elif g.Ho == 16 and g.Wo == 16:
                     cands = cands + (9,)                        # ... the patch-stationary kernel, four classes per block, is made for it
             if g.precision == PREC_SPLIT:
-                cands = V2_CANDIDATES                           # (the LDS-DMA kernels are the only ones that multiply split operands)
+                # (the LDS-DMA kernels are the only ones that multiply split operands; one 256-row block per CU: late layers need K splits)
+                cands = V2_CANDIDATES + ((1007, 2007) if kind in ("fprop", "dgrad") and out_elems <= (1 << 25) else ())
+                if kind == "dgrad" and g.Ci == 64 and g.Ho == 16 and g.Wo == 16:
+                    cands = cands + (9,)                        # the patch-stationary kernel (four parity classes per block)
             for cand in cands:
                 gg.tile = cand
                 try:
@@ -734,7 +737,14 @@ def split_planes(src, run=16, out=None):
     if out is None:
         out = torch.empty(src.shape[:-1] + (4 * src.shape[-1],), device=src.device, dtype=torch.bfloat16)
     assert out.numel() == 4 * n and out.dtype == torch.bfloat16
+    e0 = None
+    if _timing is not None:                                      # (bench.py's roofline leg charges the pass to the network's GEMMs)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _check(load().mcg_split_planes(n, int(run), _p(src), _p(out, torch.bfloat16), _stream()), "mcg_split_planes")
+    if e0 is not None:
+        e1.record()
+        _timing.setdefault(_tag + ".split", []).append((e0, e1))
     return out
 
 

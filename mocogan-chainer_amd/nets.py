@@ -145,7 +145,7 @@ class _Net:
                 return hl.conv_fprop(g, x, w, b, y, ep=ep, must_fuse=must_fuse)
 
             def split():
-                return hl.conv_fprop(gs, xs() if xs else hl.split_planes(x), self._wsplit(wname, 'f'), b, y, ep=ep, must_fuse=True)
+                return hl.conv_fprop(gs, xs() if xs else hl.split_planes(x), self._wsplit(wname, 'f'), b, y, ep=ep, must_fuse=must_fuse)
             if hl.split_pays('fprop', g, plain, split):
                 return split()
         return hl.conv_fprop(g, x, w, b, y, ep=ep, must_fuse=must_fuse)
@@ -192,7 +192,7 @@ class _Net:
                 return hl.conv_dgrad(g, y, w, b, x, ep=ep, must_fuse=must_fuse)
 
             def split():
-                return hl.conv_dgrad(gs, ys() if ys else hl.split_planes(y), self._wsplit(wname, 'd'), b, x, ep=ep, must_fuse=True)
+                return hl.conv_dgrad(gs, ys() if ys else hl.split_planes(y), self._wsplit(wname, 'd'), b, x, ep=ep, must_fuse=must_fuse)
             if hl.split_pays('dgrad', g, plain, split):
                 return split()
         return hl.conv_dgrad(g, y, w, b, x, ep=ep, must_fuse=must_fuse)

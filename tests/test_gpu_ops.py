@@ -982,7 +982,7 @@ def test_split_planes_are_an_exact_expansion(hl):
 
 
 @pytest.mark.parametrize("case", SPLIT_CASES)
-@pytest.mark.parametrize("tile", [0, 8])
+@pytest.mark.parametrize("tile", [0, 8, 2007])               # (2007: the K range of a tile over four blocks, partial tiles added)
 def test_split_fp32_products_match_the_oracle(hl, case, tile):
     """MCG_PREC_SPLIT: fp32 operands as three bf16 terms, six bf16 products per fp32 product on the bf16 MFMA, fp32 accumulation --
     forward, input gradient and weight gradient on full-mantissa fp32 inputs against the float64 oracle at the fp32 tolerances, and no worse than the
@@ -1009,6 +1009,9 @@ def test_split_fp32_products_match_the_oracle(hl, case, tile):
     hl.conv_fprop(g32, xd, wd, bd, y32)
     err, err32 = rel_l2(lay.act_from_dev(yd, Co), y_ref), rel_l2(lay.act_from_dev(y32, Co), y_ref)
     assert err < 2e-6 and err < 2 * err32 + 1e-7, (err, err32)
+    if tile >= 1000:                                                 # (the remaining checks -- fused epilogues, weight gradient -- have no K split;
+        g.tile = tile % 1000                                         #  partial tiles are added in another order: not bit for bit the unsplit y)
+        hl.conv_fprop(g, xs, ws, bd, yd)
     # statistics epilogue: the same output, the sums of it
     part = torch.zeros(hl.epilogue_part_floats(g, 'fprop', 1), device="cuda")
     ep = hl.epilogue(sums=hl.SUMS_STATS, groups=1, part=part)
@@ -1020,7 +1023,9 @@ def test_split_fp32_products_match_the_oracle(hl, case, tile):
     assert torch.allclose(sums[:Co], v.sum(0), rtol=1e-5, atol=1e-3) and torch.allclose(sums[Co:2 * Co], (v * v).sum(0), rtol=1e-5, atol=1e-3)
     if Ci >= 64:                                                    # input gradient: the LDS-DMA dgrad tiles need >= 64 output columns
         gxd = torch.full((N, Ti, H, H, Ci), 7.0, device="cuda")
+        g.tile = tile
         hl.conv_dgrad(g, gys, wsd, None, gxd)
+        g.tile = tile % 1000
         gx32 = torch.empty_like(gxd)
         hl.conv_dgrad(g32, gyd, wd, None, gx32)
         err, err32 = rel_l2(lay.act_from_dev(gxd, Ci), gx_ref), rel_l2(lay.act_from_dev(gx32, Ci), gx_ref)
@@ -1042,6 +1047,46 @@ PATCH_CASES = [(2, 7, 32, 64, 128, 4),       # D_V dc2's geometry (two clips)
                (3, 1, 32, 64, 128, 1),       # D_I dc2 / G dc4 (2-D)
                (1, 5, 32, 64, 64, 4),        # one y channel chunk
                (2, 4, 32, 64, 256, 4)]       # To = 1: every frame of x sees exactly one temporal tap
+
+
+@pytest.mark.parametrize("case", PATCH_CASES)
+def test_patch_stationary_input_gradient_split_fp32(hl, case):
+    """tile code 9 with MCG_PREC_SPLIT operands (fp32 values as three bf16 terms): full-mantissa inputs, the oracle at the fp32
+    tolerance and no worse than the fp32-MFMA kernels; bias + statistics, and the mask-multiply epilogue, on the same output."""
+    N, Ti, H, Ci, Co, kt = case
+    rng = np.random.RandomState(9200 + PATCH_CASES.index(case))
+    lay = L()
+    x = rng.uniform(-1, 1, (N, Ci, Ti, H, H))
+    W = (rng.randn(Co, Ci, kt, 4, 4) * 0.1).astype(np.float32).astype(np.float64)
+    gy = rng.randn(N, Co, Ti - kt + 1, H // 2, H // 2).astype(np.float32).astype(np.float64)
+    gx_ref, _, _ = F.conv3d_bwd(x, W, gy, (1, 2, 2), (0, 1, 1))
+    wd, gyd = lay.conv_w_to_dev(dev(W)), lay.act_to_dev(dev(gy))
+    gys, wsd = hl.split_planes(gyd), hl.split_planes(wd, run=16 * kt * 16 * Ci)
+    g = hl.make_geom(N, Ti, H, H, Ci, Co, kt, precision='f32x3')
+    g.tile = 9
+    gxd = torch.full((N, Ti, H, H, Ci), 7.0, device="cuda")
+    hl.conv_dgrad(g, gys, wsd, None, gxd)
+    gx32 = torch.empty_like(gxd)
+    hl.conv_dgrad(hl.make_geom(N, Ti, H, H, Ci, Co, kt), gyd, wd, None, gx32)
+    err, err32 = rel_l2(lay.act_from_dev(gxd, Ci), gx_ref), rel_l2(lay.act_from_dev(gx32, Ci), gx_ref)
+    assert err < 2e-6 and err < 2 * err32 + 1e-7, (err, err32)
+    b = dev(rng.randn(Ci))
+    part = torch.zeros(hl.epilogue_part_floats(g, 'dgrad', 1), device="cuda")
+    ep = hl.epilogue(sums=hl.SUMS_STATS, groups=1, part=part)
+    gxb = torch.empty_like(gxd)
+    assert hl.conv_dgrad(g, gys, wsd, b, gxb, ep=ep, must_fuse=True)
+    assert torch.equal(gxb, gxd + b)
+    sums = part[:ep.n_slots * ep.slot_stride].view(ep.n_slots, ep.slot_stride).double().sum(0)
+    v = gxb.double().view(-1, Ci)
+    assert torch.allclose(sums[:Ci], v.sum(0), rtol=1e-5, atol=1e-3) and torch.allclose(sums[Ci:2 * Ci], (v * v).sum(0), rtol=1e-5, atol=1e-3)
+    bits = torch.randint(0, 2, (N * Ti * H * H, Ci), device="cuda", dtype=torch.int64)
+    words = (bits.view(-1, Ci // 32, 32) << torch.arange(32, device="cuda")).sum(-1)
+    words = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32).contiguous()
+    part = torch.zeros(hl.epilogue_part_floats(g, 'dgrad', 1), device="cuda")
+    ep = hl.epilogue(mask_in=words, sums=hl.SUMS_COL, groups=1, part=part)
+    gxm = torch.empty_like(gxd)
+    assert hl.conv_dgrad(g, gys, wsd, None, gxm, ep=ep, must_fuse=True)
+    assert torch.equal(gxm.view(-1, Ci), gxd.view(-1, Ci) * torch.where(bits.bool(), 1.0, 0.2).float())
 
 
 @pytest.mark.parametrize("case", PATCH_CASES)

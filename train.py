@@ -55,8 +55,9 @@ def parse_args(argv=None):
                    help="colour planes of the clips: 3 = the reference's constant (train.py:49); 1 = grey-scale clips "
                         "(the Moving-MNIST shape 16x1x64x64; mnist and synthetic datasets)")
     # MI355X-path options (no counterpart in the reference's train.py)
-    p.add_argument('--mfma', choices=['f32', 'bf16'], default='f32',
-                   help="operand type of the convolution GEMMs (accumulation, parameters, Adam: always fp32)")
+    p.add_argument('--mfma', choices=['f32', 'bf16', 'f32x3'], default='f32',
+                   help="operand type of the convolution GEMMs (accumulation, parameters, Adam: always fp32); f32x3: fp32 products "
+                        "of the wide layers on the bf16 matrix pipe (operands as three bf16 terms, six bf16 products each)")
     p.add_argument('--overlap', type=int, default=1, help="side HIP streams for independent kernels")
     p.add_argument('--autotune', type=int, default=1, help="time the GEMM tile candidates once per layer geometry")
     p.add_argument('--sync_bn', type=int, default=0,
