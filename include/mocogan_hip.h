@@ -59,7 +59,7 @@ enum { MCG_PREC_F32 = 0, MCG_PREC_BF16 = 1,
         * products hi.hi + hi.mid + mid.hi + hi.lo + mid.mid + lo.hi, accumulated in fp32: what is dropped is below 2^-24 of
         * |a||b|, i.e. below the rounding of an fp32 accumulation.  The INPUT operands of the call are in the split layout
         * mcg_split_planes writes: along the channel dimension that the GEMM sums over (Ci of x and w for fprop, Co of y and
-        * w for dgrad) groups of 16 channels x 4 planes (hi, mid, lo, 0) of bf16, i.e. 4 * C uint16_t per pixel / filter row
+        * w for dgrad) groups of 16 channels x 4 planes (hi, mid, lo, padding) of bf16, i.e. 4 * C uint16_t per pixel / filter row
         * (for dgrad's w: 16 filters x 4 planes, see mcg_split_planes).
         * Outputs stay fp32.  LDS-DMA kernels only (tile 0, 7 or 8); channel counts along the sum powers of two >= 16. */
        MCG_PREC_SPLIT = 3 };
@@ -325,7 +325,8 @@ int mcg_randn(int64_t n, float sigma, uint64_t seed, uint64_t stream_id, float* 
  * element (m, c) is normal m & 3 of Philox counter (m >> 2) * C + c.  M % 4 == 0. */
 int mcg_randn_rowquad(int64_t M, int C, float sigma, uint64_t seed, uint64_t stream_id, float* out, void* stream);
 /* The split layout of MCG_PREC_SPLIT.  src is n fp32 values seen as consecutive runs of `run` values (run a multiple of 16,
- * n a multiple of run); dst gets, per run, four runs of bf16: hi, mid, lo (as above) and zeros -- 4 * n uint16_t in all.
+ * n a multiple of run); dst gets, per run, four runs of bf16: hi, mid, lo (as above) and one of padding that is neither written
+ * nor ever fetched by a MCG_PREC_SPLIT launch (it makes a group of 16 channels one 128-byte K-step) -- 4 * n uint16_t in all.
  *   run = 16                 : channels-last tensors [.. pixels][C] -> [.. pixels][C/16][4][16]   (the summed dimension of
  *                              x / y, and of w = [Co][taps][Ci] as fprop reads it);
  *   run = 16 * taps * Ci     : w as dgrad reads it -> [Co/16][4][16][taps][Ci] (the planes of 16 filters, filter by filter). */

@@ -1381,7 +1381,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // SPLIT (MCG_PREC_SPLIT: fp32 values as three bf16 terms, see mcg_split_planes): the operands' K dimension holds groups of 16
-// channels x 4 planes (hi, mid, lo, 0), i.e. the 128-byte K-step of a tile row is ONE group -- k chunk kc of the row is plane kc.
+// channels x 4 planes (hi, mid, lo, padding), i.e. the 128-byte K-step of a tile row is ONE group -- k chunk kc of the row is plane kc.
 // The MFMA phase then forms the six products hi.hi, hi.mid, mid.hi, hi.lo, mid.mid, lo.hi of a group (everything down to 2^-24
 // of the fp32 product) instead of the four chunk-by-chunk products of a bf16 K-step.  Loads, ring, images, epilogue: unchanged.
 template <class P, int BM, int BN, int STAGES, int EPI = 0, int SPLIT = 0>

@@ -982,7 +982,7 @@ bool unsupported_c(int C) { return (C >> 2) > NT || (NT % (C >> 2)) != 0; }
 
 // fp32 -> the three bf16 terms of MCG_PREC_SPLIT (include/mocogan_hip.h): hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid);
 // the differences are exact in fp32 and v == hi + mid + lo.  One thread: 8 consecutive values of a run -> one 16-byte piece of each
-// of the run's four planes (the fourth is zero).
+// of the run's three planes (the fourth, padding, is not written).
 __device__ __forceinline__ void split3(f32x8 v, bf16x8_t& hi, bf16x8_t& mid, bf16x8_t& lo) {
     hi = __builtin_convertvector(v, bf16x8_t);
     const f32x8 r1 = v - __builtin_convertvector(hi, f32x8);
@@ -997,8 +997,7 @@ __device__ __forceinline__ void store_split8(__bf16* dst, long long e, long long
     __bf16* d = dst + r * 4 * run + o;
     *reinterpret_cast<bf16x8_t*>(d) = hi;
     *reinterpret_cast<bf16x8_t*>(d + run) = mid;
-    *reinterpret_cast<bf16x8_t*>(d + 2 * run) = lo;
-    *reinterpret_cast<f32x4*>(d + 3 * run) = f32x4{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<bf16x8_t*>(d + 2 * run) = lo;        // (the fourth plane only pads a group to 128 bytes: no kernel fetches it)
 }
 __global__ __launch_bounds__(NT) void split_planes_kernel(long long n8, long long run, const float* __restrict__ src, __bf16* __restrict__ dst) {
     for (long long i = blockIdx.x * (long long)NT + threadIdx.x; i < n8; i += (long long)gridDim.x * NT)

@@ -731,7 +731,7 @@ def randint(out, modulus, seed, stream_id):
 
 def split_planes(src, run=16, out=None):
     """fp32 tensor -> its MCG_PREC_SPLIT form (include/mocogan_hip.h: mcg_split_planes): per run of `run` values four runs of
-    bf16 (hi, mid, lo, zeros).  run = 16: channels-last tensors (last dimension a multiple of 16) -> last dimension x 4."""
+    bf16 (hi, mid, lo, padding).  run = 16: channels-last tensors (last dimension a multiple of 16) -> last dimension x 4."""
     src = _dense(src)
     n = src.numel()
     if out is None:

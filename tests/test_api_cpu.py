@@ -163,15 +163,24 @@ def test_shipped_tile_table_is_well_formed():
     seen = set()
     for key, code in table:
         kind, N, Ti, Hi, Wi, Ci, Co, kt, perm, prec = key[:10]
-        base = 12 if kind == 'dgrad' else 10                                # dgrad keys carry (act, accumulate)
-        # bf16-stored geometries (fprop / dgrad) are tuned per launch form: + ('ep', sums, mask, bf16 output)  (hiplib._ep_key)
-        form = 4 if (prec == 2 and kind != 'wgrad') else 0
-        assert kind in ('fprop', 'dgrad', 'wgrad') and len(key) == base + form, key
-        assert all(isinstance(v, int) for v in key[1:base]) and (not form or (key[base] == 'ep' and all(isinstance(v, int) for v in key[base + 1:]))), key
-        assert Hi == Wi and Hi in (8, 16, 32, 64) and kt in (1, 4) and prec in (0, 1, 2) and Ci % 4 == 0 and N > 0
-        assert isinstance(code, int) and 0 <= code % 100 <= 9 and (code // 100) % 10 <= 2 and code // 1000 <= 2, code
-        assert code % 100 < 7 or (prec == 2 and code in (7, 8)) or (prec == 2 and code == 9 and kind == 'dgrad' and Ci == 64 and Hi == 32), (key, code)
-        # (7 / 8: the LDS-DMA kernels, 9: the patch-stationary input gradient -- bf16-stored operands, no K split)
+        assert Hi == Wi and Hi in (8, 16, 32, 64) and kt in (1, 4) and prec in (0, 1, 2, 3) and Ci % 4 == 0 and N > 0
+        if kind.startswith('split-'):
+            # 'f32x3' networks: does the split form (fp32 values as three bf16 terms, bf16 MFMA) of this fp32 launch pay?  (hiplib.split_pays)
+            assert kind[6:] in ('fprop', 'dgrad', 'wgrad') and len(key) == 10 and prec == 0 and code in (0, 1), (key, code)
+            assert all(isinstance(v, int) for v in key[1:])
+        else:
+            base = 12 if kind == 'dgrad' else 10                            # dgrad keys carry (act, accumulate)
+            # bf16-stored geometries (fprop / dgrad) are tuned per launch form: + ('ep', sums, mask, bf16 output)  (hiplib._ep_key)
+            form = 4 if (prec == 2 and kind != 'wgrad') else 0
+            assert kind in ('fprop', 'dgrad', 'wgrad') and len(key) == base + form, key
+            assert all(isinstance(v, int) for v in key[1:base]) and (not form or (key[base] == 'ep' and all(isinstance(v, int) for v in key[base + 1:]))), key
+            assert isinstance(code, int) and 0 <= code % 100 <= 9 and (code // 100) % 10 <= 2 and code // 1000 <= 2, code
+            # 7 / 8: the LDS-DMA kernels, 9: the patch-stationary input gradient -- bf16-stored operands (no K split) or split
+            # operands (prec 3: only these kernels; + 1000 / 2000 K splits of fprop / dgrad)
+            if prec == 3:
+                assert code % 1000 in (7, 8, 9) and (code < 1000 or kind != 'wgrad') and (code % 1000 != 9 or (kind == 'dgrad' and Ci == 64 and Hi == 32)), (key, code)
+            else:
+                assert code % 100 < 7 or (prec == 2 and code in (7, 8)) or (prec == 2 and code == 9 and kind == 'dgrad' and Ci == 64 and Hi == 32), (key, code)
         assert tuple(key) not in seen
         seen.add(tuple(key))
 

@@ -182,6 +182,24 @@ def test_two_rank_bf16_networks_with_synchronised_batchnorm():
             assert abs(res16[r][2][k] - res32[r][2][k]) < 5e-2, (r, k, res16[r][2][k], res32[r][2][k])
 
 
+def test_two_rank_split_fp32_networks(monkeypatch):
+    """precision 'f32x3' under data parallelism: the replicas stay bit-identical (every rank takes the same launch forms:
+    MCG_SPLIT=always here, rank 0's table in train.py / bench.py) and the losses agree with the fp32-MFMA run of the same shards to
+    fp32 rounding -- the split form is an fp32 computation."""
+    monkeypatch.setenv('MCG_SPLIT', 'always')
+    res3 = _run_ranks(False, 39600, precision='f32x3', nf=16)
+    monkeypatch.setenv('MCG_SPLIT', 'never')
+    res32 = _run_ranks(False, 41600, precision='f32', nf=16)
+    for name in ('gen', 'di', 'dv'):
+        for k, v in res3[0][1][name].items():
+            if 'avg_' in k or k.endswith('/N'):
+                continue
+            assert np.array_equal(v, res3[1][1][name][k]), (name, k)
+    for r in range(2):
+        for k in res3[r][2]:
+            assert abs(res3[r][2][k] - res32[r][2][k]) < 1e-4, (r, k, res3[r][2][k], res32[r][2][k])
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs two GPUs (the driver's multi-GPU node)")
 def test_two_rank_rccl_matches_the_sharded_oracle():
     """The same parity over the nccl backend (= RCCL over xGMI), one GPU per rank: covers what gloo cannot -- the

@@ -23,6 +23,11 @@ def short(name):
         if kind == 'v2':
             kind = 'v2.f32' if m.group(6) == '4' else 'v2.bf16'
         epi = re.search(r'>, \d+, \d+, (\d+), (\d+)>', name)
+        m5 = re.search(r'>, \d+, \d+, (\d+), (\d+), (\d+)>', name)          # ..., STAGES, EPI, SPLIT>
+        if m5:
+            epi = m5
+            if m5.group(3) == '1':
+                kind = 'v2.f32x3'
         return '%s %s %sx%sx%s%s' % (kind, m.group(2), m.group(3), m.group(4), m.group(5), (' e' + epi.group(2)) if epi and epi.group(2) != '0' else '')
     m = re.search(r'(\w+_c4\w*_kernel)', name)
     return m.group(1) if m else None
