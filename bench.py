@@ -402,6 +402,7 @@ def main():
             secondary.append(measure('normal', 'f32x3', 32, args.secondary_steps, 3, default_overlap('f32x3', 32)))
         elif world == 8:
             secondary.append(measure('normal', 'f32', 128, args.secondary_steps, 3, default_overlap('f32', 128)))
+            secondary.append(measure('normal', 'f32x3', 128, args.secondary_steps, 3, default_overlap('f32x3', 128)))
     if rank == 0 and args.save_tiles:
         hl.save_tile_choices(args.save_tiles)
     if rank == 0:
