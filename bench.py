@@ -373,7 +373,9 @@ def main():
                                      "fp32 product (DESIGN.md); `peak` stays the fp32 MFMA peak for comparison with the f32 line -- "
                                      "against the bf16 pipe the split launches execute 6x the algorithmic FLOPs",
                              "frac_of_bf16_mfma_peak_executed": 6.0 * achieved / PEAK_BF16_MFMA_TFLOPS} if dtype == 'f32x3' else {}),
-                         "all_conv_kernels_ms_per_step": all_conv_ms, "by_layer": by_layer,
+                         "all_conv_kernels_ms_per_step": all_conv_ms,
+                         "by_network_and_pass_ms_per_step": {k: v[1] / steps for k, v in sorted(timing.items()) if ' N=' not in k},
+                         "by_layer": by_layer,
                          "measured": "HIP events around every launch of the family during %d one-stream iterations "
                                      "(%.3f ms/step with the event records); the headline pass %s"
                                      % (steps, dt_serial_instr / steps * 1e3,

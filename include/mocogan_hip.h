@@ -48,7 +48,12 @@ enum { MCG_ACT_NONE = 0, MCG_ACT_RELU = 1, MCG_ACT_LRELU = 2, MCG_ACT_TANH = 3 }
 /* MFMA operand type of the convolution GEMMs.  Tensors are fp32 in memory either way and products are
  * accumulated in fp32; MCG_PREC_BF16 rounds both operands to bf16 (round-to-nearest-even) inside the
  * kernel and multiplies them on v_mfma_f32_32x32x16_bf16 (BASELINE config "bf16 MFMA tiles"). */
-enum { MCG_IO_OUT_BF16 = 1, MCG_IO_Y_BF16 = 2, MCG_IO_G_BF16 = 4 };   /* which tensors of an element-wise call are bf16 (see mcg_bn_act_fwd) */
+enum { MCG_IO_OUT_BF16 = 1, MCG_IO_Y_BF16 = 2, MCG_IO_G_BF16 = 4,   /* which tensors of an element-wise call are bf16 (see mcg_bn_act_fwd) */
+       /* the OUTPUT of mcg_bn_act_fwd / the mcg_bn_act_bwd family is written in the split layout of MCG_PREC_SPLIT (mcg_split_planes
+        * with run = 16: 4 * M * C uint16_t) instead of fp32 -- what 'f32x3' networks do when every reader of the tensor is a split
+        * launch.  Dense y, every channel valid, C a multiple of 16 (and of the widths the eight-channel kernels take), fp32 y / g_out;
+        * MCG_ERR_UNSUPPORTED otherwise. */
+       MCG_IO_OUT_SPLIT = 8 };
 enum { MCG_PREC_F32 = 0, MCG_PREC_BF16 = 1,
        /* as MCG_PREC_BF16, with the INPUT operands of the call (x and w for fprop, y and w for dgrad, x and y for wgrad)
         * already bf16 in memory (uint16_t, round-to-nearest-even of the fp32 values): they are loaded and staged as they
@@ -90,6 +95,10 @@ typedef struct mcg_conv_geom {
                                 * 9 = mcg_conv_dgrad only, bf16-stored operands, Ci = 64 and a 16 x 16 small side (D's dc2,
                                 * G's dc4): one block per frame computes all four output-parity classes from a y patch held
                                 * in LDS (each y pixel is loaded once per temporal tap instead of once per class and tap);
+                                * 10 = the LDS-DMA kernels with a 128x128 tile and two tile buffers: TWO blocks per CU (bf16-stored
+                                * or MCG_PREC_SPLIT operands; dgrad: Ci >= 128; wgrad: Co >= 128) -- fewer FLOP per LDS byte, but the
+                                * epilogue of one block runs under the K loop of the other and small launches divide evenly;
+                                * MCG_PREC_SPLIT launches accept 0 / 7 / 8 / 10 (+ 1000 / 2000 in fprop and dgrad) and, in dgrad, 9;
                                 * +100 / +200 also fixes the K-step depth to 32 / 64; +1000 / +2000
                                 * makes mcg_conv_fprop / mcg_conv_dgrad split the K range over 2 / 4 blocks per tile
                                 * (partial tiles are added atomically onto a cleared output; for long-K layers with

@@ -2647,7 +2647,7 @@ int make_geom(const mcg_conv_geom* c, Geom& g) {
     if (c->ci_valid < 0 || c->ci_valid > c->Ci) return MCG_ERR_BAD_ARG;
     g.cv = c->ci_valid ? c->ci_valid : c->Ci;
     if (g.prec != MCG_PREC_F32 && g.prec != MCG_PREC_BF16 && g.prec != MCG_PREC_BF16_STORE && g.prec != MCG_PREC_SPLIT) return MCG_ERR_BAD_ARG;
-    if (c->tile < 0 || c->tile % 100 > 9 || (c->tile / 100) % 10 > 2 || c->tile / 1000 > 2) return MCG_ERR_BAD_ARG;
+    if (c->tile < 0 || c->tile % 100 > 10 || (c->tile / 100) % 10 > 2 || c->tile / 1000 > 2) return MCG_ERR_BAD_ARG;
     g.tile = c->tile % 100; g.bk = ((c->tile / 100) % 10) * 32; g.ksplit = 1 << (c->tile / 1000);
     g.lgHo = ilog2_exact(g.Ho); g.lgWo = ilog2_exact(g.Wo);
     g.lgCi = ilog2_exact(g.Ci); g.lgCo = ilog2_exact(g.Co);
@@ -3010,9 +3010,10 @@ int conv_fprop_impl(const mcg_conv_geom* c, const float* x, const float* w, cons
     int t = g.tile;
     const int bk = g.bk;
     if (g.prec == MCG_PREC_SPLIT) {                                // fp32 values as three bf16 terms: the LDS-DMA kernels only
-        if ((t != 0 && t != 7 && t != 8) || !split_ok(g, true) || (e.mode & ~(EPI_STATS | EPI_COL | EPI_MASKMUL)) || e.out16) return MCG_ERR_UNSUPPORTED;
+        if ((t != 0 && t != 7 && t != 8 && t != 10) || !split_ok(g, true) || (e.mode & ~(EPI_STATS | EPI_COL | EPI_MASKMUL)) || e.out16) return MCG_ERR_UNSUPPORTED;
         const Geom h = split_geom(g, true);
-        st = (t == 8 && g.Co >= 256) ? launch_fprop_v2<256, 256, 2, 2, 1>(h, x, w, bias, y, e, ep, s) : launch_fprop_v2<256, 128, 3, 2, 1>(h, x, w, bias, y, e, ep, s);
+        if (t == 10) st = launch_fprop_v2<128, 128, 2, 2, 1>(h, x, w, bias, y, e, ep, s);        // two blocks per CU
+        else st = (t == 8 && g.Co >= 256) ? launch_fprop_v2<256, 256, 2, 2, 1>(h, x, w, bias, y, e, ep, s) : launch_fprop_v2<256, 128, 3, 2, 1>(h, x, w, bias, y, e, ep, s);
         return finish(st);
     }
     if ((t == 0 || t == 6) && c4_fprop_ok(g, e)) {                 // the 3-channel clip padded to 4: weight-stationary kernel
@@ -3027,8 +3028,12 @@ int conv_fprop_impl(const mcg_conv_geom* c, const float* x, const float* w, cons
         return finish(st);
     }
     if (t == 6 || t == 9) return MCG_ERR_UNSUPPORTED;
-    if (t == 7 || t == 8) {                                        // the LDS-DMA kernels (bf16-stored operands, wide layers)
+    if (t == 7 || t == 8 || t == 10) {                             // the LDS-DMA kernels (bf16-stored operands, wide layers)
         if (!v2_ok(g, g.Ci) || e.mode & ~(EPI_STATS | EPI_COL | EPI_MASKMUL)) return MCG_ERR_UNSUPPORTED;
+        if (t == 10) {                                             // 128x128, two buffers: TWO blocks per CU
+            if (g.prec != MCG_PREC_BF16_STORE) return MCG_ERR_UNSUPPORTED;
+            return finish(launch_fprop_v2<128, 128, 2, 2>(g, x, w, bias, y, e, ep, s));
+        }
         if (g.prec == MCG_PREC_F32)
             st = t == 7 ? launch_fprop_v2<256, 128, 3, 0>(g, x, w, bias, y, e, ep, s) : launch_fprop_v2<256, 256, 2, 0>(g, x, w, bias, y, e, ep, s);
         else
@@ -3102,12 +3107,16 @@ int conv_dgrad_impl(const mcg_conv_geom* c, const float* y, const float* w, cons
     int t = g.tile;
     const int bk = g.bk;
     if (g.prec == MCG_PREC_SPLIT) {                              // fp32 values as three bf16 terms: the LDS-DMA kernels only
-        if ((t != 0 && t != 7 && t != 8 && t != 9) || !split_ok(g, false) || g.Ci < 64 || (g.Ci & (g.Ci - 1)) || (e.mode & ~(EPI_STATS | EPI_COL | EPI_MASKMUL)) || e.out16)
+        if ((t != 0 && t != 7 && t != 8 && t != 9 && t != 10) || !split_ok(g, false) || g.Ci < 64 || (g.Ci & (g.Ci - 1)) || (e.mode & ~(EPI_STATS | EPI_COL | EPI_MASKMUL)) || e.out16)
             return MCG_ERR_UNSUPPORTED;
         const Geom h = split_geom(g, false);
         if (t == 9) {                                            // patch-stationary, four parity classes per block
             if (!dgrad_patch_ok(h)) return MCG_ERR_UNSUPPORTED;
             return finish(launch_dgrad_patch<1>(h, y, w, bias, x, act, accumulate, e, ep, s));
+        }
+        if (t == 10) {                                           // 128x128, two blocks per CU
+            if (g.Ci < 128) return MCG_ERR_UNSUPPORTED;
+            return finish(launch_dgrad_v2<128, 128, 2, 2, 1>(h, y, w, bias, x, act, accumulate, e, ep, s));
         }
         if (g.Ci == 64) st = launch_dgrad_v2<256, 64, 3, 2, 1>(h, y, w, bias, x, act, accumulate, e, ep, s);
         else st = launch_dgrad_v2<256, 128, 3, 2, 1>(h, y, w, bias, x, act, accumulate, e, ep, s);     // (256x256 with three planes of fragments spills)
@@ -3128,9 +3137,13 @@ int conv_dgrad_impl(const mcg_conv_geom* c, const float* y, const float* w, cons
         if (!dgrad_patch_ok(g) || (e.mode & ~(EPI_STATS | EPI_COL | EPI_MASKMUL))) return MCG_ERR_UNSUPPORTED;
         return finish(launch_dgrad_patch(g, y, w, bias, x, act, accumulate, e, ep, s));
     }
-    if (t == 7 || t == 8) {                                      // the LDS-DMA kernels (bf16-stored operands, wide layers)
+    if (t == 7 || t == 8 || t == 10) {                           // the LDS-DMA kernels (bf16-stored operands, wide layers)
         const long long frame_ = (long long)g.Ti * g.Hi * g.Wi * g.Ci;
         if (!v2_ok(g, g.Co) || g.Ci < 64 || (g.Ci & (g.Ci - 1)) || (e.mode & ~(EPI_STATS | EPI_COL | EPI_MASKMUL))) return MCG_ERR_UNSUPPORTED;
+        if (t == 10) {                                           // 128x128, two blocks per CU
+            if (g.prec != MCG_PREC_BF16_STORE || g.Ci < 128) return MCG_ERR_UNSUPPORTED;
+            return finish(launch_dgrad_v2<128, 128, 2, 2>(g, y, w, bias, x, act, accumulate, e, ep, s));
+        }
         (void)frame_;
 #define MCG_DG2(PM_) do {                                                                                              \
             if (g.Ci == 64) st = launch_dgrad_v2<256, 64, 3, PM_>(g, y, w, bias, x, act, accumulate, e, ep, s);                 \
@@ -3179,10 +3192,11 @@ extern "C" int mcg_conv_wgrad(const mcg_conv_geom* c, const float* x, const floa
         const long long x_el = (g.perm_n ? (long long)(g.perm_n - 1) * g.xs0 + (long long)(g.N / g.perm_n - 1) * g.xs1 : (long long)(g.N - 1) * g.xs0) +
                                (long long)g.Ti * g.Hi * g.Wi * g.Ci;
         const long long y_el = (long long)g.N * g.To * g.Ho * g.Wo * g.Co;
-        if ((g.tile != 0 && g.tile != 7 && g.tile != 8) || g.Co < 128 || (g.Co & 63) || g.Ci < 64 || (g.Ci & (g.Ci - 1)) || g.ksplit != 1 ||
+        if ((g.tile != 0 && g.tile != 7 && g.tile != 8 && g.tile != 10) || g.Co < 128 || (g.Co & 63) || g.Ci < 64 || (g.Ci & (g.Ci - 1)) || g.ksplit != 1 ||
             x_el * 8 >= (1ll << 31) || y_el * 8 >= (1ll << 31) || (y_el / g.Co) % 16) return MCG_ERR_UNSUPPORTED;
         Geom h = g;
         h.prec = MCG_PREC_BF16_STORE; h.x_bytes = (u32)(x_el * 8); h.y_bytes = (u32)(y_el * 8);
+        if (g.tile == 10) return finish(launch_wgrad_v2<128, 128, 2, 2, 1>(h, x, y, dw, (hipStream_t)stream));      // two blocks per CU
         st = (g.Co == 128 || g.tile != 8) ? launch_wgrad_v2<128, 256, 3, 2, 1>(h, x, y, dw, (hipStream_t)stream)
                                           : launch_wgrad_v2<256, 256, 2, 2, 1>(h, x, y, dw, (hipStream_t)stream);
         return finish(st);
@@ -3200,8 +3214,12 @@ extern "C" int mcg_conv_wgrad(const mcg_conv_geom* c, const float* x, const floa
         return finish(st);
     }
     if (t == 6 || t == 9) return MCG_ERR_UNSUPPORTED;
-    if (t == 7 || t == 8) {                                      // the LDS-DMA kernels: 128x256 (Co = 128) or 256x256
+    if (t == 7 || t == 8 || t == 10) {                           // the LDS-DMA kernels: 128x256 (Co = 128) or 256x256; 10: 128x128, two blocks per CU
         if ((g.prec != MCG_PREC_BF16_STORE && g.prec != MCG_PREC_F32) || g.Co < 128 || (g.Co & 63) || g.Ci < 64 || (g.Ci & (g.Ci - 1))) return MCG_ERR_UNSUPPORTED;
+        if (t == 10) {
+            if (g.prec != MCG_PREC_BF16_STORE) return MCG_ERR_UNSUPPORTED;
+            return finish(launch_wgrad_v2<128, 128, 2, 2>(g, x, y, dw, s));
+        }
         if (g.prec == MCG_PREC_F32) {
             if (g.Co == 128 || t == 7) st = launch_wgrad_v2<128, 256, 3, 0>(g, x, y, dw, s);
             else st = launch_wgrad_v2<256, 256, 2, 0>(g, x, y, dw, s);

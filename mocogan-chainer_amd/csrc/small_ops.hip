@@ -41,7 +41,28 @@ __device__ __forceinline__ f32x8 load8(const float* in, long long e, int in16) {
     const f32x4 a = *reinterpret_cast<const f32x4*>(in + e), b = *reinterpret_cast<const f32x4*>(in + e + 4);
     return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
-__device__ __forceinline__ void store8(float* out, long long e, f32x8 v, int out16) {
+// fp32 -> the three bf16 terms of MCG_PREC_SPLIT (include/mocogan_hip.h): hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid);
+// the differences are exact in fp32 and v == hi + mid + lo.  One thread: 8 consecutive values of a run -> one 16-byte piece of each
+// of the run's three planes (the fourth, padding, is not written).
+__device__ __forceinline__ void split3(f32x8 v, bf16x8_t& hi, bf16x8_t& mid, bf16x8_t& lo) {
+    hi = __builtin_convertvector(v, bf16x8_t);
+    const f32x8 r1 = v - __builtin_convertvector(hi, f32x8);
+    mid = __builtin_convertvector(r1, bf16x8_t);
+    const f32x8 r2 = r1 - __builtin_convertvector(mid, f32x8);
+    lo = __builtin_convertvector(r2, bf16x8_t);
+}
+__device__ __forceinline__ void store_split8(__bf16* dst, long long e, long long run, f32x8 v) {      // e: index of the first of 8 source values
+    bf16x8_t hi, mid, lo;
+    split3(v, hi, mid, lo);
+    const long long r = e / run, o = e - r * run;
+    __bf16* d = dst + r * 4 * run + o;
+    *reinterpret_cast<bf16x8_t*>(d) = hi;
+    *reinterpret_cast<bf16x8_t*>(d + run) = mid;
+    *reinterpret_cast<bf16x8_t*>(d + 2 * run) = lo;        // (the fourth plane only pads a group to 128 bytes: no kernel fetches it)
+}
+__device__ __forceinline__ void store8(float* out, long long e, f32x8 v, int out16) {       // out16: MCG_IO_OUT_BF16 / MCG_IO_OUT_SPLIT / 0
+    if (out16 & MCG_IO_OUT_SPLIT) { store_split8(reinterpret_cast<__bf16*>(out), e, 16, v); return; }
+    if (out16 & MCG_IO_OUT_SPLIT) { store_split8(reinterpret_cast<__bf16*>(out), e, 16, v); return; }     // (out16: MCG_IO_OUT_BF16 / _SPLIT / 0)
     if (out16) { *reinterpret_cast<bf16x8_t*>(reinterpret_cast<__bf16*>(out) + e) = __builtin_convertvector(v, bf16x8_t); return; }
     *reinterpret_cast<f32x4*>(out + e) = __builtin_shufflevector(v, v, 0, 1, 2, 3);
     *reinterpret_cast<f32x4*>(out + e + 4) = __builtin_shufflevector(v, v, 4, 5, 6, 7);
@@ -435,7 +456,7 @@ __global__ __launch_bounds__(NT) void bn_act_fwd8_kernel(long long n8, int C, co
 #pragma unroll
             for (int k = 0; k < 4; ++k) { v[k] = fmaf(sigma, z0[k], v[k]); v[4 + k] = fmaf(sigma, z1[k], v[4 + k]); }
         }
-        store8(out, i * 8, v, io & MCG_IO_OUT_BF16);
+        store8(out, i * 8, v, io & (MCG_IO_OUT_BF16 | MCG_IO_OUT_SPLIT));
     };
     for (long long i0 = (long long)blockIdx.x * NT + threadIdx.x; i0 < n8; i0 += 2 * stride) {
         const long long i1 = i0 + stride < n8 ? i0 + stride : i0;
@@ -468,7 +489,7 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_apply8_kernel(long long n8, int
             const float xh = (yv[k] - mean[k]) * istd[k];
             o[k] = k0[k] * (gb - xh * k1[k] - k2[k]);
         }
-        store8(gx, i * 8, o, io & MCG_IO_OUT_BF16);
+        store8(gx, i * 8, o, io & (MCG_IO_OUT_BF16 | MCG_IO_OUT_SPLIT));
     };
     for (long long i0 = (long long)blockIdx.x * NT + threadIdx.x; i0 < n8; i0 += 2 * stride) {
         const long long i1 = i0 + stride < n8 ? i0 + stride : i0;
@@ -980,25 +1001,6 @@ Folded fold_slots(const float* part, int n_slots, int slot_stride, int C, float*
 bool unsupported_c(int C) { return (C >> 2) > NT || (NT % (C >> 2)) != 0; }
 
 
-// fp32 -> the three bf16 terms of MCG_PREC_SPLIT (include/mocogan_hip.h): hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid);
-// the differences are exact in fp32 and v == hi + mid + lo.  One thread: 8 consecutive values of a run -> one 16-byte piece of each
-// of the run's three planes (the fourth, padding, is not written).
-__device__ __forceinline__ void split3(f32x8 v, bf16x8_t& hi, bf16x8_t& mid, bf16x8_t& lo) {
-    hi = __builtin_convertvector(v, bf16x8_t);
-    const f32x8 r1 = v - __builtin_convertvector(hi, f32x8);
-    mid = __builtin_convertvector(r1, bf16x8_t);
-    const f32x8 r2 = r1 - __builtin_convertvector(mid, f32x8);
-    lo = __builtin_convertvector(r2, bf16x8_t);
-}
-__device__ __forceinline__ void store_split8(__bf16* dst, long long e, long long run, f32x8 v) {      // e: index of the first of 8 source values
-    bf16x8_t hi, mid, lo;
-    split3(v, hi, mid, lo);
-    const long long r = e / run, o = e - r * run;
-    __bf16* d = dst + r * 4 * run + o;
-    *reinterpret_cast<bf16x8_t*>(d) = hi;
-    *reinterpret_cast<bf16x8_t*>(d + run) = mid;
-    *reinterpret_cast<bf16x8_t*>(d + 2 * run) = lo;        // (the fourth plane only pads a group to 128 bytes: no kernel fetches it)
-}
 __global__ __launch_bounds__(NT) void split_planes_kernel(long long n8, long long run, const float* __restrict__ src, __bf16* __restrict__ dst) {
     for (long long i = blockIdx.x * (long long)NT + threadIdx.x; i < n8; i += (long long)gridDim.x * NT)
         store_split8(dst, i * 8, run, load8(src, i * 8, 0));
@@ -1044,7 +1046,8 @@ extern "C" int mcg_bn_act_fwd(int64_t M, int C, int c_valid, const float* y, int
     if (!y || !out || M <= 0 || C <= 0 || (C & 3)) return MCG_ERR_BAD_ARG;
     if (y_rows_per_item < 0 || (y_rows_per_item > 0 && (M % y_rows_per_item || (y_item_stride & 3)))) return MCG_ERR_BAD_ARG;
     long long n4 = (long long)M * (C >> 2);
-    if (out_bf16 & ~(MCG_IO_OUT_BF16 | MCG_IO_Y_BF16)) return MCG_ERR_BAD_ARG;
+    if (out_bf16 & ~(MCG_IO_OUT_BF16 | MCG_IO_Y_BF16 | MCG_IO_OUT_SPLIT)) return MCG_ERR_BAD_ARG;
+    if ((out_bf16 & MCG_IO_OUT_SPLIT) && out_bf16 != MCG_IO_OUT_SPLIT) return MCG_ERR_BAD_ARG;
 #define MCG_FWD(IO_) hipLaunchKernelGGL(bn_act_fwd_kernel<IO_>, dim3(ew_grid(n4)), dim3(NT), 0, (hipStream_t)stream, n4, C, c_valid, y, \
                        (long long)y_rows_per_item * (C >> 2), (long long)y_item_stride, scale_shift, act,                             \
                        addend, sigma, seed, stream_id, (float*)out)
@@ -1052,7 +1055,10 @@ extern "C" int mcg_bn_act_fwd(int64_t M, int C, int c_valid, const float* y, int
     const bool wide = out_bf16 != 0 && (C & 7) == 0 && y_rows_per_item == 0 && c_valid == C && NT % (C >> 3 < NT ? C >> 3 : NT) == 0 && (C >> 3) <= NT;
 #define MCG_FWD8(IO_) hipLaunchKernelGGL(bn_act_fwd8_kernel<IO_>, dim3(ew_grid(n4 / 2)), dim3(NT), 0, (hipStream_t)stream, n4 / 2, C, y, scale_shift, act, \
                        addend, sigma, seed, stream_id, (float*)out)
-    if (wide) { switch (out_bf16) { case 1: MCG_FWD8(1); break; case 2: MCG_FWD8(2); break; default: MCG_FWD8(3); } }
+    if (out_bf16 == MCG_IO_OUT_SPLIT) {                        // the eight-channel kernel only (a 16-byte piece of each plane per thread)
+        if (!wide || (C & 15)) return MCG_ERR_UNSUPPORTED;
+        MCG_FWD8(8);
+    } else if (wide) { switch (out_bf16) { case 1: MCG_FWD8(1); break; case 2: MCG_FWD8(2); break; default: MCG_FWD8(3); } }
     else
     switch (out_bf16) { case 0: MCG_FWD(0); break; case 1: MCG_FWD(1); break; case 2: MCG_FWD(2); break; default: MCG_FWD(3); }
 #undef MCG_FWD8
@@ -1061,7 +1067,10 @@ extern "C" int mcg_bn_act_fwd(int64_t M, int C, int c_valid, const float* y, int
 }
 
 // launches of the two BatchNorm-backward kernels for a run-time set of MCG_IO_* flags (compile-time in the kernels)
-static bool wide_c(int io, int C) { return (io & 7) != 0 && (C & 7) == 0 && (C >> 3) <= NT && NT % (C >> 3) == 0; }
+static bool wide_c(int io, int C) { return (io & 15) != 0 && (C & 7) == 0 && (C >> 3) <= NT && NT % (C >> 3) == 0; }
+static bool split_out_ok(int io, int C, const float* stats) {      // MCG_IO_OUT_SPLIT: fp32 inputs, BatchNorm behind it, C % 16 == 0
+    return io == MCG_IO_OUT_SPLIT && stats && wide_c(io, C) && (C & 15) == 0;
+}
 
 static void launch_bwd_partial(int io, int blocks, hipStream_t s, long long M, int C, long long rows_per_block, const float* g_out,
                                const float* y, const float* stats, int act, float* part) {
@@ -1086,6 +1095,10 @@ static void launch_bwd_partial(int io, int blocks, hipStream_t s, long long M, i
 }
 static void launch_bwd_apply(int io, hipStream_t s, long long n4, int C, const float* g_out, const float* y, const float* stats,
                              const float* coef, int act, float* gx) {
+    if (io & MCG_IO_OUT_SPLIT) {
+        hipLaunchKernelGGL(bn_act_bwd_apply8_kernel<MCG_IO_OUT_SPLIT>, dim3(ew_grid(n4 / 2)), dim3(NT), 0, s, n4 / 2, C, g_out, y, stats, coef, act, gx);
+        return;
+    }
     if (stats && wide_c(io, C)) {
 #define MCG_AP8(IO_) case IO_: hipLaunchKernelGGL(bn_act_bwd_apply8_kernel<IO_>, dim3(ew_grid(n4 / 2)), dim3(NT), 0, s, n4 / 2, C, g_out, y, stats, coef, act, gx); break
         switch (io & 7) { MCG_AP8(1); MCG_AP8(2); MCG_AP8(3); MCG_AP8(4); MCG_AP8(5); MCG_AP8(6); default: MCG_AP8(7); }
@@ -1102,6 +1115,7 @@ extern "C" int mcg_bn_act_bwd(int64_t M, int C, const float* g_out, const float*
     if (!g_out || !y || !gx || M <= 0 || C <= 0 || (C & 3)) return MCG_ERR_BAD_ARG;
     // gx_bf16: MCG_IO_* flags (OUT = gx, Y = y, G = g_out).  In place only between tensors of one element type
     if (gx == (const void*)g_out && !(gx_bf16 & MCG_IO_OUT_BF16) != !(gx_bf16 & MCG_IO_G_BF16)) return MCG_ERR_BAD_ARG;
+    if ((gx_bf16 & MCG_IO_OUT_SPLIT) && (gx == (const void*)g_out || !split_out_ok(gx_bf16, C, stats))) return MCG_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     long long n4 = (long long)M * (C >> 2);
     float* coef = nullptr;
@@ -1124,6 +1138,7 @@ extern "C" int mcg_bn_act_bwd_from_partials(int64_t M, int C, const float* g_out
                                             void* workspace, void* stream) {
     if (!g_out || !y || !gx || !stats || !gamma || !part || !workspace || M <= 0 || bad_c(C) || n_slots <= 0 || slot_stride < 2 * C) return MCG_ERR_BAD_ARG;
     if (gx == (const void*)g_out && !(gx_bf16 & MCG_IO_OUT_BF16) != !(gx_bf16 & MCG_IO_G_BF16)) return MCG_ERR_BAD_ARG;
+    if ((gx_bf16 & MCG_IO_OUT_SPLIT) && (gx == (const void*)g_out || !split_out_ok(gx_bf16, C, stats))) return MCG_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     float* coef = (float*)workspace + (long long)MAX_PART * 2 * C;
     const Folded f = fold_slots(part, n_slots, slot_stride, C, (float*)workspace, s);

@@ -32,7 +32,7 @@ class ConvGeom(C.Structure):
 
 
 SUMS_NONE, SUMS_STATS, SUMS_BN_BWD, SUMS_COL = 0, 1, 2, 3
-IO_OUT_BF16, IO_Y_BF16, IO_G_BF16 = 1, 2, 4          # MCG_IO_*: which tensors of an element-wise call are bf16
+IO_OUT_BF16, IO_Y_BF16, IO_G_BF16, IO_OUT_SPLIT = 1, 2, 4, 8          # MCG_IO_*: which tensors of an element-wise call are bf16
 
 
 class ConvEpilogue(C.Structure):
@@ -222,6 +222,7 @@ def timing_end():
 
 
 split_launches = 0          # conv launches in the MCG_PREC_SPLIT form so far (tests assert that the form really ran)
+split_only_outputs = 0      # element-wise launches that wrote their output in the split layout only
 
 
 def _launch(kind, fn, *args):
@@ -251,7 +252,7 @@ def _launch(kind, fn, *args):
 TILE_CANDIDATES = (0, 101, 102, 103, 201, 202, 203)     # (the long tiles 4 = 256x64 and 5 = 64x256 exist, but when they
                                                         # win the isolated timing they lose inside the iteration: measured)
 FPROP_SPLIT_CANDIDATES = (1103, 1203, 1202, 2103, 2203, 2202)     # 2- / 4-way split-K: only when few tiles (see _tuned)
-V2_CANDIDATES = (7, 8)                                  # gemm_bf16_v2_kernel (bf16-stored or fp32 operands): 256x128 / 256x256 (wgrad 128x256 / 256x256), LDS-DMA ring
+V2_CANDIDATES = (7, 8, 10)                              # gemm_bf16_v2_kernel (bf16-stored / split / fp32 operands): 256x128 / 256x256 (wgrad 128x256 / 256x256) one block per CU; 10 = 128x128, two blocks per CU
 _autotune = False
 _tile_cache = {}
 
@@ -314,6 +315,17 @@ def split_covers(kind, g):
         return (g.Co >= 128 and g.Co % 64 == 0 and p2(g.Ci, 64) and x_el is not None and x_el * 8 < 1 << 31 and y_el * 8 < 1 << 31
                 and (y_el // g.Co) % 16 == 0)
     return p2(g.Co, 16) and p2(g.Ci, 64) and y_el * 8 < 1 << 31
+
+
+def split_decided(kind, g):
+    """True when a launch of this pass and geometry is KNOWN to take the split form (MCG_SPLIT=always, or the table says so): the
+    producers of its operands may then write the split layout only.  False while undecided."""
+    if not split_covers(kind, g):
+        return False
+    mode = os.environ.get('MCG_SPLIT', 'auto')
+    if mode != 'auto':
+        return mode == 'always'
+    return _tile_cache.get(_geom_key('split-' + kind, g)) == 1
 
 
 def split_pays(kind, g, run_plain, run_split):
@@ -390,7 +402,7 @@ def _tuned(kind, g, extra, out_side, run_on):
                     cands = cands + (9,)                        # ... the patch-stationary kernel, four classes per block, is made for it
             if g.precision == PREC_SPLIT:
                 # (the LDS-DMA kernels are the only ones that multiply split operands; one 256-row block per CU: late layers need K splits)
-                cands = V2_CANDIDATES + ((1007, 2007) if kind in ("fprop", "dgrad") and out_elems <= (1 << 25) else ())
+                cands = V2_CANDIDATES + ((1007, 2007, 1010, 2010) if kind in ("fprop", "dgrad") and out_elems <= (1 << 25) else ())
                 if kind == "dgrad" and g.Ci == 64 and g.Ho == 16 and g.Wo == 16:
                     cands = cands + (9,)                        # the patch-stationary kernel (four parity classes per block)
             for cand in cands:
@@ -623,26 +635,39 @@ def bn_stats(M, Cn, y, gamma, beta, stats, avg_mean, avg_var, ws, eps=2e-5, deca
                                          _p(avg_var), eps, decay, _stream()), "mcg_bn_stats_from_sums")
 
 
+def _pout(out, split_out):
+    """(pointer, MCG_IO_OUT_* flag) of an element-wise output: fp32, bf16, or (split_out) the split layout of PREC_SPLIT"""
+    if split_out:
+        global split_only_outputs
+        split_only_outputs += 1
+        return _p(_dense(out), torch.bfloat16), IO_OUT_SPLIT
+    op, o16 = _pany(_dense(out))
+    return op, IO_OUT_BF16 * o16
+
+
 def bn_act_fwd(M, Cn, y, scale_shift, act, out, addend=None, sigma=0.0, seed=0, stream_id=0, c_valid=None,
-               rows_per_item=0, item_stride=0):
-    """y dense [M][Cn], or (rows_per_item > 0) a view whose items are item_stride elements apart."""
+               rows_per_item=0, item_stride=0, split_out=False):
+    """y dense [M][Cn], or (rows_per_item > 0) a view whose items are item_stride elements apart.
+    split_out: `out` is [M][4 Cn] bf16 and receives the split layout (split_planes' form) instead of fp32 values."""
     if rows_per_item == 0:
         _dense(y)
-    op, o16 = _pany(_dense(out))
+    op, oflag = _pout(out, split_out)
     yp, y16 = _pany(y)
     _check(load().mcg_bn_act_fwd(M, Cn, Cn if c_valid is None else c_valid, yp, rows_per_item, item_stride, _p(scale_shift), act,
-                                 _p(_dense(addend)), sigma, seed, stream_id, op, IO_OUT_BF16 * o16 + IO_Y_BF16 * y16, _stream()),
+                                 _p(_dense(addend)), sigma, seed, stream_id, op, oflag + IO_Y_BF16 * y16, _stream()),
            "mcg_bn_act_fwd")
 
 
-def bn_act_bwd(M, Cn, g_out, y, stats, gamma, act, gx, dgamma, dbeta, ws, sync=None):
-    gp, g16 = _pany(_dense(gx))
+def bn_act_bwd(M, Cn, g_out, y, stats, gamma, act, gx, dgamma, dbeta, ws, sync=None, split_out=False):
+    gp, gflag = _pout(gx, split_out)
+    g16 = gflag == IO_OUT_BF16
     ip, i16 = _pany(_dense(g_out))
     yp, y16 = _pany(_dense(y))
     if sync is None or sync.world == 1 or stats is None:
-        _check(load().mcg_bn_act_bwd(M, Cn, ip, yp, _p(stats), _p(gamma), act, gp, IO_OUT_BF16 * g16 + IO_Y_BF16 * y16 + IO_G_BF16 * i16,
+        _check(load().mcg_bn_act_bwd(M, Cn, ip, yp, _p(stats), _p(gamma), act, gp, gflag + IO_Y_BF16 * y16 + IO_G_BF16 * i16,
                                      _p(dgamma), _p(dbeta), _p(ws), _stream()), "mcg_bn_act_bwd")
         return
+    assert not split_out
     local = torch.empty(2 * Cn, dtype=torch.float64, device=y.device)
     _check(load().mcg_bn_bwd_sums(M, Cn, ip, yp, _p(stats), act, IO_Y_BF16 * y16 + IO_G_BF16 * i16, _p(local, torch.float64), _p(ws),
                                   _stream()), "mcg_bn_bwd_sums")
@@ -659,12 +684,12 @@ def bn_stats_from_partials(M, Cn, part, n_slots, slot_stride, gamma, beta, stats
                                              _p(avg_var), eps, decay, _p(ws), _stream()), "mcg_bn_stats_from_partials")
 
 
-def bn_act_bwd_from_partials(M, Cn, g_out, y, stats, gamma, act, part, n_slots, slot_stride, gx, dgamma, dbeta, ws):
-    gp, g16 = _pany(_dense(gx))
+def bn_act_bwd_from_partials(M, Cn, g_out, y, stats, gamma, act, part, n_slots, slot_stride, gx, dgamma, dbeta, ws, split_out=False):
+    gp, gflag = _pout(gx, split_out)
     ip, i16 = _pany(_dense(g_out))
     yp, y16 = _pany(_dense(y))
     _check(load().mcg_bn_act_bwd_from_partials(M, Cn, ip, yp, _p(stats), _p(gamma), act, _p(part), n_slots, slot_stride, gp,
-                                               IO_OUT_BF16 * g16 + IO_Y_BF16 * y16 + IO_G_BF16 * i16, _p(dgamma), _p(dbeta), _p(ws),
+                                               gflag + IO_Y_BF16 * y16 + IO_G_BF16 * i16, _p(dgamma), _p(dbeta), _p(ws),
                                                _stream()), "mcg_bn_act_bwd_from_partials")
 
 

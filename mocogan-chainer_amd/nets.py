@@ -150,6 +150,13 @@ class _Net:
                 return split()
         return hl.conv_fprop(g, x, w, b, y, ep=ep, must_fuse=must_fuse)
 
+    def _split_only(self, *launches):
+        """'f32x3': may the producer of a tensor write its split form ONLY?  Yes when every GEMM that reads it -- launches:
+        (pass, geometry) pairs -- is known to take the split form (hl.split_decided); the fp32 tensor then stays allocated (shapes,
+        slicing) but is never written nor read."""
+        return (self.precision == 'f32x3' and self.sync_bn is None and os.environ.get('MCG_SPLIT_ONLY', '1') == '1'
+                and all(hl.split_decided(kind, g) for kind, g in launches))
+
     @staticmethod
     def _sp(store, key, t):
         """the split form of tensor t, made once per (store, key): forward keeps what the weight gradient reads again"""
@@ -480,6 +487,11 @@ class DisNet(_Net):
                 self._cfprop(g, a, 'dc%d/W' % l, w, b, y, xs=lambda: self._sp(saved['split'], l, saved['a'][l]))
             saved['y'][l] = y
             a = torch.empty_like(y, dtype=adt)
+            a_split = None                                       # 'f32x3': layer l + 1's GEMMs both read the split form -> written directly
+            if l < 4:
+                gn = self._geom(l + 1, N)
+                if self._split_only(('fprop', gn), ('wgrad', gn)):
+                    a_split = saved['split'][l + 1] = torch.empty(y.shape[:-1] + (4 * co,), device=dev, dtype=torch.bfloat16)
             if l >= 2:
                 saved['stats'][l] = []
             for gi, grp in enumerate(groups):
@@ -503,7 +515,10 @@ class DisNet(_Net):
                         ss = stats[2 * co:]
                     else:
                         ss = self._test_scale_shift(name)
-                hl.bn_act_fwd(m, co, yg, ss, hl.ACT_LRELU, ag, **(noise_args(grp, l + 1) if l < 4 else {}))
+                if a_split is not None:
+                    hl.bn_act_fwd(m, co, yg, ss, hl.ACT_LRELU, a_split[gi * n:(gi + 1) * n], split_out=True, **noise_args(grp, l + 1))
+                else:
+                    hl.bn_act_fwd(m, co, yg, ss, hl.ACT_LRELU, ag, **(noise_args(grp, l + 1) if l < 4 else {}))
             saved['a'][l + 1] = a
         k = a[0].numel()
         logits = torch.empty((N, self.out_channels), device=dev)
@@ -520,7 +535,7 @@ class DisNet(_Net):
         if mask is not None:
             rows = mask.shape[0] // saved['G']
             mask = mask[gi * rows:(gi + 1) * rows]
-        return {'n': n, 'G': 1, 'a': {l: v[sl] for l, v in saved['a'].items()},
+        return {'n': n, 'G': 1, 'a': {l: v[sl] for l, v in saved['a'].items()}, 'split': {l: v[sl] for l, v in saved.get('split', {}).items()},
                 'y': {l: (None if v is None else v[sl]) for l, v in saved['y'].items()},
                 'stats': {l: [v[gi]] for l, v in saved['stats'].items()}, 'mask1': mask}
 
@@ -567,17 +582,24 @@ class DisNet(_Net):
             if l >= 2:
                 name = 'bn%d' % l
                 gy = torch.empty_like(g, dtype=torch.bfloat16) if s16 else g       # bf16-stored operand of wgrad / dgrad, else in place
+                # 'f32x3': both GEMMs that read gy take the split form -> written in that form only (g keeps its shape, not its meaning)
+                gy_split = None
+                if self._split_only(('dgrad', geom), *((('wgrad', geom),) if param_grads else ())):
+                    gy_split = torch.empty(g.shape[:-1] + (4 * co,), device=g.device, dtype=torch.bfloat16)
                 for gi in range(G):
                     gg, yg, go = g[gi * n:(gi + 1) * n], y[gi * n:(gi + 1) * n], gy[gi * n:(gi + 1) * n]
+                    if gy_split is not None:
+                        go = gy_split[gi * n:(gi + 1) * n]
                     dg = fp.grad(name + '/gamma') if param_grads else None
                     db = fp.grad(name + '/beta') if param_grads else None
                     if pending is not None:
                         ep, part = pending
                         hl.bn_act_bwd_from_partials(m, co, gg, yg, saved['stats'][l][gi], fp.param(name + '/gamma'), hl.ACT_LRELU,
-                                                    part[gi * 2 * co:], ep.n_slots, ep.slot_stride, go, dg, db, self.ws)
+                                                    part[gi * 2 * co:], ep.n_slots, ep.slot_stride, go, dg, db, self.ws,
+                                                    split_out=gy_split is not None)
                     else:
                         hl.bn_act_bwd(m, co, gg, yg, saved['stats'][l][gi], fp.param(name + '/gamma'), hl.ACT_LRELU, go, dg, db, self.ws,
-                                      sync=self.sync_bn)
+                                      sync=self.sync_bn, split_out=gy_split is not None)
                 g = gy
             elif mask1 is None:
                 for gi in range(G):
@@ -585,6 +607,8 @@ class DisNet(_Net):
                     hl.bn_act_bwd(m, co, gg, yg, None, None, hl.ACT_LRELU, gg, None, None, self.ws)
             # (l == 1 with a stored mask: dc2's input-gradient GEMM applied leaky_relu's backward in its epilogue)
             gsp = {}                                             # 'f32x3': the split form of g, shared by the two GEMMs that read it
+            if l >= 2 and gy_split is not None:
+                gsp[0] = gy_split
 
             def gys():
                 return self._sp(gsp, 0, g)
@@ -790,7 +814,12 @@ class GenNet(_Net):
                 ss = torch.cat((scale, fp.param(name + '/beta') - self.running[name + '/avg_mean'] * scale))
             saved['y'][l] = y
             a = torch.empty_like(y, dtype=torch.bfloat16 if self._s16(l + 1) else torch.float32)   # the operand of layer l + 1's GEMMs
-            hl.bn_act_fwd(m, co, y, ss, hl.ACT_RELU, a)
+            gn = self._geom(l + 1, frames) if l < 4 else None
+            if gn is not None and self._split_only(('dgrad', gn), ('wgrad', gn)):      # 'f32x3': both readers take the split form
+                saved['split'][l + 1] = torch.empty(y.shape[:-1] + (4 * co,), device=dev, dtype=torch.bfloat16)
+                hl.bn_act_fwd(m, co, y, ss, hl.ACT_RELU, saved['split'][l + 1], split_out=True)
+            else:
+                hl.bn_act_fwd(m, co, y, ss, hl.ACT_RELU, a)
             saved['a'][l + 1] = a
             h = 4 << l
             pending = None
@@ -848,20 +877,25 @@ class GenNet(_Net):
             ci = lay.pad4(self.chans[l])
             m = g.numel() // ci
             s16 = self._s16(l)
+            gy_split = None
             if l < 5:
                 name = 'bn%d' % l
                 gy = torch.empty_like(g, dtype=torch.bfloat16) if s16 else g      # bf16-stored operand of wgrad / fprop, else in place
+                if self._split_only(('wgrad', geom), ('fprop', geom)):            # 'f32x3': written in the split form only
+                    gy_split = torch.empty(g.shape[:-1] + (4 * ci,), device=g.device, dtype=torch.bfloat16)
+                go = gy_split if gy_split is not None else gy
                 if pending is not None:
                     ep, part = pending
                     hl.bn_act_bwd_from_partials(m, ci, g, saved['y'][l], saved['stats'][l], fp.param(name + '/gamma'), hl.ACT_RELU, part,
-                                                ep.n_slots, ep.slot_stride, gy, fp.grad(name + '/gamma'), fp.grad(name + '/beta'), self.ws)
+                                                ep.n_slots, ep.slot_stride, go, fp.grad(name + '/gamma'), fp.grad(name + '/beta'), self.ws,
+                                                split_out=gy_split is not None)
                 else:
-                    hl.bn_act_bwd(m, ci, g, saved['y'][l], saved['stats'][l], fp.param(name + '/gamma'), hl.ACT_RELU, gy,
-                                  fp.grad(name + '/gamma'), fp.grad(name + '/beta'), self.ws, sync=self.sync_bn)
+                    hl.bn_act_bwd(m, ci, g, saved['y'][l], saved['stats'][l], fp.param(name + '/gamma'), hl.ACT_RELU, go,
+                                  fp.grad(name + '/gamma'), fp.grad(name + '/beta'), self.ws, sync=self.sync_bn, split_out=gy_split is not None)
                 g = gy
             if l == 5:
                 hl.colsum_acc(m, ci, g, fp.grad('dc5/b'), self.ws)         # dc1..dc4 feed BatchNorm: exact zero
-            gsp = {}                                             # 'f32x3': the split form of g, shared by the two GEMMs that read it
+            gsp = {} if gy_split is None else {0: gy_split}      # 'f32x3': the split form of g, shared by the two GEMMs that read it
 
             def gxs():
                 return self._sp(gsp, 0, g)

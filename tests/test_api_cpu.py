@@ -174,13 +174,13 @@ def test_shipped_tile_table_is_well_formed():
             form = 4 if (prec == 2 and kind != 'wgrad') else 0
             assert kind in ('fprop', 'dgrad', 'wgrad') and len(key) == base + form, key
             assert all(isinstance(v, int) for v in key[1:base]) and (not form or (key[base] == 'ep' and all(isinstance(v, int) for v in key[base + 1:]))), key
-            assert isinstance(code, int) and 0 <= code % 100 <= 9 and (code // 100) % 10 <= 2 and code // 1000 <= 2, code
+            assert isinstance(code, int) and 0 <= code % 100 <= 10 and (code // 100) % 10 <= 2 and code // 1000 <= 2, code
             # 7 / 8: the LDS-DMA kernels, 9: the patch-stationary input gradient -- bf16-stored operands (no K split) or split
             # operands (prec 3: only these kernels; + 1000 / 2000 K splits of fprop / dgrad)
             if prec == 3:
-                assert code % 1000 in (7, 8, 9) and (code < 1000 or kind != 'wgrad') and (code % 1000 != 9 or (kind == 'dgrad' and Ci == 64 and Hi == 32)), (key, code)
+                assert code % 1000 in (7, 8, 9, 10) and (code < 1000 or kind != 'wgrad') and (code % 1000 != 9 or (kind == 'dgrad' and Ci == 64 and Hi == 32)), (key, code)
             else:
-                assert code % 100 < 7 or (prec == 2 and code in (7, 8)) or (prec == 2 and code == 9 and kind == 'dgrad' and Ci == 64 and Hi == 32), (key, code)
+                assert code % 100 < 7 or (prec == 2 and code in (7, 8, 10)) or (prec == 2 and code == 9 and kind == 'dgrad' and Ci == 64 and Hi == 32), (key, code)
         assert tuple(key) not in seen
         seen.add(tuple(key))
 

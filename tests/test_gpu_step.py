@@ -310,10 +310,14 @@ def test_update_core_with_split_fp32_convolutions(pkg, monkeypatch):
     fp32-MFMA iteration.  MCG_SPLIT=always: every launch that has a split form takes it (no timing decides)."""
     hl = pkg[0]
     monkeypatch.setenv('MCG_SPLIT', 'always')
-    before = hl.split_launches
+    before, before_only = hl.split_launches, hl.split_only_outputs
     _run_steps(pkg, "normal", 6, nf=16, n=3, steps=2, seed=77, min_tight_steps=0, precision='f32x3')
     _run_steps(pkg, "infogan", 6, nf=16, n=3, steps=2, seed=78, min_tight_steps=0, overlap=True, precision='f32x3')
     assert hl.split_launches - before >= 2 * 2 * 8, "the split form did not run"
+    # ... and where every reader of an activation / gradient tensor is a split launch, BatchNorm's passes wrote the split form only
+    assert hl.split_only_outputs > before_only
+    monkeypatch.setenv('MCG_SPLIT_ONLY', '0')                      # the other path: fp32 tensors, split on the way into the GEMMs
+    _run_steps(pkg, "normal", 6, nf=16, n=3, steps=1, seed=77, min_tight_steps=0, precision='f32x3')
 
 
 PERF_CASES = [("normal", 0, 1303), ("normal", 6, 1311), ("infogan", 6, 1313), ("cgan", 6, 1320)]
