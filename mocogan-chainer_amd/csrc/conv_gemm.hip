@@ -3031,7 +3031,7 @@ int conv_fprop_impl(const mcg_conv_geom* c, const float* x, const float* w, cons
     if (t == 7 || t == 8 || t == 10) {                             // the LDS-DMA kernels (bf16-stored operands, wide layers)
         if (!v2_ok(g, g.Ci) || e.mode & ~(EPI_STATS | EPI_COL | EPI_MASKMUL)) return MCG_ERR_UNSUPPORTED;
         if (t == 10) {                                             // 128x128, two buffers: TWO blocks per CU
-            if (g.prec != MCG_PREC_BF16_STORE) return MCG_ERR_UNSUPPORTED;
+            if (g.prec == MCG_PREC_F32) return finish(launch_fprop_v2<128, 128, 2, 0>(g, x, w, bias, y, e, ep, s));
             return finish(launch_fprop_v2<128, 128, 2, 2>(g, x, w, bias, y, e, ep, s));
         }
         if (g.prec == MCG_PREC_F32)
@@ -3141,7 +3141,8 @@ int conv_dgrad_impl(const mcg_conv_geom* c, const float* y, const float* w, cons
         const long long frame_ = (long long)g.Ti * g.Hi * g.Wi * g.Ci;
         if (!v2_ok(g, g.Co) || g.Ci < 64 || (g.Ci & (g.Ci - 1)) || (e.mode & ~(EPI_STATS | EPI_COL | EPI_MASKMUL))) return MCG_ERR_UNSUPPORTED;
         if (t == 10) {                                           // 128x128, two blocks per CU
-            if (g.prec != MCG_PREC_BF16_STORE || g.Ci < 128) return MCG_ERR_UNSUPPORTED;
+            if (g.Ci < 128) return MCG_ERR_UNSUPPORTED;
+            if (g.prec == MCG_PREC_F32) return finish(launch_dgrad_v2<128, 128, 2, 0>(g, y, w, bias, x, act, accumulate, e, ep, s));
             return finish(launch_dgrad_v2<128, 128, 2, 2>(g, y, w, bias, x, act, accumulate, e, ep, s));
         }
         (void)frame_;
@@ -3217,7 +3218,7 @@ extern "C" int mcg_conv_wgrad(const mcg_conv_geom* c, const float* x, const floa
     if (t == 7 || t == 8 || t == 10) {                           // the LDS-DMA kernels: 128x256 (Co = 128) or 256x256; 10: 128x128, two blocks per CU
         if ((g.prec != MCG_PREC_BF16_STORE && g.prec != MCG_PREC_F32) || g.Co < 128 || (g.Co & 63) || g.Ci < 64 || (g.Ci & (g.Ci - 1))) return MCG_ERR_UNSUPPORTED;
         if (t == 10) {
-            if (g.prec != MCG_PREC_BF16_STORE) return MCG_ERR_UNSUPPORTED;
+            if (g.prec == MCG_PREC_F32) return finish(launch_wgrad_v2<128, 128, 2, 0>(g, x, y, dw, s));
             return finish(launch_wgrad_v2<128, 128, 2, 2>(g, x, y, dw, s));
         }
         if (g.prec == MCG_PREC_F32) {

@@ -400,6 +400,8 @@ def _tuned(kind, g, extra, out_side, run_on):
                     cands = cands + V2_CANDIDATES
                 elif g.Ho == 16 and g.Wo == 16:
                     cands = cands + (9,)                        # ... the patch-stationary kernel, four classes per block, is made for it
+            if g.precision == PREC_F32 and g.Ci >= 64 and g.Co >= 64 and kind != "dgrad" or (g.precision == PREC_F32 and kind == "dgrad" and g.Ci >= 128 and g.Co >= 64):
+                cands = cands + (10,)                           # the LDS-DMA kernel on fp32 operands, 128x128, two blocks per CU
             if g.precision == PREC_SPLIT:
                 # (the LDS-DMA kernels are the only ones that multiply split operands; one 256-row block per CU: late layers need K splits)
                 cands = V2_CANDIDATES + ((1007, 2007, 1010, 2010) if kind in ("fprop", "dgrad") and out_elems <= (1 << 25) else ())

@@ -180,7 +180,7 @@ def test_shipped_tile_table_is_well_formed():
             if prec == 3:
                 assert code % 1000 in (7, 8, 9, 10) and (code < 1000 or kind != 'wgrad') and (code % 1000 != 9 or (kind == 'dgrad' and Ci == 64 and Hi == 32)), (key, code)
             else:
-                assert code % 100 < 7 or (prec == 2 and code in (7, 8, 10)) or (prec == 2 and code == 9 and kind == 'dgrad' and Ci == 64 and Hi == 32), (key, code)
+                assert code % 100 < 7 or (prec in (0, 2) and code == 10) or (prec == 2 and code in (7, 8)) or (prec == 2 and code == 9 and kind == 'dgrad' and Ci == 64 and Hi == 32), (key, code)
         assert tuple(key) not in seen
         seen.add(tuple(key))
 

@@ -883,8 +883,6 @@ def test_lds_dma_kernels_match_the_oracle(hl, case, tile, prec):
     a ring of tile buffers, 8 waves) on bf16-representable inputs against the float64 oracle at the fp32 tolerances, plain
     and with the statistics epilogue / a bf16 output; the padding taps are the zeros the buffer range check writes."""
     N, Ti, H, Ci, Co, kt = case
-    if tile == 10 and prec == 'f32':
-        pytest.skip("the two-blocks-per-CU tile exists for bf16-stored and split operands")
     rng = np.random.RandomState(9000 + V2_CASES.index(case))
     lay = L()
     x, W = _bf16_round(rng.uniform(-1, 1, (N, Ci, Ti, H, H))), _bf16_round(rng.randn(Co, Ci, kt, 4, 4) * 0.1)

@@ -25,7 +25,8 @@ def main():
     ap.add_argument('--reps', type=int, default=3)
     ap.add_argument('--sweeps', type=int, default=1)
     ap.add_argument('--min-gain', type=float, default=0.002, help='relative iteration-time gain needed to switch')
-    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'])
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16', 'f32x3'])
+    ap.add_argument('--cands', default='', help='comma-separated tile codes to try INSTEAD of the usual candidate lists (e.g. 10)')
     ap.add_argument('--overlap', type=int, default=1)
     ap.add_argument('--out', required=True)
     args = ap.parse_args()
@@ -65,7 +66,7 @@ def main():
             if ' N=' in name and name.split('.')[1].split()[0] == k[0] and ('N=%d T=%d H=%d Ci=%d Co=%d' % (k[1], k[2], k[3], k[5], k[6])) in name:
                 return ms
         return 0.0
-    precs = (hl.PRECISIONS['bf16'], hl.PRECISIONS['bf16s']) if args.dtype == 'bf16' else (hl.PRECISIONS[args.dtype],)   # bf16 networks: both operand forms
+    precs = (hl.PRECISIONS['bf16'], hl.PRECISIONS['bf16s']) if args.dtype == 'bf16' else (hl.PRECISIONS['f32'], hl.PRECISIONS['f32x3']) if args.dtype == 'f32x3' else (hl.PRECISIONS[args.dtype],)   # bf16 networks: both operand forms
     keys = sorted([k for k in cache if k[9] in precs and k[1] in (args.batch, 2 * args.batch, 16 * args.batch)], key=key_cost, reverse=True)
     base = measure()
     print('baseline %.3f ms/iteration, %d geometries' % (base, len(keys)), flush=True)
@@ -80,6 +81,8 @@ def main():
                 cands += [4]                                 # 256 x 64: the widest tile a 64-column output admits
             if k[0] == 'wgrad':                             # more / fewer pixel splits around the current tile
                 cands += [1000 + c for c in hl.TILE_CANDIDATES if c] + [2000 + c for c in hl.TILE_CANDIDATES if c]
+            if args.cands:
+                cands = [int(c) for c in args.cands.split(',')]
             cur = cache[k]
             best_c, best_t = cur, base
             for c in cands:
