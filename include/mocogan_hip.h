@@ -115,7 +115,7 @@ typedef struct mcg_conv_geom {
 
 /* ABI revision of this header: a host built against another revision must not call in (argument lists differ).
  * 3 = round 3 (mcg_randint, bf16 tensors in the synchronised-BatchNorm backward; round 2 changed mcg_bn_act_fwd / mcg_bn_act_bwd / mcg_adam_wd / mcg_conv_geom). */
-#define MCG_ABI_VERSION 3
+#define MCG_ABI_VERSION 4
 int mcg_version(void);
 
 /* ---- implicit-GEMM convolution on the fp32 MFMA (v_mfma_f32_32x32x2_f32) ------------------- */
@@ -172,7 +172,7 @@ typedef struct mcg_conv_epilogue {
     uint32_t* mask_out;         /* [rows][(C+31)/32] words, bit c & 31 of word c >> 5 set <=> pre-activation >= 0; or NULL */
     int32_t out_bf16;           /* the OUTPUT tensor (y of fprop, x of dgrad) is bf16 (uint16_t, round-to-nearest-even) --
                                  * what the next layer's GEMMs (with act) or the element-wise passes (without) of a bf16
-                                 * network read.  With the plain store or any epilogue but MCG_SUMS_BN_BWD; never with a
+                                 * network read.  With the plain store or any epilogue (MCG_SUMS_BN_BWD: LDS-DMA kernels only); never with a
                                  * split-K tile code, an accumulating dgrad or the Ci = 4 layers (MCG_ERR_UNSUPPORTED).  The
                                  * sums of an epilogue are those of the STORED (rounded) values: BatchNorm then normalises the
                                  * tensor it reads with that tensor's own mean and variance */
@@ -180,6 +180,9 @@ typedef struct mcg_conv_epilogue {
     const uint32_t* mask_in;
     /* out (host side, valid after the call): */
     int32_t n_slots, slot_stride;   /* part holds n_slots slots, slot_stride floats apart; group i starts i*2*C in */
+    /* in (ABI 4): MCG_SUMS_BN_BWD on the LDS-DMA kernels (tile 7 / 8 / 10, bf16-stored or split operands -- the only kernels that take it
+     * together with out_bf16): bn_y is bf16 (uint16_t) instead of fp32; the sums are those of the STORED output values */
+    int32_t bn_y_bf16;
 } mcg_conv_epilogue;
 /* upper bound of the bytes `part` needs for this geometry (any tile choice); pass = 0 fprop, 1 dgrad */
 int64_t mcg_conv_epilogue_part_bytes(const mcg_conv_geom* g, int pass, int groups);

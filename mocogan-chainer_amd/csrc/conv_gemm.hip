@@ -75,6 +75,7 @@ struct Epi {
     long long grp_rows;         // rows of one group (fprop with noise: local row index = row - group * grp_rows)
     float* part; int slot_stride;
     const float* bn_y; const float* bn_stats[2]; int bn_act;
+    int bn_y16;                 // bn_y is bf16 (LDS-DMA kernels' row-wise epilogue only)
     const float* addend[2]; float sigma; u64 seed; u64 stream[2];
     u32* mask_out; const u32* mask_in; int mask_cb;
     int out16;                  // the output tensor is bf16 (bf16 networks: what the element-wise passes and the next GEMMs read;
@@ -1249,7 +1250,9 @@ __device__ __forceinline__ void rowwise_epilogue(const P& p, f32x16 (&acc)[TM][T
         // ONE row decode, vector arithmetic, and a lane keeps the sums of ITS columns -- lanes that own the same columns are
         // combined with shuffles, the WM waves that share them through LDS, one partial per (block tile, group, channel) as in
         // fused_epilogue (fixed order, no atomics).
-        const int mode = EPI == 1 ? (e.mode & (EPI_STATS | EPI_COL | EPI_MASKMUL)) : 0;
+        // (class 2: the two sums of BatchNorm's backward pass -- sum g', sum g' x_hat with g' = v act'(bn(y)) -- of the stored values v: the
+        //  saved BatchNorm input y is read run by run like the output is written, the per-channel statistics as 16-byte vectors)
+        const int mode = EPI == 1 ? (e.mode & (EPI_STATS | EPI_COL | EPI_MASKMUL)) : EPI == 2 ? (e.mode & EPI_BNBWD) : 0;
         f32x4 s0[NBP][2][2], s1[NBP][2][2];                      // [column pair][group][half of an 8-column run]
 #pragma unroll
         for (int i = 0; i < NBP; ++i)
@@ -1268,7 +1271,21 @@ __device__ __forceinline__ void rowwise_epilogue(const P& p, f32x16 (&acc)[TM][T
             if ((mode & EPI_SUMS) && ri.ok && n < C) {
                 f32x4 vs = v;
                 if (o16) vs = __builtin_convertvector(__builtin_convertvector(v, bf16x4), f32x4);      // the sums are those of the values as STORED
-                if (ri.grp) { s0[bp][1][h] += vs; s1[bp][1][h] += vs * vs; } else { s0[bp][0][h] += vs; s1[bp][0][h] += vs * vs; }
+                f32x4 t0 = vs, t1 = vs * vs;
+                if constexpr (EPI == 2) {
+                    const float* st = ri.grp ? e.bn_stats[1] : e.bn_stats[0];
+                    const f32x4 mu = *reinterpret_cast<const f32x4*>(st + n), is = *reinterpret_cast<const f32x4*>(st + C + n);
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(st + 2 * C + n), sh = *reinterpret_cast<const f32x4*>(st + 3 * C + n);
+                    f32x4 yv;
+                    if (e.bn_y16) yv = __builtin_convertvector(*reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(e.bn_y) + ri.base + n), f32x4);
+                    else yv = *reinterpret_cast<const f32x4*>(e.bn_y + ri.base + n);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float gb = vs[k] * epi_act_mask(fmaf(yv[k], sc[k], sh[k]), e.bn_act);
+                        t0[k] = gb; t1[k] = gb * (yv[k] - mu[k]) * is[k];
+                    }
+                }
+                if (ri.grp) { s0[bp][1][h] += t0; s1[bp][1][h] += t1; } else { s0[bp][0][h] += t0; s1[bp][0][h] += t1; }
             }
         };
 #pragma unroll
@@ -1290,7 +1307,7 @@ __device__ __forceinline__ void rowwise_epilogue(const P& p, f32x16 (&acc)[TM][T
                         const int idx = lane + 64 * it, row = idx / CH, ch = idx % CH;
                         f32x4 lo = *reinterpret_cast<const f32x4*>(&slab[row * SLABW + ch * 8]);
                         f32x4 hi = *reinterpret_cast<const f32x4*>(&slab[row * SLABW + ch * 8 + 4]);
-                        if constexpr (EPI == 1) {
+                        if constexpr (EPI != 0) {
                             const RowInfo ri = p.row_info(mrow + row);
                             fused(bp, 0, ri, ncol + ch * 8, lo);
                             fused(bp, 1, ri, ncol + ch * 8 + 4, hi);
@@ -1303,7 +1320,7 @@ __device__ __forceinline__ void rowwise_epilogue(const P& p, f32x16 (&acc)[TM][T
                     for (int it = 0; it < 32 * CH / 64; ++it) {
                         const int idx = lane + 64 * it, row = idx / CH, ch = idx % CH;
                         f32x4 v = *reinterpret_cast<const f32x4*>(&slab[row * SLABW + ch * 4]);
-                        if constexpr (EPI == 1) {
+                        if constexpr (EPI != 0) {
                             const RowInfo ri = p.row_info(mrow + row);
                             fused(bp, 0, ri, ncol + ch * 4, v);
                             p.store_vec4(ri.ok ? ri.base : -1, ncol + ch * 4, v, false);
@@ -1311,7 +1328,7 @@ __device__ __forceinline__ void rowwise_epilogue(const P& p, f32x16 (&acc)[TM][T
                     }
                 }
             }
-        if constexpr (EPI == 1) {
+        if constexpr (EPI != 0) {
             if (mode & EPI_SUMS) {
                 float* red = reinterpret_cast<float*>(smem) + grp * (WM * BN * 4);
                 // a lane's columns: run ch = lane % CH of every slab row it read; lanes lane % CH apart hold the same columns
@@ -2696,6 +2713,7 @@ int launch_fprop(const Geom& g, const float* x, const float* w, const float* bia
     dim3 grid((p.M + BM - 1) / BM, (g.Co + BN - 1) / BN, splits);
     const int cls = e.mode ? epi_class(e.mode) : 0;
     if (PM == 2 && cls > 1) return MCG_ERR_UNSUPPORTED;
+    if (cls == 2 && (e.out16 || e.bn_y16)) return MCG_ERR_UNSUPPORTED;     // (bf16 tensors around BatchNorm's backward sums: the LDS-DMA kernels)
     if constexpr (PM == 0) {
         if (cls == 0) hipLaunchKernelGGL((gemm_kernel<Pol, BM, BN, BK, 0>), grid, dim3(NTHREADS), 0, s, p);
         else if (cls == 1) hipLaunchKernelGGL((gemm_kernel<Pol, BM, BN, BK, 1>), grid, dim3(NTHREADS), 0, s, p);
@@ -2736,6 +2754,7 @@ int launch_dgrad(const Geom& g, const float* y, const float* w, const float* bia
 #endif
     const int cls = e.mode ? epi_class(e.mode) : 0;                      // (class 3 is fprop only: make_epi)
     if (PM == 2 && cls > 1) return MCG_ERR_UNSUPPORTED;
+    if (cls == 2 && (e.out16 || e.bn_y16)) return MCG_ERR_UNSUPPORTED;
     if constexpr (PM == 0) {
         if (cls == 0) hipLaunchKernelGGL((gemm_kernel<Pol, BM, BN, BK, 0>), grid, dim3(NTHREADS), 0, s, p);
         else if (cls == 1) hipLaunchKernelGGL((gemm_kernel<Pol, BM, BN, BK, 1>), grid, dim3(NTHREADS), 0, s, p);
@@ -2833,11 +2852,12 @@ int launch_fprop_v2(const Geom& g, const float* x, const float* w, const float* 
     else if (hipMemsetAsync(y, 0, (size_t)p.M * g.Co * sizeof(float), s) != hipSuccess) return MCG_ERR_LAUNCH;
     if (ep) { ep->n_slots = (p.M + BM - 1) / BM; ep->slot_stride = e.slot_stride; }
     const int cls = e.mode ? epi_class(e.mode) : 0;
-    if (cls > 1) return MCG_ERR_UNSUPPORTED;
+    if (cls > 2 || (cls == 2 && PM != 2)) return MCG_ERR_UNSUPPORTED;       // (class 2, BatchNorm's backward sums: bf16-stored / split operands)
     const dim3 grid((p.M + BM - 1) / BM, (g.Co + BN - 1) / BN, splits);
     constexpr size_t lds = (size_t)STAGES * (BM + BN) * 128;
     if (cls == 0) MCG_V2_LAUNCH((gemm_bf16_v2_kernel<Pol, BM, BN, STAGES, 0, SPLIT>), grid, lds, p);
-    else MCG_V2_LAUNCH((gemm_bf16_v2_kernel<Pol, BM, BN, STAGES, 1, SPLIT>), grid, lds, p);
+    else if (cls == 1) MCG_V2_LAUNCH((gemm_bf16_v2_kernel<Pol, BM, BN, STAGES, 1, SPLIT>), grid, lds, p);
+    else if constexpr (PM == 2) MCG_V2_LAUNCH((gemm_bf16_v2_kernel<Pol, BM, BN, STAGES, 2, SPLIT>), grid, lds, p);
     return MCG_OK;
 }
 
@@ -2861,10 +2881,11 @@ int launch_dgrad_v2(const Geom& g, const float* y, const float* w, const float* 
     p.gxm = (p.M + BM - 1) / BM; p.gyn = (g.Ci + BN - 1) / BN; p.tiles8 = (p.gxm * p.gyn + 7) / 8;
     const dim3 grid(8 * p.tiles8 * 4 * splits, 1, 1);
     const int cls = e.mode ? epi_class(e.mode) : 0;
-    if (cls > 1) return MCG_ERR_UNSUPPORTED;
+    if (cls > 2 || (cls == 2 && PM != 2)) return MCG_ERR_UNSUPPORTED;
     constexpr size_t lds = (size_t)STAGES * (BM + BN) * 128;
     if (cls == 0) MCG_V2_LAUNCH((gemm_bf16_v2_kernel<Pol, BM, BN, STAGES, 0, SPLIT>), grid, lds, p);
-    else MCG_V2_LAUNCH((gemm_bf16_v2_kernel<Pol, BM, BN, STAGES, 1, SPLIT>), grid, lds, p);
+    else if (cls == 1) MCG_V2_LAUNCH((gemm_bf16_v2_kernel<Pol, BM, BN, STAGES, 1, SPLIT>), grid, lds, p);
+    else if constexpr (PM == 2) MCG_V2_LAUNCH((gemm_bf16_v2_kernel<Pol, BM, BN, STAGES, 2, SPLIT>), grid, lds, p);
     return MCG_OK;
 }
 
@@ -2968,6 +2989,7 @@ int make_epi(const mcg_conv_epilogue* ep, const Geom& g, int pass, Epi& e) {
             if (!ep->bn_y || !ep->bn_stats[0] || (ep->groups == 2 && !ep->bn_stats[1])) return MCG_ERR_BAD_ARG;
             if (ep->bn_act != MCG_ACT_RELU && ep->bn_act != MCG_ACT_LRELU) return MCG_ERR_UNSUPPORTED;
             e.bn_y = ep->bn_y; e.bn_stats[0] = ep->bn_stats[0]; e.bn_stats[1] = ep->bn_stats[1]; e.bn_act = ep->bn_act;
+            e.bn_y16 = ep->bn_y_bf16 ? 1 : 0;
         }
     }
     if (ep->act != MCG_ACT_NONE) {
@@ -2985,7 +3007,6 @@ int make_epi(const mcg_conv_epilogue* ep, const Geom& g, int pass, Epi& e) {
         e.mode |= EPI_MASKMUL; e.mask_in = ep->mask_in;
     }
     if ((e.mode || e.out16) && g.ksplit > 1) return MCG_ERR_UNSUPPORTED;        // partial tiles cannot carry an epilogue (and are added in fp32)
-    if (e.out16 && (e.mode & EPI_BNBWD)) return MCG_ERR_UNSUPPORTED;
     if ((e.mode & EPI_ACT) && (e.mode & ~EPI_ACT)) return MCG_ERR_UNSUPPORTED;            // one class per launch (epi_class)
     if ((e.mode & EPI_BNBWD) && (e.mode & ~EPI_BNBWD)) return MCG_ERR_UNSUPPORTED;
     return MCG_OK;
@@ -3010,7 +3031,7 @@ int conv_fprop_impl(const mcg_conv_geom* c, const float* x, const float* w, cons
     int t = g.tile;
     const int bk = g.bk;
     if (g.prec == MCG_PREC_SPLIT) {                                // fp32 values as three bf16 terms: the LDS-DMA kernels only
-        if ((t != 0 && t != 7 && t != 8 && t != 10) || !split_ok(g, true) || (e.mode & ~(EPI_STATS | EPI_COL | EPI_MASKMUL)) || e.out16) return MCG_ERR_UNSUPPORTED;
+        if ((t != 0 && t != 7 && t != 8 && t != 10) || !split_ok(g, true) || (e.mode & ~(EPI_STATS | EPI_COL | EPI_MASKMUL | EPI_BNBWD)) || e.out16) return MCG_ERR_UNSUPPORTED;
         const Geom h = split_geom(g, true);
         if (t == 10) st = launch_fprop_v2<128, 128, 2, 2, 1>(h, x, w, bias, y, e, ep, s);        // two blocks per CU
         else st = (t == 8 && g.Co >= 256) ? launch_fprop_v2<256, 256, 2, 2, 1>(h, x, w, bias, y, e, ep, s) : launch_fprop_v2<256, 128, 3, 2, 1>(h, x, w, bias, y, e, ep, s);
@@ -3029,7 +3050,7 @@ int conv_fprop_impl(const mcg_conv_geom* c, const float* x, const float* w, cons
     }
     if (t == 6 || t == 9) return MCG_ERR_UNSUPPORTED;
     if (t == 7 || t == 8 || t == 10) {                             // the LDS-DMA kernels (bf16-stored operands, wide layers)
-        if (!v2_ok(g, g.Ci) || e.mode & ~(EPI_STATS | EPI_COL | EPI_MASKMUL)) return MCG_ERR_UNSUPPORTED;
+        if (!v2_ok(g, g.Ci) || e.mode & ~(EPI_STATS | EPI_COL | EPI_MASKMUL | EPI_BNBWD)) return MCG_ERR_UNSUPPORTED;
         if (t == 10) {                                             // 128x128, two buffers: TWO blocks per CU
             if (g.prec == MCG_PREC_F32) return finish(launch_fprop_v2<128, 128, 2, 0>(g, x, w, bias, y, e, ep, s));
             return finish(launch_fprop_v2<128, 128, 2, 2>(g, x, w, bias, y, e, ep, s));
@@ -3107,7 +3128,7 @@ int conv_dgrad_impl(const mcg_conv_geom* c, const float* y, const float* w, cons
     int t = g.tile;
     const int bk = g.bk;
     if (g.prec == MCG_PREC_SPLIT) {                              // fp32 values as three bf16 terms: the LDS-DMA kernels only
-        if ((t != 0 && t != 7 && t != 8 && t != 9 && t != 10) || !split_ok(g, false) || g.Ci < 64 || (g.Ci & (g.Ci - 1)) || (e.mode & ~(EPI_STATS | EPI_COL | EPI_MASKMUL)) || e.out16)
+        if ((t != 0 && t != 7 && t != 8 && t != 9 && t != 10) || !split_ok(g, false) || g.Ci < 64 || (g.Ci & (g.Ci - 1)) || (e.mode & ~(EPI_STATS | EPI_COL | EPI_MASKMUL | EPI_BNBWD)) || e.out16)
             return MCG_ERR_UNSUPPORTED;
         const Geom h = split_geom(g, false);
         if (t == 9) {                                            // patch-stationary, four parity classes per block
@@ -3139,7 +3160,7 @@ int conv_dgrad_impl(const mcg_conv_geom* c, const float* y, const float* w, cons
     }
     if (t == 7 || t == 8 || t == 10) {                           // the LDS-DMA kernels (bf16-stored operands, wide layers)
         const long long frame_ = (long long)g.Ti * g.Hi * g.Wi * g.Ci;
-        if (!v2_ok(g, g.Co) || g.Ci < 64 || (g.Ci & (g.Ci - 1)) || (e.mode & ~(EPI_STATS | EPI_COL | EPI_MASKMUL))) return MCG_ERR_UNSUPPORTED;
+        if (!v2_ok(g, g.Co) || g.Ci < 64 || (g.Ci & (g.Ci - 1)) || (e.mode & ~(EPI_STATS | EPI_COL | EPI_MASKMUL | EPI_BNBWD))) return MCG_ERR_UNSUPPORTED;
         if (t == 10) {                                           // 128x128, two blocks per CU
             if (g.Ci < 128) return MCG_ERR_UNSUPPORTED;
             if (g.prec == MCG_PREC_F32) return finish(launch_dgrad_v2<128, 128, 2, 0>(g, y, w, bias, x, act, accumulate, e, ep, s));

@@ -41,7 +41,7 @@ class ConvEpilogue(C.Structure):
                 ("bn_stats", C.c_void_p * 2), ("bn_act", C.c_int32), ("act", C.c_int32), ("addend", C.c_void_p * 2),
                 ("sigma", C.c_float), ("seed", C.c_uint64), ("stream_id", C.c_uint64 * 2),
                 ("mask_out", C.c_void_p), ("out_bf16", C.c_int32), ("mask_in", C.c_void_p), ("n_slots", C.c_int32),
-                ("slot_stride", C.c_int32)]
+                ("slot_stride", C.c_int32), ("bn_y_bf16", C.c_int32)]
 
 
 _P, _I, _I64, _U64, _F, _D = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double
@@ -86,7 +86,7 @@ SIGNATURES = {
     "mcg_split_planes": (_I, [_I64, _I64, _P, _P, _P]),
 }
 
-ABI_VERSION = 3          # MCG_ABI_VERSION of include/mocogan_hip.h these prototypes were written against
+ABI_VERSION = 4          # MCG_ABI_VERSION of include/mocogan_hip.h these prototypes were written against
 
 _lib = None
 
@@ -483,7 +483,9 @@ def epilogue(sums=SUMS_NONE, groups=1, part=None, bn_y=None, bn_stats=(None, Non
              addend=(None, None), sigma=0.0, seed=0, stream_id=(0, 0), mask_out=None, mask_in=None, out_bf16=False):
     """Builds a ConvEpilogue; the tensors must stay alive until the launch has been queued (they are the caller's)."""
     ep = ConvEpilogue()
-    ep.sums, ep.groups, ep.part, ep.bn_y = sums, groups, _vp(part), _vp(_dense(bn_y))
+    y16 = bn_y is not None and bn_y.dtype == torch.bfloat16
+    ep.sums, ep.groups, ep.part, ep.bn_y = sums, groups, _vp(part), _vp(_dense(bn_y), torch.bfloat16 if y16 else torch.float32)
+    ep.bn_y_bf16 = int(y16)
     ep.bn_stats[0], ep.bn_stats[1] = _vp(bn_stats[0]), _vp(bn_stats[1] if len(bn_stats) > 1 else None)
     ep.bn_act, ep.act = bn_act, act
     ep.addend[0], ep.addend[1] = _vp(_dense(addend[0])), _vp(_dense(addend[1] if len(addend) > 1 else None))

@@ -27,9 +27,13 @@ IMG = 64                      # output size hard-coded in the reference, model/n
 #   stats: BatchNorm statistics (sum, sum of squares per channel) from the producing fprop / deconvolution
 #   dc1  : D's first layer: leaky_relu + add_noise (+ sign bits for backward) in dc1's epilogue, the leaky_relu mask and
 #          dc1's bias gradient in the epilogue of dc2's input-gradient GEMM
-#   bwd  : the per-channel sums of BatchNorm's backward pass from the GEMM that produces the incoming gradient
+#   bwd  : the per-channel sums of BatchNorm's backward pass from the GEMM that produces the incoming gradient, fp32-MFMA kernels
 #          (off by default: measured on MI355X it costs the producing GEMMs more -- they read the saved BatchNorm input
-#          in their epilogue -- than the removed reduction pass took: +0.20 ms against -0.18 ms per iteration at batch 32)
+#          in their per-element epilogue -- than the removed reduction pass took: +0.20 ms against -0.18 ms per iteration at batch 32)
+#   bwd2 : the same sums from the ROW-WISE epilogue of the LDS-DMA kernels (bf16 networks, 'f32x3' split launches): 16-byte reads of
+#          the saved BatchNorm input next to the 16-byte stores; a launch whose kernel cannot carry them falls back to the pass.
+#          Off by default as well: measured at bf16 batch 256 the GEMMs grow by 0.58 ms and the removed pass took 0.6 (10883 against
+#          10894 clips/s); 'f32x3' batch 32: 2693 against 2681 -- with one block per CU nothing overlaps an epilogue's reads
 OUT16 = os.environ.get('MCG_OUT16', '1') == '1'        # bf16 networks: GEMM outputs in bf16 where the schedule allows (A/B switch)
 FUSE = set(filter(None, os.environ.get('MCG_FUSE', 'stats,dc1').split(',')))
 
@@ -150,6 +154,24 @@ class _Net:
                 return split()
         return hl.conv_fprop(g, x, w, b, y, ep=ep, must_fuse=must_fuse)
 
+    def _fuse_bwd_sums(self, s16, kind, g):
+        """should the GEMM (kind, g) that produces a gradient also produce the sums of the BatchNorm backward pass that reads it?"""
+        if self.sync_bn is not None:
+            return False
+        if self.precision == 'f32x3':
+            return 'bwd2' in FUSE and hl.split_decided(kind, g)
+        return ('bwd2' in FUSE) if s16 else ('bwd' in FUSE)
+
+    @staticmethod
+    def _with_bwd_sums(launch, ep):
+        """launch(ep) -> fused?  A kernel that cannot carry the sums (an fp32-MFMA-family tile around bf16 tensors, the patch kernel)
+        refuses before anything is queued: the plain launch follows and the stand-alone pass does the sums."""
+        try:
+            return launch(ep)
+        except hl.McgError:
+            launch(None)
+            return False
+
     def _split_only(self, *launches):
         """'f32x3': may the producer of a tensor write its split form ONLY?  Yes when every GEMM that reads it -- launches:
         (pass, geometry) pairs -- is known to take the split form (hl.split_decided); the fp32 tensor then stays allocated (shapes,
@@ -174,7 +196,7 @@ class _Net:
             xs = xs or (lambda: hl.split_planes(x))
             ys = ys or (lambda: hl.split_planes(y))
 
-            def plain(out=None):
+            def plain():
                 hl.conv_wgrad(g, x, y, self._wg_scratch(dw))
 
             def split():
@@ -570,7 +592,6 @@ class DisNet(_Net):
             hl.fc_wgrad(N, k, co5, a5.view(N, k), g_logits, fp.grad('dc5/W').view(co5, k), fp.grad('dc5/b'))
         g = torch.empty_like(a5)
         hl.fc_dgrad(N, k, co5, g_logits, fp.param('dc5/W').view(co5, k), None, 0, g.view(N, k))
-        fuse_bwd = 'bwd' in FUSE and self.sync_bn is None
         mask1 = saved.get('mask1')
         pending = None            # (epilogue, partial sums) the GEMM that produced g left for the layer processed next
         for l in (4, 3, 2, 1):
@@ -626,19 +647,18 @@ class DisNet(_Net):
             if l > 1:
                 w = self._w('dc%d/W' % l, s16)
                 # bf16 networks: the gradient BatchNorm's backward of layer l - 1 reads is bf16 as well (see forward_groups)
-                g16 = (OUT16 and l > 2 and s16 and self.sync_bn is None and not fuse_bwd
-                       and hl.dgrad_tile(geom, g, w, None) < 1000)
+                g16 = OUT16 and l > 2 and s16 and self.sync_bn is None and hl.dgrad_tile(geom, g, w, None) < 1000
                 ga = torch.empty_like(saved['a'][l], dtype=torch.bfloat16 if g16 else torch.float32)
                 if l == 2 and mask1 is not None:
                     part = self._part_buf(geom, 'dgrad', 1) if param_grads else None
                     ep = hl.epilogue(mask_in=mask1, sums=hl.SUMS_COL if param_grads else hl.SUMS_NONE, groups=1, part=part)
                     self._cdgrad(geom, g, 'dc%d/W' % l, w, None, ga, ep=ep, must_fuse=True, ys=gys)
                     pending = (ep, part) if param_grads else None
-                elif l > 2 and fuse_bwd and not s16:
+                elif l > 2 and self._fuse_bwd_sums(s16, 'dgrad', geom):
                     part = self._part_buf(geom, 'dgrad', G)
                     ep = hl.epilogue(sums=hl.SUMS_BN_BWD, groups=G, part=part, bn_y=saved['y'][l - 1], bn_stats=saved['stats'][l - 1],
-                                     bn_act=hl.ACT_LRELU)
-                    if self._cdgrad(geom, g, 'dc%d/W' % l, w, None, ga, ep=ep, ys=gys):
+                                     bn_act=hl.ACT_LRELU, out_bf16=g16)
+                    if self._with_bwd_sums(lambda e: self._cdgrad(geom, g, 'dc%d/W' % l, w, None, ga, ep=e, ys=gys), ep):
                         pending = (ep, part)
                 else:
                     self._cdgrad(geom, g, 'dc%d/W' % l, w, None, ga, ys=gys)
@@ -870,7 +890,6 @@ class GenNet(_Net):
         hl.set_tag('G')
         g = torch.empty((frames, IMG, IMG, self.cp_out), device=dev)
         hl.tanh_bwd_to_frames(n, T, IMG * IMG * self.cp_out, gx_clip, saved['x'], g)
-        fuse_bwd = 'bwd' in FUSE and self.sync_bn is None
         pending = None               # (epilogue, partial sums) the GEMM that produced g left for BatchNorm's backward
         for l in (5, 4, 3, 2):
             geom = self._geom(l, frames)
@@ -903,15 +922,15 @@ class GenNet(_Net):
             if l == 2 and on_late_bucket is not None:
                 self._after_wgrads(on_late_bucket)
             wl = self._w('dc%d/W' % l, s16)
-            g16 = (OUT16 and 2 < l < 5 and s16 and self.sync_bn is None and not fuse_bwd       # (layer 1's gradient feeds the fp32 fully-connected layer)
+            g16 = (OUT16 and 2 < l < 5 and s16 and self.sync_bn is None                        # (layer 1's gradient feeds the fp32 fully-connected layer)
                    and hl.fprop_tile(geom, g, wl, None) < 1000)                            # (as DisNet.backward)
             ga = torch.empty_like(saved['a'][l], dtype=torch.bfloat16 if g16 else torch.float32)
             pending = None
-            if fuse_bwd and not s16:     # ga is the gradient w.r.t. relu(bn_{l-1}(y_{l-1})): the sums of that BatchNorm's backward
+            if self._fuse_bwd_sums(s16, 'fprop', geom):     # ga is the gradient w.r.t. relu(bn_{l-1}(y_{l-1})): the sums of that BatchNorm's backward
                 part = self._part_buf(geom, 'fprop', 1)
                 ep = hl.epilogue(sums=hl.SUMS_BN_BWD, groups=1, part=part, bn_y=saved['y'][l - 1], bn_stats=[saved['stats'][l - 1]],
-                                 bn_act=hl.ACT_RELU)
-                if self._cfprop(geom, g, 'dc%d/W' % l, wl, None, ga, ep=ep, xs=gxs):
+                                 bn_act=hl.ACT_RELU, out_bf16=g16)
+                if self._with_bwd_sums(lambda e: self._cfprop(geom, g, 'dc%d/W' % l, wl, None, ga, ep=e, xs=gxs), ep):
                     pending = (ep, part)
             else:
                 self._cfprop(geom, g, 'dc%d/W' % l, wl, None, ga, xs=gxs)

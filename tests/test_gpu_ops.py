@@ -950,6 +950,75 @@ def test_lds_dma_kernels_match_the_oracle(hl, case, tile, prec):
                       torch.zeros((32, 4, 4, 4, 16), device="cuda", dtype=odt), None, torch.zeros((2, 2, 8, 8, 32), device="cuda"))
 
 
+@pytest.mark.parametrize("case", [(2, 6, 16, 128, 256, 4), (4, 1, 16, 128, 128, 1), (2, 5, 8, 256, 256, 4)])
+@pytest.mark.parametrize("tile", [7, 8, 10])
+@pytest.mark.parametrize("prec", ['bf16s', 'f32x3'])
+def test_lds_dma_kernels_carry_batchnorm_backward_sums(hl, case, tile, prec):
+    """MCG_SUMS_BN_BWD in the row-wise epilogue of the LDS-DMA kernels (round 3): the input-gradient GEMM of a discriminator layer /
+    the backward-data GEMM of a generator layer also produces (sum g', sum g' x_hat) of the BatchNorm backward pass that reads its
+    output -- with bf16 tensors around it in bf16 networks (the sums are those of the STORED gradient) and with split operands.
+    Checked against the stand-alone pass on the same stored values, for one and two groups, both activations, both passes."""
+    N, Ti, H, Ci, Co, kt = case
+    rng = np.random.RandomState(9300 + 7 * tile + (prec == 'bf16s'))
+    lay = L()
+    s16 = prec == 'bf16s'
+    rnd = _bf16_round if s16 else (lambda a: np.asarray(a, np.float32).astype(np.float64))
+    x, W = rnd(rng.uniform(-1, 1, (N, Ci, Ti, H, H))), rnd(rng.randn(Co, Ci, kt, 4, 4) * 0.1)
+    gy = rnd(rng.randn(N, Co, Ti - kt + 1, H // 2, H // 2))
+    xd, wd, gyd = lay.act_to_dev(dev(x)), lay.conv_w_to_dev(dev(W)), lay.act_to_dev(dev(gy))
+    g = hl.make_geom(N, Ti, H, H, Ci, Co, kt, precision=prec)
+    g.tile = tile
+    if s16:
+        ops = dict(x=xd.to(torch.bfloat16), w=wd.to(torch.bfloat16), wd=wd.to(torch.bfloat16), gy=gyd.to(torch.bfloat16))
+    else:
+        ops = dict(x=hl.split_planes(xd), w=hl.split_planes(wd), wd=hl.split_planes(wd, run=16 * kt * 16 * Ci), gy=hl.split_planes(gyd))
+    odt = torch.bfloat16 if s16 else torch.float32
+    ws = torch.empty(hl.bn_workspace_floats(max(Ci, Co, 64)), device="cuda")
+    for kind in ('dgrad', 'fprop'):
+        C_out = Ci if kind == 'dgrad' else Co
+        oshape = (N, Ti, H, H, Ci) if kind == 'dgrad' else (N, g.To, g.Ho, g.Wo, Co)
+        M = int(np.prod(oshape[:-1]))
+
+        def launch(out, ep=None):
+            if kind == 'dgrad':
+                return hl.conv_dgrad(g, ops['gy'], ops['wd'], None, out, ep=ep, must_fuse=ep is not None)
+            return hl.conv_fprop(g, ops['x'], ops['w'], None, out, ep=ep, must_fuse=ep is not None)
+        plain = torch.empty(oshape, device="cuda", dtype=odt)
+        launch(plain)
+        ybn = (torch.randn((M, C_out), device="cuda") * 1.3 + 0.2).to(odt)          # the saved BatchNorm input (bf16 in bf16 networks)
+        gam = dev(1 + 0.1 * rng.randn(C_out))
+        for groups in (1, 2):
+            mg = M // groups
+            st = []
+            for gi in range(groups):
+                s_ = torch.empty(4 * C_out, device="cuda")
+                hl.bn_stats(mg, C_out, ybn[gi * mg:(gi + 1) * mg].float(), gam, dev(0.1 * rng.randn(C_out)), s_, None, None, ws)
+                st.append(s_)
+            for act in (hl.ACT_LRELU, hl.ACT_RELU):
+                part = torch.full((hl.epilogue_part_floats(g, kind, groups),), float('nan'), device="cuda")
+                ep = hl.epilogue(sums=hl.SUMS_BN_BWD, groups=groups, part=part, bn_y=ybn.view(oshape), bn_stats=st, bn_act=act, out_bf16=s16)
+                out = torch.empty(oshape, device="cuda", dtype=odt)
+                assert launch(out, ep)
+                assert torch.equal(out, plain)
+                for gi in range(groups):
+                    sl = slice(gi * mg, (gi + 1) * mg)
+                    gin, yin = out.view(M, C_out)[sl].contiguous(), ybn[sl].contiguous()
+                    gref, dg_ref, db_ref = torch.empty((mg, C_out), device="cuda"), torch.zeros(C_out, device="cuda"), torch.zeros(C_out, device="cuda")
+                    hl.bn_act_bwd(mg, C_out, gin, yin, st[gi], gam, act, gref, dg_ref, db_ref, ws)
+                    got, dg, db = torch.empty((mg, C_out), device="cuda"), torch.zeros(C_out, device="cuda"), torch.zeros(C_out, device="cuda")
+                    hl.bn_act_bwd_from_partials(mg, C_out, gin, yin, st[gi], gam, act, part[gi * 2 * C_out:], ep.n_slots, ep.slot_stride, got, dg, db, ws)
+                    assert rel_l2(got, gref.cpu().double().numpy()) < 1e-5, (kind, groups, gi, act)
+                    assert rel_l2(dg, dg_ref.cpu().double().numpy()) < 1e-5 and rel_l2(db, db_ref.cpu().double().numpy()) < 1e-5
+    # the kernels of the fp32-MFMA family refuse the combination with bf16 tensors (the caller then runs the stand-alone pass)
+    if s16:
+        g.tile = 1
+        with pytest.raises(hl.McgError):
+            hl.conv_dgrad(g, ops['gy'], ops['wd'], None, torch.empty((N, Ti, H, H, Ci), device="cuda", dtype=odt),
+                          ep=hl.epilogue(sums=hl.SUMS_BN_BWD, groups=1, part=torch.zeros(hl.epilogue_part_floats(g, 'dgrad', 1), device="cuda"),
+                                         bn_y=torch.zeros((N, Ti, H, H, Ci), device="cuda", dtype=odt), bn_stats=[torch.ones(4 * Ci, device="cuda")],
+                                         bn_act=hl.ACT_RELU, out_bf16=True), must_fuse=True)
+
+
 SPLIT_CASES = [(2, 7, 16, 64, 128, 4),      # 3-D, Ci = 64 (dgrad: the 256 x 64 tile)
                (3, 1, 16, 128, 64, 1),      # ragged 256-row tile; Co = 64
                (1, 5, 8, 256, 256, 4),      # long K, the 256 x 256 tile when asked for

@@ -318,6 +318,10 @@ def test_update_core_with_split_fp32_convolutions(pkg, monkeypatch):
     assert hl.split_only_outputs > before_only
     monkeypatch.setenv('MCG_SPLIT_ONLY', '0')                      # the other path: fp32 tensors, split on the way into the GEMMs
     _run_steps(pkg, "normal", 6, nf=16, n=3, steps=1, seed=77, min_tight_steps=0, precision='f32x3')
+    # BatchNorm's backward sums from the row-wise epilogue of the split launches (nets.FUSE 'bwd2': off by default, no gain measured)
+    nets = pkg[2]
+    monkeypatch.setattr(nets, 'FUSE', nets.FUSE | {'bwd2'})
+    _run_steps(pkg, "normal", 6, nf=16, n=3, steps=1, seed=77, min_tight_steps=0, precision='f32x3')
 
 
 PERF_CASES = [("normal", 0, 1303), ("normal", 6, 1311), ("infogan", 6, 1313), ("cgan", 6, 1320)]

@@ -49,7 +49,6 @@ def main():
     ap.add_argument('--tile', type=int, default=0)
     ap.add_argument('--only', default='')
     ap.add_argument('--precision', default='f32', choices=['f32', 'bf16', 'bf16s', 'f32x3'])
-    ap.add_argument('--check', action='store_true', help='f32x3: also print the error of each pass against an fp64 convolution of a few output rows')
     ap.add_argument('--net', default='', help='restrict to layers whose name starts with this (e.g. D_V)')
     ap.add_argument('--layer', default='', help='restrict to layers whose name contains this (e.g. dc1)')
     ap.add_argument('--autotune', action='store_true', help='time the tile candidates per geometry first')
