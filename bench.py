@@ -66,6 +66,13 @@ def dv_conv_algorithmic_bytes_per_step(batch, dtype='f32'):
     fprop = 2 * batch * (sum(x_b) + sum(y_b)) + sum(w_b)
     wgrad = 2 * batch * (sum(x_b) + sum(y_b)) + sum(w_b)
     dgrad = 2 * batch * (sum(y_b[1:]) + sum(x_b[1:])) + batch * (sum(y_b) + sum(x_b)) + 2 * sum(w_b)
+    if dtype == 'f32x3':
+        # the INPUT operands of dc2..dc4's launches are read as three bf16 terms (6 instead of 4 bytes per value); outputs stay fp32
+        xin, yin, win = sum(x_b[1:]), sum(y_b[1:]), sum(w_b[1:])
+        extra = 0.5 * (2 * batch * xin + win)                       # fprop reads x, w
+        extra += 0.5 * (2 * batch * (xin + yin))                    # wgrad reads x, y
+        extra += 0.5 * (3 * batch * yin + 2 * win)                  # dgrad (two launches at 2n / n clips) reads y, w
+        return fprop + wgrad + dgrad + extra
     return fprop + wgrad + dgrad
 
 
@@ -73,7 +80,7 @@ def pmc_traffic(batch, dtype='f32'):
     """HBM-side traffic of the D_V conv launches of one step, from the committed rocprofv3 --pmc summary
     (FETCH_SIZE / WRITE_SIZE cannot be read from inside the process; tools/pmc_traffic.py documents the
     collection).  Scaled linearly from the profiled batch.  Returns (bytes_per_step | None, source)."""
-    names = ('r03_dv_conv_traffic_bf16.json',) if dtype == 'bf16' else \
+    names = ('r03_dv_conv_traffic_bf16.json',) if dtype == 'bf16' else ('r03_dv_conv_traffic_f32x3.json',) if dtype == 'f32x3' else \
         ('r03_dv_conv_traffic.json', 'r02_dv_conv_traffic.json', 'r01_dv_conv_traffic.json')
     for name in names:                                                              # newest collection first
         try:
@@ -341,7 +348,7 @@ def main():
             gflop = 2.0 * N_ * (T_ - kt_ + 1) * (H_ // 2) ** 2 * kt_ * 16 * min(Ci_, 3 if Ci_ == 4 else Ci_) * Co_ / 1e9
             by_layer[k] = {"launches_per_step": n_l / steps, "ms_per_launch": ms / n_l,
                            "tflops": gflop * n_l / ms if ms > 0 else 0.0}
-        traffic, traffic_src = pmc_traffic(B, dtype) if dtype != 'f32x3' else (None, None)
+        traffic, traffic_src = pmc_traffic(B, dtype)
         peak = PEAK_BF16_MFMA_TFLOPS if dtype == 'bf16' else PEAK_FP32_MFMA_TFLOPS
         cfg_name = "configs[2]" if (dtype == 'bf16' and B == 256 and model == 'normal') else \
             "configs[1]" if (dtype == 'f32' and B == 32 and model == 'normal') else \

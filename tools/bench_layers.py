@@ -67,19 +67,20 @@ def main():
             continue
         if args.layer and args.layer not in name:
             continue
-        g = hl.make_geom(N, T, H, H, Ci, Co, kt, precision=args.precision, ci_valid=ci_real)
+        prec = args.precision
+        if prec == 'f32x3' and (Ci % 16 or Co % 16):
+            prec = 'f32'                                    # the 4-channel layers of an f32x3 network run the fp32 kernels
+        if prec == 'bf16s' and (Ci % 8 or Co % 8):
+            prec = 'bf16'                                   # ... of a bf16 network: fp32 tensors, rounded in the kernel
+        g = hl.make_geom(N, T, H, H, Ci, Co, kt, precision=prec, ci_valid=ci_real)
         x = torch.randn((N, T, H, H, Ci), device='cuda')
         y = torch.randn((N, g.To, g.Ho, g.Wo, Co), device='cuda')
         w = torch.randn((Co, kt, 4, 4, Ci), device='cuda') * 0.05
         dw = torch.zeros_like(w)
         flops = 2.0 * N * g.To * g.Ho * g.Wo * kt * 16 * ci_real * Co
-        if args.precision == 'bf16s':                       # operands bf16 in memory, outputs fp32
-            if Ci % 8 or Co % 8:
-                continue
+        if prec == 'bf16s':                                 # operands bf16 in memory, outputs fp32
             xi, yi, wi = x.to(torch.bfloat16), y.to(torch.bfloat16), w.to(torch.bfloat16)
-        elif args.precision == 'f32x3':                     # fp32 values as three bf16 terms (fprop / dgrad; the split of the operands is not timed)
-            if Ci % 16 or Co % 16:
-                continue
+        elif prec == 'f32x3':                               # fp32 values as three bf16 terms (the split of the operands is not timed)
             xi, yi, wi = hl.split_planes(x), hl.split_planes(y), hl.split_planes(w)
             wd = hl.split_planes(w, run=16 * kt * 16 * Ci)      # the filter as dgrad reads it: planes of 16 filters
         else:
@@ -87,7 +88,7 @@ def main():
         passes = [('fprop', lambda: hl.conv_fprop(g, xi, wi, None, y)),
                   ('dgrad', lambda: hl.conv_dgrad(g, yi, wi, None, x)),
                   ('wgrad', lambda: hl.conv_wgrad(g, xi, yi, dw))]
-        if args.precision == 'f32x3':
+        if prec == 'f32x3':
             passes = [passes[0], ('dgrad', lambda: hl.conv_dgrad(g, yi, wd, None, x)), passes[2]]
         for p, fn in passes:
             if args.only and p != args.only:
