@@ -185,6 +185,39 @@ def test_shipped_tile_table_is_well_formed():
         seen.add(tuple(key))
 
 
+def test_split_form_predicates(monkeypatch):
+    """hiplib.split_covers / split_decided (host logic of the 'f32x3' networks): which launches have a MCG_PREC_SPLIT form, and when
+    a producer may rely on it (MCG_SPLIT=always / never, else the table entry 'split-<pass>' == 1)."""
+    import mocogan_chainer_amd.hiplib as hl
+    wide = hl.make_geom(64, 13, 32, 32, 64, 128, 4)             # D_V dc2 at 64 clips
+    clip = hl.make_geom(64, 16, 64, 64, 4, 64, 4, ci_valid=3)   # the 4-channel first layer
+    narrow = hl.make_geom(4, 5, 16, 16, 16, 32, 4)
+    assert hl.split_covers('fprop', wide) and hl.split_covers('dgrad', wide) and hl.split_covers('wgrad', wide)
+    assert not any(hl.split_covers(k, clip) for k in ('fprop', 'dgrad', 'wgrad'))
+    assert hl.split_covers('fprop', narrow) and not hl.split_covers('dgrad', narrow) and not hl.split_covers('wgrad', narrow)
+    huge = hl.make_geom(512, 13, 32, 32, 64, 128, 4)            # 8 bytes per value must stay below the 2 GiB buffer range
+    assert not hl.split_covers('fprop', huge)
+    monkeypatch.setenv('MCG_SPLIT', 'always')
+    assert hl.split_decided('fprop', wide) and not hl.split_decided('fprop', clip)
+    monkeypatch.setenv('MCG_SPLIT', 'never')
+    assert not hl.split_decided('fprop', wide)
+    monkeypatch.setenv('MCG_SPLIT', 'auto')
+    key = hl._geom_key('split-fprop', wide)
+    old = hl._tile_cache.pop(key, None)
+    try:
+        assert not hl.split_decided('fprop', wide)              # undecided: the producers keep writing fp32
+        hl._tile_cache[key] = 1
+        assert hl.split_decided('fprop', wide)
+        hl._tile_cache[key] = 0
+        assert not hl.split_decided('fprop', wide)
+    finally:
+        hl._tile_cache.pop(key, None)
+        if old is not None:
+            hl._tile_cache[key] = old
+    g3 = hl.with_precision(wide, 'f32x3')
+    assert g3.precision == hl.PREC_SPLIT and g3.tile == 0 and wide.precision == hl.PREC_F32
+
+
 def test_prefetch_iterator_resumes_from_a_restored_position():
     """load_state must drop the look-ahead queued from the old position; a resumed PrefetchIterator has to
     show what a SerialIterator restored to the same state shows (reference: --resume, train.py:162-163)."""
