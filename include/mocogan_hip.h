@@ -96,7 +96,7 @@ typedef struct mcg_conv_geom {
                                 * G's dc4): one block per frame computes all four output-parity classes from a y patch held
                                 * in LDS (each y pixel is loaded once per temporal tap instead of once per class and tap);
                                 * 10 = the LDS-DMA kernels with a 128x128 tile and two tile buffers: TWO blocks per CU (fp32,
-                                * bf16-stored or MCG_PREC_SPLIT operands; dgrad: Ci >= 128; wgrad: Co >= 128) -- fewer FLOP per LDS byte, but the
+                                * bf16-stored or MCG_PREC_SPLIT operands; dgrad: Ci >= 128, or Ci = 64 as a 256x64 tile with two buffers (bf16-stored / split); wgrad: Co >= 128) -- fewer FLOP per LDS byte, but the
                                 * epilogue of one block runs under the K loop of the other and small launches divide evenly;
                                 * MCG_PREC_SPLIT launches accept 0 / 7 / 8 / 10 (+ 1000 / 2000 in fprop and dgrad) and, in dgrad, 9;
                                 * +100 / +200 also fixes the K-step depth to 32 / 64; +1000 / +2000

@@ -3135,8 +3135,8 @@ int conv_dgrad_impl(const mcg_conv_geom* c, const float* y, const float* w, cons
             if (!dgrad_patch_ok(h)) return MCG_ERR_UNSUPPORTED;
             return finish(launch_dgrad_patch<1>(h, y, w, bias, x, act, accumulate, e, ep, s));
         }
-        if (t == 10) {                                           // 128x128, two blocks per CU
-            if (g.Ci < 128) return MCG_ERR_UNSUPPORTED;
+        if (t == 10) {                                           // two blocks per CU: 128x128, or 256x64 with two buffers (2 x 80 KB of LDS)
+            if (g.Ci == 64) return finish(launch_dgrad_v2<256, 64, 2, 2, 1>(h, y, w, bias, x, act, accumulate, e, ep, s));
             return finish(launch_dgrad_v2<128, 128, 2, 2, 1>(h, y, w, bias, x, act, accumulate, e, ep, s));
         }
         if (g.Ci == 64) st = launch_dgrad_v2<256, 64, 3, 2, 1>(h, y, w, bias, x, act, accumulate, e, ep, s);
@@ -3161,8 +3161,11 @@ int conv_dgrad_impl(const mcg_conv_geom* c, const float* y, const float* w, cons
     if (t == 7 || t == 8 || t == 10) {                           // the LDS-DMA kernels (bf16-stored operands, wide layers)
         const long long frame_ = (long long)g.Ti * g.Hi * g.Wi * g.Ci;
         if (!v2_ok(g, g.Co) || g.Ci < 64 || (g.Ci & (g.Ci - 1)) || (e.mode & ~(EPI_STATS | EPI_COL | EPI_MASKMUL | EPI_BNBWD))) return MCG_ERR_UNSUPPORTED;
-        if (t == 10) {                                           // 128x128, two blocks per CU
-            if (g.Ci < 128) return MCG_ERR_UNSUPPORTED;
+        if (t == 10) {                                           // two blocks per CU: 128x128, or (Ci = 64, bf16-stored) 256x64 with two buffers
+            if (g.Ci == 64) {
+                if (g.prec != MCG_PREC_BF16_STORE) return MCG_ERR_UNSUPPORTED;
+                return finish(launch_dgrad_v2<256, 64, 2, 2>(g, y, w, bias, x, act, accumulate, e, ep, s));
+            }
             if (g.prec == MCG_PREC_F32) return finish(launch_dgrad_v2<128, 128, 2, 0>(g, y, w, bias, x, act, accumulate, e, ep, s));
             return finish(launch_dgrad_v2<128, 128, 2, 2>(g, y, w, bias, x, act, accumulate, e, ep, s));
         }

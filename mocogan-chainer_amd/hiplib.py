@@ -398,8 +398,10 @@ def _tuned(kind, g, extra, out_side, run_on):
                 # against 128-134 TFLOP/s on the big layers, and one 256-row block per CU quantises badly at batch 32
                 if not (kind == "dgrad" and g.Ci == 64):        # (64 output columns per parity class: the 256x64 tile never wins)
                     cands = cands + V2_CANDIDATES
-                elif g.Ho == 16 and g.Wo == 16:
-                    cands = cands + (9,)                        # ... the patch-stationary kernel, four classes per block, is made for it
+                else:
+                    cands = cands + (10,)                       # ... but 256x64 with two buffers lets two blocks share a CU
+                    if g.Ho == 16 and g.Wo == 16:
+                        cands = cands + (9,)                    # ... and the patch-stationary kernel, four classes per block, is made for it
             if g.precision == PREC_F32 and g.Ci >= 64 and g.Co >= 64 and kind != "dgrad" or (g.precision == PREC_F32 and kind == "dgrad" and g.Ci >= 128 and g.Co >= 64):
                 cands = cands + (10,)                           # the LDS-DMA kernel on fp32 operands, 128x128, two blocks per CU
             if g.precision == PREC_SPLIT:
