@@ -403,20 +403,29 @@ def main():
     # networks, batch 256) and configs[3] (--model infogan, batch 32); on 8 GPUs configs[4] (global batch 1024).
     headline_cfg = args.model == 'normal' and args.dtype == 'f32' and args.batch == 32
     secondary = []
+
+    def also(model, dtype, B):
+        """a secondary workload must never cost the headline its line: a failure (the same on every rank: same code, same shapes)
+        is recorded in its place"""
+        try:
+            secondary.append(measure(model, dtype, B, args.secondary_steps, 3, default_overlap(dtype, B)))
+        except Exception as exc:                                   # noqa: BLE001
+            if rank == 0:
+                secondary.append({"config": {"workload": "%s %s batch %d" % (model, dtype, B)}, "dtype": dtype, "error": repr(exc)[:300]})
     if args.secondary and headline_cfg:
         if world == 1:
-            secondary.append(measure('normal', 'bf16', 256, args.secondary_steps, 3, default_overlap('bf16', 256)))
-            secondary.append(measure('infogan', 'f32', 32, args.secondary_steps, 3, default_overlap('f32', 32)))
+            also('normal', 'bf16', 256)
+            also('infogan', 'f32', 32)
             # configs[1] again with the wide convolutions' fp32 products formed on the bf16 matrix pipe (three-term operands)
-            secondary.append(measure('normal', 'f32x3', 32, args.secondary_steps, 3, default_overlap('f32x3', 32)))
-        elif world == 8:
-            secondary.append(measure('normal', 'f32', 128, args.secondary_steps, 3, default_overlap('f32', 128)))
-            secondary.append(measure('normal', 'f32x3', 128, args.secondary_steps, 3, default_overlap('f32x3', 128)))
+            also('normal', 'f32x3', 32)
+        elif world == 8 or os.environ.get('MCG_BENCH_SECONDARY_DP') == '1':
+            also('normal', 'f32', 128)
+            also('normal', 'f32x3', 128)
     if rank == 0 and args.save_tiles:
         hl.save_tile_choices(args.save_tiles)
     if rank == 0:
         keep = ("config", "dtype", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "roofline", "dist", "losses")
-        out["secondary"] = [{k: s_[k] for k in keep} for s_ in secondary]
+        out["secondary"] = [{k: s_[k] for k in keep if k in s_} | ({"error": s_["error"]} if "error" in s_ else {}) for s_ in secondary]
         out["tile_choices"] = {"%s N=%d T=%d H=%d Ci=%d Co=%d p=%d" % (k[0], k[1], k[2], k[3], k[5], k[6], k[9]): v
                                for k, v in sorted(hl.tile_choices().items(), key=str)}
         if world == 1 and not args.no_cpu_baseline:
