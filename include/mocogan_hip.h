@@ -304,7 +304,8 @@ int mcg_tanh_bwd_to_frames(int N, int T, int64_t frame_elems, const float* g_cli
  * z [T*N][dim_zc + dim_zm] = concat(tile(zc), zm)  (model/net.py:102-107).
  * saved: [T][N][4*dim_zm] (r, z, h_bar, h_prev) for the backward pass.
  * Sizes: dim_zm <= 16 and dim_zm + dim_zl <= 32 (one thread per hidden unit, the weights of its row in registers;
- * the reference's default is 10 (+ 6 labels)); larger sizes return MCG_ERR_UNSUPPORTED. */
+ * the reference's default is 10 (+ 6 labels)); up to dim_zm = 64 and dim_zm + dim_zl = 128 the same recurrence with the
+ * weights read from memory (~10x the time per step); larger sizes return MCG_ERR_UNSUPPORTED. */
 int mcg_gru_seq_fwd(int N, int T, int dim_zm, int dim_zl, int dim_zc, const float* params,
                     const float* h0, const float* e, const int32_t* labels, const float* zc,
                     float* z, float* saved, void* stream);

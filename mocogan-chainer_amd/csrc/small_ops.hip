@@ -4,6 +4,7 @@
 // All tensors are channels-last fp32 with C % 4 == 0, so every kernel moves 16 bytes per lane.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #include "mocogan_hip.h"
 #include "mcg_common.h"
 
@@ -860,6 +861,125 @@ __global__ __launch_bounds__(GRU_S * GRU_U) void gru_bwd_kernel(int N, int T, in
 }
 
 // ------------------------------------------------------------------------------------------
+// GRU, wide states (16 < dim_zm <= 64, dim_zm + dim_zl <= 128; the reference accepts any --dim_zm, train.py:39): the same
+// recurrence with the weights read from memory (L1 / L2: a few hundred KB at most) and run-time loop bounds -- a step is a chain of
+// dependent loads, ~10 x the time of the register-resident kernels above, which keep the default sizes.  Thread = (sample, unit):
+// GRUW_S samples x 64 units per block.  Backward: every thread adds its row's parameter gradients into the block's copy of the
+// gradient in LDS (dynamic: gru_offsets().total floats) step by step; one pass of global atomics at the end, as above.
+// ------------------------------------------------------------------------------------------
+constexpr int GRUW_S = 4, GRUW_U = 64, GRUW_IN = 128;
+
+__global__ __launch_bounds__(GRUW_S * GRUW_U) void gru_fwd_wide_kernel(int N, int T, int dz, int dl, int dc, const float* __restrict__ params,
+                                                                     const float* __restrict__ h0, const float* __restrict__ e,
+                                                                     const int32_t* __restrict__ labels, const float* __restrict__ zc,
+                                                                     float* __restrict__ z, float* __restrict__ saved) {
+    __shared__ float xs[GRUW_S][GRUW_IN], hs[GRUW_S][GRUW_U], rhs[GRUW_S][GRUW_U];
+    const GruOff o = gru_offsets(dz, dl);
+    const int s = threadIdx.x / GRUW_U, j = threadIdx.x % GRUW_U;
+    const int n = blockIdx.x * GRUW_S + s;
+    const bool live = n < N && j < dz;
+    const int in = dz + dl, zw = dc + dz;
+    const float* Wr = params + o.w[0] + j * in; const float* Ur = params + o.w[1] + j * dz;
+    const float* Wz = params + o.w[2] + j * in; const float* Uz = params + o.w[3] + j * dz;
+    const float* Wh = params + o.w[4] + j * in; const float* Uh = params + o.w[5] + j * dz;
+    const float b_r = j < dz ? params[o.b[0] + j] + params[o.b[1] + j] : 0.f;
+    const float b_z = j < dz ? params[o.b[2] + j] + params[o.b[3] + j] : 0.f;
+    const float b_h = j < dz ? params[o.b[4] + j] + params[o.b[5] + j] : 0.f;
+    for (int c = j; c < GRUW_IN; c += GRUW_U) xs[s][c] = 0.f;
+    hs[s][j] = 0.f; rhs[s][j] = 0.f;
+    __syncthreads();
+    if (live) hs[s][j] = h0[n * dz + j];
+    if (n < N) {
+        for (int c = j; c < dl; c += GRUW_U) xs[s][c] = (c == labels[n]) ? 1.f : 0.f;
+        for (int t = 0; t < T; ++t) for (int c = j; c < dc; c += GRUW_U) z[((long long)t * N + n) * zw + c] = zc[n * dc + c];
+    }
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        if (live) xs[s][dl + j] = e[((long long)t * N + n) * dz + j];
+        __syncthreads();
+        float ar = b_r, az = b_z, hb = b_h;
+        if (live) {
+            for (int c = 0; c < in; ++c) { const float xv = xs[s][c]; ar = fmaf(Wr[c], xv, ar); az = fmaf(Wz[c], xv, az); hb = fmaf(Wh[c], xv, hb); }
+            for (int c = 0; c < dz; ++c) { const float hv = hs[s][c]; ar = fmaf(Ur[c], hv, ar); az = fmaf(Uz[c], hv, az); }
+        }
+        const float r = sigmoidf_(ar), zz = sigmoidf_(az), h = hs[s][j];
+        if (live) rhs[s][j] = r * h;
+        __syncthreads();
+        if (live) {
+            for (int c = 0; c < dz; ++c) hb = fmaf(Uh[c], rhs[s][c], hb);
+            hb = tanhf(hb);
+            const float hn = (1.f - zz) * h + zz * hb;
+            float* sv = saved + ((long long)t * N + n) * 4 * dz;
+            sv[j] = r; sv[dz + j] = zz; sv[2 * dz + j] = hb; sv[3 * dz + j] = h;
+            z[((long long)t * N + n) * zw + dc + j] = hn;
+            hs[s][j] = hn;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(GRUW_S * GRUW_U) void gru_bwd_wide_kernel(int N, int T, int dz, int dl, int dc, const float* __restrict__ params,
+                                                                     const float* __restrict__ e, const int32_t* __restrict__ labels,
+                                                                     const float* __restrict__ saved, const float* __restrict__ gz,
+                                                                     float* __restrict__ dparams) {
+    extern __shared__ float DPw[];                                   // gru_offsets().total floats: the block's share of the gradient
+    __shared__ float xs[GRUW_S][GRUW_IN], ga_s[GRUW_S][GRUW_U], gaz_s[GRUW_S][GRUW_U], gar_s[GRUW_S][GRUW_U];
+    __shared__ float h_s[GRUW_S][GRUW_U], rh_s[GRUW_S][GRUW_U];
+    const GruOff o = gru_offsets(dz, dl);
+    for (int i = threadIdx.x; i < o.total; i += blockDim.x) DPw[i] = 0.f;
+    const int s = threadIdx.x / GRUW_U, j = threadIdx.x % GRUW_U;
+    const int n = blockIdx.x * GRUW_S + s;
+    const bool live = n < N && j < dz;
+    const int in = dz + dl, zw = dc + dz;
+    const float* Uh = params + o.w[5]; const float* Uz = params + o.w[3]; const float* Ur = params + o.w[1];       // column j: [i * dz + j]
+    for (int c = j; c < GRUW_IN; c += GRUW_U) xs[s][c] = 0.f;
+    ga_s[s][j] = 0.f; gaz_s[s][j] = 0.f; gar_s[s][j] = 0.f; h_s[s][j] = 0.f; rh_s[s][j] = 0.f;
+    __syncthreads();
+    if (n < N) for (int c = j; c < dl; c += GRUW_U) xs[s][c] = (c == labels[n]) ? 1.f : 0.f;
+    float gh = 0.f;
+    __syncthreads();
+    for (int t = T - 1; t >= 0; --t) {
+        float r = 0.f, zz = 0.f, hb = 0.f, h = 0.f, gzv = 0.f;
+        if (live) {
+            const float* sv = saved + ((long long)t * N + n) * 4 * dz;
+            r = sv[j]; zz = sv[dz + j]; hb = sv[2 * dz + j]; h = sv[3 * dz + j];
+            gzv = gz[((long long)t * N + n) * zw + dc + j];
+        }
+        const float ghn = gh + gzv;
+        const float gzz = ghn * (hb - h), ghb = ghn * zz;
+        const float ga = ghb * (1.f - hb * hb);
+        const float gaz = gzz * zz * (1.f - zz);
+        if (live) {
+            xs[s][dl + j] = e[((long long)t * N + n) * dz + j];
+            ga_s[s][j] = ga; gaz_s[s][j] = gaz; h_s[s][j] = h; rh_s[s][j] = r * h;
+        }
+        __syncthreads();
+        float grh = 0.f;
+        if (live) for (int i = 0; i < dz; ++i) grh = fmaf(ga_s[s][i], Uh[i * dz + j], grh);
+        gh = ghn * (1.f - zz) + grh * r;
+        const float gar = grh * h * r * (1.f - r);
+        if (live) gar_s[s][j] = gar;
+        __syncthreads();
+        if (live) {
+            for (int i = 0; i < dz; ++i) { gh = fmaf(gaz_s[s][i], Uz[i * dz + j], gh); gh = fmaf(gar_s[s][i], Ur[i * dz + j], gh); }
+            for (int c = 0; c < in; ++c) {
+                const float xv = xs[s][c];
+                atomicAdd(&DPw[o.w[4] + j * in + c], ga * xv); atomicAdd(&DPw[o.w[2] + j * in + c], gaz * xv); atomicAdd(&DPw[o.w[0] + j * in + c], gar * xv);
+            }
+            for (int c = 0; c < dz; ++c) {
+                atomicAdd(&DPw[o.w[5] + j * dz + c], ga * rh_s[s][c]); atomicAdd(&DPw[o.w[3] + j * dz + c], gaz * h_s[s][c]);
+                atomicAdd(&DPw[o.w[1] + j * dz + c], gar * h_s[s][c]);
+            }
+            atomicAdd(&DPw[o.b[4] + j], ga); atomicAdd(&DPw[o.b[5] + j], ga);
+            atomicAdd(&DPw[o.b[2] + j], gaz); atomicAdd(&DPw[o.b[3] + j], gaz);
+            atomicAdd(&DPw[o.b[0] + j], gar); atomicAdd(&DPw[o.b[1] + j], gar);
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < o.total; i += blockDim.x) atomicAdd(dparams + i, DPw[i]);
+}
+
+// ------------------------------------------------------------------------------------------
 // losses: one block
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float softplusf_(float v) { return fmaxf(v, 0.f) + log1pf(expf(-fabsf(v))); }
@@ -1276,9 +1396,12 @@ extern "C" int mcg_fc_wgrad(int M, int K, int Co, const float* x, const float* y
 extern "C" int mcg_gru_seq_fwd(int N, int T, int dim_zm, int dim_zl, int dim_zc, const float* params, const float* h0, const float* e,
                                const int32_t* labels, const float* zc, float* z, float* saved, void* stream) {
     if (!params || !h0 || !e || !zc || !z || !saved || N <= 0 || T <= 0) return MCG_ERR_BAD_ARG;
-    if (dim_zm <= 0 || dim_zm > GRU_U || dim_zl < 0 || dim_zm + dim_zl > GRU_MAXIN || dim_zc < 0) return MCG_ERR_UNSUPPORTED;
+    if (dim_zm <= 0 || dim_zm > GRUW_U || dim_zl < 0 || dim_zm + dim_zl > GRUW_IN || dim_zc < 0) return MCG_ERR_UNSUPPORTED;
     if (dim_zl && !labels) return MCG_ERR_BAD_ARG;
-    if (dim_zm + dim_zl <= 16)
+    if (dim_zm > GRU_U || dim_zm + dim_zl > GRU_MAXIN)             // wide states: the weights stay in memory
+        hipLaunchKernelGGL(gru_fwd_wide_kernel, dim3((N + GRUW_S - 1) / GRUW_S), dim3(GRUW_S * GRUW_U), 0, (hipStream_t)stream, N, T, dim_zm, dim_zl,
+                           dim_zc, params, h0, e, labels, zc, z, saved);
+    else if (dim_zm + dim_zl <= 16)
         hipLaunchKernelGGL(gru_fwd_kernel<16>, dim3((N + GRU_S - 1) / GRU_S), dim3(GRU_S * GRU_U), 0, (hipStream_t)stream, N, T, dim_zm, dim_zl, dim_zc,
                            params, h0, e, labels, zc, z, saved);
     else
@@ -1290,9 +1413,17 @@ extern "C" int mcg_gru_seq_fwd(int N, int T, int dim_zm, int dim_zl, int dim_zc,
 extern "C" int mcg_gru_seq_bwd(int N, int T, int dim_zm, int dim_zl, int dim_zc, const float* params, const float* e, const int32_t* labels,
                                const float* saved, const float* gz, float* dparams, void* stream) {
     if (!params || !e || !saved || !gz || !dparams || N <= 0 || T <= 0) return MCG_ERR_BAD_ARG;
-    if (dim_zm <= 0 || dim_zm > GRU_U || dim_zl < 0 || dim_zm + dim_zl > GRU_MAXIN || dim_zc < 0) return MCG_ERR_UNSUPPORTED;
+    if (dim_zm <= 0 || dim_zm > GRUW_U || dim_zl < 0 || dim_zm + dim_zl > GRUW_IN || dim_zc < 0) return MCG_ERR_UNSUPPORTED;
     if (dim_zl && !labels) return MCG_ERR_BAD_ARG;
-    if (dim_zm + dim_zl <= 16)
+    if (dim_zm > GRU_U || dim_zm + dim_zl > GRU_MAXIN) {
+        const size_t lds = (size_t)gru_offsets(dim_zm, dim_zl).total * sizeof(float);       // <= 6 * (64 * 128 + 64) floats: 148 KB with the 8 KB of static vectors
+        static std::once_flag once;
+        static hipError_t attr = hipSuccess;
+        std::call_once(once, [&] { attr = hipFuncSetAttribute((const void*)gru_bwd_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
+        if (attr != hipSuccess) return MCG_ERR_LAUNCH;
+        hipLaunchKernelGGL(gru_bwd_wide_kernel, dim3((N + GRUW_S - 1) / GRUW_S), dim3(GRUW_S * GRUW_U), lds, (hipStream_t)stream, N, T, dim_zm, dim_zl,
+                           dim_zc, params, e, labels, saved, gz, dparams);
+    } else if (dim_zm + dim_zl <= 16)
         hipLaunchKernelGGL(gru_bwd_kernel<16>, dim3((N + GRU_S - 1) / GRU_S), dim3(GRU_S * GRU_U), 0, (hipStream_t)stream, N, T, dim_zm, dim_zl, dim_zc,
                            params, e, labels, saved, gz, dparams);
     else

@@ -338,13 +338,15 @@ def test_pack_unpack_and_tanh_bwd_to_frames(hl):
     assert rel_l2(gf, ref) < 1e-6
 
 
-@pytest.mark.parametrize("N,dim_zl", [(5, 0), (37, 6)])
-def test_gru_sequence(hl, N, dim_zl):
+@pytest.mark.parametrize("N,dim_zl,dz", [(5, 0, 10), (37, 6, 10), (7, 0, 24), (9, 6, 40), (3, 64, 64)])
+def test_gru_sequence(hl, N, dim_zl, dz):
+    """mcg_gru_seq_fwd / _bwd against the oracle's StatelessGRU steps: the register-resident kernels (dim_zm <= 16, the reference's
+    default 10 with and without labels) and the wide-state pair (weights in memory: --dim_zm up to 64, model/net.py:38-41)."""
     rng = np.random.RandomState(N)
-    T, dz, dc = 16, 10, 50
-    p = onet.init_generator(rng, dim_zl=dim_zl, n_filters=2, dtype=np.float64)
+    T, dc = 16, 50
+    p = onet.init_generator(rng, dim_zl=dim_zl, dim_zm=dz, n_filters=2, dtype=np.float64)
     gp = {k: (v + 0.1 * rng.randn(*v.shape)) for k, v in p.items() if k.startswith('g0/')}
-    draw = onet.gen_draw(rng, N, dim_zl=dim_zl, dtype=np.float64)
+    draw = onet.gen_draw(rng, N, dim_zl=dim_zl, dim_zm=dz, dtype=np.float64)
     # oracle: run the recurrence alone
     gpo = {k[3:]: v for k, v in gp.items()}
     zl = np.eye(dim_zl)[draw['labels']] if dim_zl else None

@@ -134,19 +134,19 @@ def test_discriminator_forward_backward(pkg, ndim, out, nf):
         assert rel_l2(st['bn%d/avg_var' % l], p_run['bn%d/avg_var' % l]) < 1e-5
 
 
-@pytest.mark.parametrize("dim_zl,nf", [(0, 8), (6, 16)])
-def test_generator_forward_backward(pkg, dim_zl, nf):
+@pytest.mark.parametrize("dim_zl,nf,dim_zm", [(0, 8, 10), (6, 16, 10), (6, 8, 40)])        # (40: the wide-state GRU kernels, --dim_zm > 16)
+def test_generator_forward_backward(pkg, dim_zl, nf, dim_zm):
     hl, lay, nets, _ = pkg
     rng = np.random.RandomState(200 + dim_zl)
     n = 3
-    p = _perturb(_f64(onet.init_generator(rng, dim_zl=dim_zl, n_filters=nf)), rng)
-    draw = onet.gen_draw(rng, n, dim_zl=dim_zl, dtype=F64)
+    p = _perturb(_f64(onet.init_generator(rng, dim_zl=dim_zl, dim_zm=dim_zm, n_filters=nf)), rng)
+    draw = onet.gen_draw(rng, n, dim_zl=dim_zl, dim_zm=dim_zm, dtype=F64)
     x_ref, _, cache = onet.gen_forward(copy.deepcopy(p), draw)
     gx = rng.randn(*x_ref.shape)
     grads = oupd.zero_grads(p)
     onet.gen_backward(p, cache, gx, grads)
 
-    g = nets.GenNet(dim_zl=dim_zl, n_filters=nf)
+    g = nets.GenNet(dim_zl=dim_zl, dim_zm=dim_zm, n_filters=nf)
     g.load_reference_params(p)
     xd, saved = g.forward(n, draw_to_dev(draw))                    # [n][T][64][64][4]
     x_clip_ref = x_ref.transpose(1, 2, 0, 3, 4)                     # (N,C,T,H,W)

@@ -35,10 +35,10 @@ def parse_args(argv=None):
         (('--log_tensorboard_interval',), int, 10, 'epochs between TensorBoard sample videos'),
         (('--num_gen_samples',), int, 36, 'videos per TensorBoard sample grid (a square number)'),
         (('--dim_zc',), int, 50, 'size of the content code z_c'),
-        (('--dim_zm',), int, 10, 'size of the motion code z_m (GRU state).  The fused GRU kernels (mcg_gru_seq_fwd / _bwd: 16 steps in '
-                                 'one launch, weights in registers, one thread per hidden unit) cover dim_zm <= 16 and '
-                                 'dim_zm + num_labels <= 32; larger values are refused with MCG_ERR_UNSUPPORTED (the reference, '
-                                 'model/net.py:38-41, accepts any; its default and every BASELINE config use 10)'),
+        (('--dim_zm',), int, 10, 'size of the motion code z_m (GRU state).  dim_zm <= 16 and dim_zm + num_labels <= 32 (the '
+                                 'reference\'s default 10, every BASELINE config) run the fused register-resident GRU kernels; up to '
+                                 'dim_zm = 64 / dim_zm + num_labels = 128 a slower kernel pair with the weights in memory; beyond that '
+                                 'MCG_ERR_UNSUPPORTED (the reference, model/net.py:38-41, accepts any)'),
         (('--n_filters_gen',), int, 64, 'base width; as in the reference it is used for all three networks'),
         (('--n_filters_idis',), int, 64, 'accepted and reported, not used (reference quirk)'),
         (('--n_filters_vdis',), int, 64, 'accepted and reported, not used (reference quirk)'),
