@@ -157,3 +157,36 @@ class SyntheticDataset:
         return video, (int(rng.randint(0, self.num_labels)) if self.num_labels else None)
 
     get_example = __getitem__
+
+
+class ShardedDataset:
+    """Data parallel: rank r of `world` sees items r, r + world, r + 2 world, ... of `dataset` (ChainerMN's scatter_dataset without
+    the shuffle) -- the ranks' iterators together make ONE pass over the data per epoch.  No reference counterpart (the reference
+    is single-device, train.py:87-91).  Forwards the raw-frame accessor the prefetching loader uses when the dataset has one."""
+
+    def __init__(self, dataset, rank, world):
+        if not 0 <= rank < world:
+            raise ValueError('rank %d outside world %d' % (rank, world))
+        self.dataset, self.rank, self.world = dataset, rank, world
+
+    def __getattr__(self, name):                     # (only reached for names the instance does not have)
+        if name == 'get_example_raw' and 'dataset' in self.__dict__ and hasattr(self.dataset, 'get_example_raw'):
+            return self._raw
+        raise AttributeError(name)
+
+    def _raw(self, i):
+        return self.dataset.get_example_raw(self.rank + int(i) * self.world)
+
+    def __len__(self):
+        return (len(self.dataset) - self.rank + self.world - 1) // self.world
+
+    def __getitem__(self, i):
+        if not 0 <= int(i) < len(self):
+            raise IndexError(i)
+        return self.dataset[self.rank + int(i) * self.world]
+
+    def get_example(self, i, *a, **kw):
+        get = getattr(self.dataset, 'get_example', None)
+        j = self.rank + int(i) * self.world
+        return get(j, *a, **kw) if get is not None else self.dataset[j]
+

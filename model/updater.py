@@ -126,9 +126,20 @@ class Updater:
             x_real, labels = it.next_device_batch(self._step.device)                 # pinned memory, normalised on the GPU
         else:
             batch = it.next()
-            videos = np.stack([b[0] for b in batch]).astype(np.float32)              # concat_examples
             labels = [b[1] for b in batch]
-            x_real = torch.as_tensor(videos).to(self._step.device, non_blocking=True)
+            # concat_examples straight into a reused PINNED staging buffer: one host copy, and the H2D copy is asynchronous
+            shape = (len(batch),) + tuple(np.shape(batch[0][0]))
+            pin = getattr(self, '_pin', None)
+            if pin is None or tuple(pin.shape) != shape:
+                pin = self._pin = torch.empty(shape, dtype=torch.float32, pin_memory=torch.cuda.is_available())
+            evt = getattr(self, '_pin_evt', None)
+            if evt is not None:
+                evt.synchronize()                                                    # the previous batch has left the buffer
+            np.stack([b[0] for b in batch], out=pin.numpy(), casting='unsafe')
+            x_real = pin.to(self._step.device, non_blocking=True)
+            if x_real.is_cuda:
+                self._pin_evt = torch.cuda.Event()
+                self._pin_evt.record()
         t_real = None if labels[0] is None else torch.as_tensor(np.asarray(labels, dtype=np.int32)).to(self._step.device)
         self._step.run(x_real, t_real)
         if self.is_new_epoch:

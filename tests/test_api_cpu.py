@@ -185,6 +185,37 @@ def test_shipped_tile_table_is_well_formed():
         seen.add(tuple(key))
 
 
+class _RawSynthetic(__import__('datasets').SyntheticDataset):        # (module level: the shard is pickled with its dataset)
+    def get_example_raw(self, i):
+        return ('raw', i)
+
+
+def test_sharded_dataset_partitions_the_data():
+    """datasets.ShardedDataset (train.py --dp_shard, data parallel): the ranks' shards are disjoint, cover the dataset, differ in
+    length by at most one, survive pickling (the prefetching loader ships the dataset to its workers) and forward the raw accessor."""
+    import pickle
+    from datasets import ShardedDataset, SyntheticDataset
+    ds = SyntheticDataset(11, num_labels=6, video_length=2, img_size=8)
+    shards = [ShardedDataset(ds, r, 3) for r in range(3)]
+    assert sorted(len(s_) for s_ in shards) == [3, 4, 4]
+    seen = []
+    for r, sh in enumerate(shards):
+        for i in range(len(sh)):
+            v, lab = sh[i]
+            j = r + 3 * i
+            assert np.array_equal(v, ds[j][0]) and lab == ds[j][1] and np.array_equal(sh.get_example(i)[0], v)
+            seen.append(j)
+        with pytest.raises(IndexError):
+            sh[len(sh)]
+    assert sorted(seen) == list(range(11))
+    assert not hasattr(shards[0], 'get_example_raw')              # (the synthetic dataset has no raw frames)
+
+    sh = pickle.loads(pickle.dumps(ShardedDataset(_RawSynthetic(11, video_length=2, img_size=8), 2, 3)))
+    assert hasattr(sh, 'get_example_raw') and sh.get_example_raw(1) == ('raw', 5) and len(sh) == 3
+    with pytest.raises(ValueError):
+        ShardedDataset(ds, 3, 3)
+
+
 def test_split_form_predicates(monkeypatch):
     """hiplib.split_covers / split_decided (host logic of the 'f32x3' networks): which launches have a MCG_PREC_SPLIT form, and when
     a producer may rely on it (MCG_SPLIT=always / never, else the table entry 'split-<pass>' == 1)."""

@@ -59,6 +59,9 @@ def parse_args(argv=None):
                    help="operand type of the convolution GEMMs (accumulation, parameters, Adam: always fp32); f32x3: fp32 products "
                         "of the wide layers on the bf16 matrix pipe (operands as three bf16 terms, six bf16 products each)")
     p.add_argument('--overlap', type=int, default=1, help="side HIP streams for independent kernels")
+    p.add_argument('--dp_shard', type=int, default=1,
+                   help="data parallel: 1 (default) = rank r trains on items r, r + world, ... (an epoch of all ranks is one pass over "
+                        "the data); 0 = every rank walks the whole dataset in its own order (an epoch is world passes)")
     p.add_argument('--autotune', type=int, default=1, help="time the GEMM tile candidates once per layer geometry")
     p.add_argument('--sync_bn', type=int, default=0,
                    help="data parallel only: 1 = BatchNorm statistics over the global batch (all-reduced sums) instead of per rank")
@@ -103,7 +106,8 @@ def main(argv=None):
     elif args.dataset_type == "mnist":
         num_labels, train_dataset = 0, MovingMnistDataset(args.dataset, video_length, channels=channel)
     else:
-        num_labels, train_dataset = 6, SyntheticDataset(args.synthetic_size, 6, channel, video_length, size, seed=rank)
+        num_labels, train_dataset = 6, SyntheticDataset(args.synthetic_size, 6, channel, video_length, size,
+                                                        seed=0 if (world > 1 and args.dp_shard) else rank)   # (shards partition ONE dataset)
 
     if args.model == "normal":
         use_label, c_d, out_d = False, channel, 1
@@ -124,6 +128,9 @@ def main(argv=None):
     image_gen = ImageGenerator(args.dim_zc, args.dim_zm, num_labels, channel, nf, video_length)
     image_dis = ImageDiscriminator(c_d, out_d, nf, use_noise, noise_sigma)
     video_dis = VideoDiscriminator(c_d, out_d, nf, use_noise, noise_sigma)
+    if world > 1 and args.dp_shard:
+        from datasets import ShardedDataset
+        train_dataset = ShardedDataset(train_dataset, rank, world)     # the ranks together make one pass over the data per epoch
     np.random.seed(args.seed + 1 + rank)                         # data order / sub-sequence offsets differ per rank
     if args.loader_workers > 0:
         train_iter = T.PrefetchIterator(train_dataset, args.batchsize, n_workers=args.loader_workers, seed=args.seed + rank)
@@ -167,9 +174,9 @@ def main(argv=None):
         # Data parallel (no reference counterpart).  Replicas are identical by construction (same seed) and stay so
         # because every rank applies the same averaged gradient; rank 0's parameters, Adam moments and running
         # statistics are still broadcast once, after construction / resume, so that nothing depends on that.
-        # Epoch semantics: every rank walks the WHOLE dataset in its own order with its own batchsize, i.e. one
-        # "epoch" is world-size passes over the data and --max_epoch counts those; BatchNorm running statistics
-        # are per rank and rank 0's are the ones saved.
+        # Epoch semantics: with --dp_shard 1 (default) rank r walks items r, r + world, ... in its own order, so one epoch of all
+        # ranks is ONE pass over the data; with --dp_shard 0 every rank walks the WHOLE dataset (an "epoch" is world-size passes).
+        # BatchNorm running statistics are per rank and rank 0's are the ones saved.
         import torch
         for link in (image_gen, image_dis, video_dis):
             net = link.impl
