@@ -1733,8 +1733,13 @@ __global__ __launch_bounds__(NT2) void dgrad_patch_kernel(DgPatchPol p) {
         const int py = (pr * 57) >> 10, px = pr - py * PW;                  // pr / 18 for pr < 324
         const int h = py - 1, w_ = px - 1;
         const bool ok = pr < NPIX && (unsigned)h < (unsigned)g.Ho && (unsigned)w_ < (unsigned)g.Wo;
-        poff[j] = ok ? (u32)(((h * g.Wo + w_) * g.Co + ((cp ^ ((pr >> 1) & 7)) << 3)) * 2) : OOB;
-        if (SPLIT && ((cp ^ ((pr >> 1) & 7)) >> 1) == 3) poff[j] = OOB;      // the zero plane: not fetched, never multiplied
+        // LDS image of the patch: chunk c of pixel (py, px) at position c ^ ((px >> 1) & 7).  The key is the pixel's COLUMN, not its
+        // index: a ds_read_b128 lane group takes 8 pixels of one patch row and 8 of the next (columns x..x+3, x+12..x+15 | x+4..x+11);
+        // with the index-based key of the GEMM tiles ((pr >> 1) & 7, 18 pixels per row) those two sets of keys overlap -- a 2-way bank
+        // conflict on every A fragment (PMC: SQ_LDS_BANK_CONFLICT 32 % of the LDS cycles), with the column-based key they are disjoint
+        const int kx = (px >> 1) & 7;
+        poff[j] = ok ? (u32)(((h * g.Wo + w_) * g.Co + ((cp ^ kx) << 3)) * 2) : OOB;
+        if (SPLIT && ((cp ^ kx) >> 1) == 3) poff[j] = OOB;                   // the zero plane: not fetched, never multiplied
     }
     auto issue_patch = [&](int s, int j0, int j1) {
         const int a = a_lo + s / CC, cc = s - (s / CC) * CC;
@@ -1777,6 +1782,7 @@ __global__ __launch_bounds__(NT2) void dgrad_patch_kernel(DgPatchPol p) {
     int prow[2];                                                  // this lane's two rows of the frame as patch pixels (shift 0)
 #pragma unroll
     for (int i = 0; i < 2; ++i) { const int r_ = wr_ * 64 + i * 32 + li; prow[i] = ((r_ >> 4) + 1) * PW + (r_ & 15) + 1; }
+    const int pcol = (li & 15) + 1;                               // ... and their patch column (the same for both: rows 32 apart)
     const int tq = (lane & 15) >> 2, tcl = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);
     u32 tb[2];
 #pragma unroll
@@ -1806,7 +1812,7 @@ __global__ __launch_bounds__(NT2) void dgrad_patch_kernel(DgPatchPol p) {
             const int shift = (cg - bh) * PW + (pw - bw);         // ph = cg
             const int pr0 = p0 + shift, pr1 = p1 + shift;
             const unsigned char* ap0 = pb + pr0 * 128; const unsigned char* ap1 = pb + pr1 * 128;
-            const int sw0 = (pr0 >> 1) & 7, sw1 = (pr1 >> 1) & 7;
+            const int sw0 = ((pcol + (pw - bw)) >> 1) & 7, sw1 = sw0;        // (column-based key: see the patch loads)
             // (the filter fragments through the asm form of the transposing read: see tr16_issue; two k chunks in flight)
             const u32 bb32 = lds_addr(bb);
             if constexpr (SPLIT) {

@@ -29,6 +29,9 @@ def short(name):
             if m5.group(3) == '1':
                 kind = 'v2.f32x3'
         return '%s %s %sx%sx%s%s' % (kind, m.group(2), m.group(3), m.group(4), m.group(5), (' e' + epi.group(2)) if epi and epi.group(2) != '0' else '')
+    m = re.search(r'dgrad_patch_kernel<(\d), (\d)>', name)
+    if m:
+        return 'patch dgrad%s%s' % (' f32x3' if m.group(2) == '1' else '', (' e' + m.group(1)) if m.group(1) != '0' else '')
     m = re.search(r'(\w+_c4\w*_kernel)', name)
     return m.group(1) if m else None
 
