@@ -24,6 +24,9 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2516.8         # MI355X_MICROARCH.md: bf16 MFMA, dense (16x the f32 MFMA rate)
+PEAK_F32X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0   # 'f32x3': six bf16 products per fp32 product -> 419.5 algorithmic TFLOP/s
+LINE_LIMIT = 4096                      # bytes of the one stdout line (the driver parses it; round 3's 51 KB line was not parsed)
+DETAIL_FILE = 'bench_detail.json'      # everything else: per-layer tables, tile choices, full secondary records
 
 
 def dv_conv_flops_per_clip():
@@ -124,7 +127,7 @@ def cpu_baseline(batch, warmup, steps):
         threads = os.cpu_count()
     med3, t3 = _cpu_time_shape(3, 6, batch, warmup, steps)
     med1, t1 = _cpu_time_shape(1, 0, batch, warmup, steps)
-    return {"value": batch / med3, "unit": "clips/s", "cores": int(threads), "kind": "port",
+    return {"value": batch / med3, "unit": "clips/s", "cores": int(threads), "kind": "port", "batch": batch, "timed_iterations": steps,
             "blas_threads": int(threads), "host_cpus": os.cpu_count(),
             "c1_moving_mnist_shape": {"value": batch / med1, "unit": "clips/s", "shape": "16x1x64x64", "batch": batch,
                                       "median_s_per_iteration": med1},
@@ -194,6 +197,59 @@ def dry_run(args, world, rank):
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True,
                           "max_over_ranks_check": float(t)}))
     return 0
+
+
+def _round(v, nd=4):
+    return round(v, nd) if isinstance(v, float) else v
+
+
+def compact_line(out, secondary, cpu, detail_path):
+    """The ONE stdout line: the contract fields, `config`, `roofline`, `cpu_baseline` and one short record per secondary workload --
+    at most LINE_LIMIT bytes.  Per-layer tables, tile choices and the full secondary records live in DETAIL_FILE."""
+    rl = out.get("roofline") or {}
+    line = {k: _round(out[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                        "scaling", "vs_baseline", "dtype", "data") if k in out}
+    cfg = out.get("config") or {}
+    line["config"] = {k: cfg[k] for k in ("workload", "variant", "per_gpu_batch", "global_batch", "parallelism", "side_streams", "sync_bn")
+                      if k in cfg}
+    line["roofline"] = {k: _round(rl[k]) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "kernel_ms_per_step", "traffic",
+                                                   "algorithmic_bytes", "traffic_source", "algorithmic_gflop_per_step") if k in rl}
+    if "by_pass" in rl:
+        line["roofline"]["tflops_by_pass"] = {k: _round(v["tflops"], 1) for k, v in rl["by_pass"].items()}
+    if cpu is not None:
+        line["cpu_baseline"] = {"value": _round(cpu["value"]), "unit": cpu["unit"], "cores": cpu["cores"], "kind": cpu["kind"],
+                                "sample": "oracle/ (NumPy im2col+BLAS fp32 restatement of the Chainer-CPU algorithm, not Chainer), "
+                                          "update_core at batch %d, full width, median of %d timed iterations"
+                                          % (cpu.get("batch", 0), cpu.get("timed_iterations", 0))}
+    sec = []
+    for s_ in secondary:
+        if s_ is None:
+            continue
+        r = {"workload": (s_.get("config") or {}).get("workload", "")[-40:], "dtype": s_.get("dtype")}
+        c = s_.get("config") or {}
+        if "per_gpu_batch" in c:
+            r["workload"] = "%s batch %d/GPU %s" % (c.get("variant"), c["per_gpu_batch"], c["workload"][c["workload"].rfind("(BASELINE"):])
+        if "error" in s_:
+            r["error"] = s_["error"][:160]
+        else:
+            r.update(value=_round(s_["value"], 1), ms_per_step=_round(s_["ms_per_step"], 3), frac=_round(s_["roofline"]["frac"]),
+                     peak=_round(s_["roofline"]["peak"], 1))
+        sec.append(r)
+    if sec:
+        line["secondary"] = sec
+    if "dist" in out:
+        line["dist"] = {k: out["dist"][k] for k in ("backend", "world_size")}
+    line["losses"] = {k: _round(v) for k, v in (out.get("losses") or {}).items()}
+    line["detail"] = os.path.basename(detail_path) if detail_path else None
+    text = json.dumps(line)
+    if len(text) > LINE_LIMIT:                       # never exceed the bound: drop the optional parts, longest first
+        for k in ("secondary", "losses", "dist"):
+            line.pop(k, None)
+            text = json.dumps(line)
+            if len(text) <= LINE_LIMIT:
+                break
+    assert len(text) <= LINE_LIMIT, len(text)
+    return text
 
 
 def main():
@@ -295,12 +351,15 @@ def main():
             ts.run(x_real, t_real)
         barrier()
         hl.timing_begin()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            ts.run(x_real, t_real)
-        barrier()
-        dt_serial_instr = time.perf_counter() - t0
-        timing = hl.timing_end()
+        timing = None
+        try:
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                ts.run(x_real, t_real)
+            barrier()
+            dt_serial_instr = time.perf_counter() - t0
+        finally:
+            timing = hl.timing_end()                   # (an exception must not leave the event records armed for the next workload)
         # Pass 2 (headline): un-instrumented, EXACTLY `steps` iterations between barrier + synchronize, with the
         # side-stream placement unless --overlap 0.  Same kernels, same arithmetic, same results.
         ts.set_overlap(bool(overlap))
@@ -349,7 +408,8 @@ def main():
             by_layer[k] = {"launches_per_step": n_l / steps, "ms_per_launch": ms / n_l,
                            "tflops": gflop * n_l / ms if ms > 0 else 0.0}
         traffic, traffic_src = pmc_traffic(B, dtype)
-        peak = PEAK_BF16_MFMA_TFLOPS if dtype == 'bf16' else PEAK_FP32_MFMA_TFLOPS
+        # f32x3 executes six bf16 MFMA products per algorithmic fp32 product: its roof in ALGORITHMIC TFLOP/s is the dense bf16 peak / 6
+        peak = PEAK_BF16_MFMA_TFLOPS if dtype == 'bf16' else PEAK_F32X3_TFLOPS if dtype == 'f32x3' else PEAK_FP32_MFMA_TFLOPS
         cfg_name = "configs[2]" if (dtype == 'bf16' and B == 256 and model == 'normal') else \
             "configs[1]" if (dtype == 'f32' and B == 32 and model == 'normal') else \
             "configs[1], fp32 products on the bf16 pipe" if (dtype == 'f32x3' and B == 32 and model == 'normal') else \
@@ -377,9 +437,8 @@ def main():
                          "algorithmic_gflop_per_step": tot / 1e9, "kernel_ms_per_step": dv_total_ms, "by_pass": kern,
                          **({"operand_split_ms_per_step": dv_split_ms,
                              "note": "fp32 products on the bf16 matrix pipe: operands as three bf16 terms, six bf16 MFMA products per "
-                                     "fp32 product (DESIGN.md); `peak` stays the fp32 MFMA peak for comparison with the f32 line -- "
-                                     "against the bf16 pipe the split launches execute 6x the algorithmic FLOPs",
-                             "frac_of_bf16_mfma_peak_executed": 6.0 * achieved / PEAK_BF16_MFMA_TFLOPS} if dtype == 'f32x3' else {}),
+                                     "fp32 product (DESIGN.md); `peak` = dense bf16 MFMA peak / 6 in algorithmic TFLOP/s",
+                             "x_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS} if dtype == 'f32x3' else {}),
                          "all_conv_kernels_ms_per_step": all_conv_ms,
                          "by_network_and_pass_ms_per_step": {k: v[1] / steps for k, v in sorted(timing.items()) if ' N=' not in k},
                          "by_layer": by_layer,
@@ -398,6 +457,31 @@ def main():
     def default_overlap(dtype, B):
         return int(os.environ.get('MCG_OVERLAP', '0' if (dtype == 'bf16' and B >= 128) else '1'))
 
+    def all_ranks_ok(ok):
+        """MIN over the ranks of a local success flag (one small all-reduce every rank reaches)"""
+        if world == 1:
+            return ok
+        f = torch.tensor([1.0 if ok else 0.0], device='cuda')
+        dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        return bool(f.item() > 0.5)
+
+    def preflight(model, dtype, B):
+        """N > 1 only: ONE local iteration of the workload (no collective inside) on throw-away networks.  A rank that cannot run
+        it (out of memory, a geometry the library refuses) says so HERE, where every rank still reaches the flag's all-reduce --
+        inside measure() the other ranks would be left waiting in RCCL."""
+        ok = True
+        try:
+            gen, di, dv = mstep.make_models(model, num_labels=6, seed=0)
+            ts = mstep.TrainStep(model, gen, di, dv, seed=0, rank=rank, precision=dtype)
+            ts.run(torch.zeros((B, 3, 16, 64, 64), device='cuda'), torch.zeros(B, dtype=torch.int32, device='cuda'))
+            torch.cuda.synchronize()
+            del ts, gen, di, dv
+        except Exception as exc:                                   # noqa: BLE001
+            sys.stderr.write('bench.py rank %d: preflight of %s %s batch %d failed: %r\n' % (rank, model, dtype, B, exc))
+            ok = False
+        torch.cuda.empty_cache()
+        return all_ranks_ok(ok)
+
     out = measure(args.model, args.dtype, args.batch, args.steps, args.warmup, args.overlap)
     # The other single-GPU workloads BASELINE.json names ride on the same line (a few steps each): configs[2] (bf16
     # networks, batch 256) and configs[3] (--model infogan, batch 32); on 8 GPUs configs[4] (global batch 1024).
@@ -405,13 +489,21 @@ def main():
     secondary = []
 
     def also(model, dtype, B):
-        """a secondary workload must never cost the headline its line: a failure (the same on every rank: same code, same shapes)
-        is recorded in its place"""
+        """a secondary workload must never cost the headline its line.  One GPU: a failure is recorded in its place.  N > 1: the
+        workload only starts when every rank has run it once locally (preflight); after that an exception is a real bug and is
+        raised -- swallowing it on one rank would leave the others in a collective."""
+        if world > 1:
+            if not preflight(model, dtype, B):
+                if rank == 0:
+                    secondary.append({"config": {"workload": "%s %s batch %d" % (model, dtype, B)}, "dtype": dtype,
+                                      "error": "preflight failed on at least one rank (see stderr)"})
+                return
+            secondary.append(measure(model, dtype, B, args.secondary_steps, 3, default_overlap(dtype, B)))
+            return
         try:
             secondary.append(measure(model, dtype, B, args.secondary_steps, 3, default_overlap(dtype, B)))
         except Exception as exc:                                   # noqa: BLE001
-            if rank == 0:
-                secondary.append({"config": {"workload": "%s %s batch %d" % (model, dtype, B)}, "dtype": dtype, "error": repr(exc)[:300]})
+            secondary.append({"config": {"workload": "%s %s batch %d" % (model, dtype, B)}, "dtype": dtype, "error": repr(exc)[:300]})
     if args.secondary and headline_cfg:
         if world == 1:
             also('normal', 'bf16', 256)
@@ -424,13 +516,20 @@ def main():
     if rank == 0 and args.save_tiles:
         hl.save_tile_choices(args.save_tiles)
     if rank == 0:
-        keep = ("config", "dtype", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "roofline", "dist", "losses")
-        out["secondary"] = [{k: s_[k] for k in keep if k in s_} | ({"error": s_["error"]} if "error" in s_ else {}) for s_ in secondary]
-        out["tile_choices"] = {"%s N=%d T=%d H=%d Ci=%d Co=%d p=%d" % (k[0], k[1], k[2], k[3], k[5], k[6], k[9]): v
-                               for k, v in sorted(hl.tile_choices().items(), key=str)}
+        cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_batch, args.cpu_sample_warmup, args.cpu_sample_steps)
-        print(json.dumps(out))
+            cpu = cpu_baseline(args.cpu_sample_batch, args.cpu_sample_warmup, args.cpu_sample_steps)
+        tiles = {"%s N=%d T=%d H=%d Ci=%d Co=%d p=%d" % (k[0], k[1], k[2], k[3], k[5], k[6], k[9]): v
+                 for k, v in sorted(hl.tile_choices().items(), key=str)}
+        detail = dict(out, secondary=[s_ for s_ in secondary if s_ is not None], tile_choices=tiles, cpu_baseline=cpu)
+        detail_path = os.environ.get('MCG_BENCH_DETAIL', os.path.join(ROOT, DETAIL_FILE))
+        try:
+            with open(detail_path, 'w') as f:
+                json.dump(detail, f, indent=1)
+        except OSError as exc:
+            sys.stderr.write('bench.py: could not write %s: %r\n' % (detail_path, exc))
+            detail_path = None
+        print(compact_line(out, secondary, cpu, detail_path))
     if world > 1:
         dist.destroy_process_group()
 

@@ -161,12 +161,18 @@ class SyntheticDataset:
 
 class ShardedDataset:
     """Data parallel: rank r of `world` sees items r, r + world, r + 2 world, ... of `dataset` (ChainerMN's scatter_dataset without
-    the shuffle) -- the ranks' iterators together make ONE pass over the data per epoch.  No reference counterpart (the reference
-    is single-device, train.py:87-91).  Forwards the raw-frame accessor the prefetching loader uses when the dataset has one."""
+    the shuffle) -- the ranks' iterators together make ONE pass over the data per epoch.  EVERY shard has the same length
+    ceil(N / world) (scatter_dataset's force_equal_length=True): when world does not divide N the last index of the short shards
+    wraps around to the front of the dataset, (rank + i * world) % N.  Equal lengths are what keeps the ranks in step -- each rank
+    stops on its own iterator's epoch count, and a rank that ran out of batches first would leave the others waiting in the
+    gradient all-reduce forever.  No reference counterpart (the reference is single-device, train.py:87-91).  Forwards the
+    raw-frame accessor the prefetching loader uses when the dataset has one."""
 
     def __init__(self, dataset, rank, world):
         if not 0 <= rank < world:
             raise ValueError('rank %d outside world %d' % (rank, world))
+        if len(dataset) == 0:
+            raise ValueError('cannot shard an empty dataset')
         self.dataset, self.rank, self.world = dataset, rank, world
 
     def __getattr__(self, name):                     # (only reached for names the instance does not have)
@@ -174,19 +180,22 @@ class ShardedDataset:
             return self._raw
         raise AttributeError(name)
 
+    def _index(self, i):
+        i = int(i)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        return (self.rank + i * self.world) % len(self.dataset)
+
     def _raw(self, i):
-        return self.dataset.get_example_raw(self.rank + int(i) * self.world)
+        return self.dataset.get_example_raw(self._index(i))
 
     def __len__(self):
-        return (len(self.dataset) - self.rank + self.world - 1) // self.world
+        return (len(self.dataset) + self.world - 1) // self.world
 
     def __getitem__(self, i):
-        if not 0 <= int(i) < len(self):
-            raise IndexError(i)
-        return self.dataset[self.rank + int(i) * self.world]
+        return self.dataset[self._index(i)]
 
     def get_example(self, i, *a, **kw):
         get = getattr(self.dataset, 'get_example', None)
-        j = self.rank + int(i) * self.world
+        j = self._index(i)
         return get(j, *a, **kw) if get is not None else self.dataset[j]
-

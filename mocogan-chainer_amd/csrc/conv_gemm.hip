@@ -937,10 +937,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(P p) {
 #endif
         MCG_T(ts1);
         const int kn = p.next_valid(k0 + BK);
-        // prefetch the next live step; past the end the offsets are forced out of range (loads return 0,
-        // nothing is consumed), which keeps the loop body free of divergent branches
+        // prefetch the next live step; past the end the CURRENT step is loaded again (nothing is consumed), which keeps the
+        // loop body free of divergent branches and every generated address one the policy produces for a live step
+        // (round 3 loaded step kend - BK there, which is a negative pixel range for a weight gradient with fewer than BK pixels)
 #ifndef MCG_PROBE_NOLOADS
-        { const int kl = kn < kend ? kn : kend - BK; p.load_a(kl, ra); p.load_b(kl, rb); }
+        { const int kl = kn < kend ? kn : k0; p.load_a(kl, ra); p.load_b(kl, rb); }
 #endif
         MCG_T(ts2);
 #ifdef MCG_SETPRIO          // (experiment: the wave's MFMA phase at raised issue priority)
@@ -1156,7 +1157,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(P p) {
         }
         __syncthreads();
         const int kn = p.next_valid(k0 + BK);
-        { const int kl = kn < kend ? kn : kend - BK; p.load_a(kl, ra); p.load_b(kl, rb); }
+        { const int kl = kn < kend ? kn : k0; p.load_a(kl, ra); p.load_b(kl, rb); }      // (past the end: the current step again, unused)
 #pragma unroll
         for (int kc = 0; kc < BK / 16; ++kc) {
             bf16x8 fa[TM], fb[TN];

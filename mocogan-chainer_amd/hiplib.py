@@ -271,6 +271,16 @@ def set_autotune(on, use_pretuned=True):
             _tile_cache.setdefault(tuple(k), int(v))
 
 
+def reset_tuning():
+    """Back to the state of a fresh import: tuner off, no cached tile choices, no tile override.  (tests/conftest.py calls this
+    before every test module so that no module inherits a timing-dependent tile table from an earlier one; train.main() and
+    bench.py switch the tuner on for their own process.)"""
+    global _autotune, _tile_override
+    _autotune = False
+    _tile_override = 0
+    _tile_cache.clear()
+
+
 def tile_choices():
     """{(pass, geometry...): tile code} chosen so far (for logs / DESIGN.md tables)."""
     return dict(_tile_cache)

@@ -6,6 +6,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+if os.path.dirname(os.path.abspath(__file__)) not in sys.path:
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def pytest_configure(config):
@@ -15,3 +17,32 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def repo_root():
     return ROOT
+
+
+# Order of the GPU modules under `-x`: what pins the product against the oracle first (golden vectors, whole iterations, full-width
+# layers, the API surface), then the op-level oracle tests, then the guard-band runs, and the self-comparison / bit-identity tests
+# last -- a failure among the latter must not hide the oracle tests behind it (round 3's driver run: 137 tests unreached).
+_GPU_MODULE_ORDER = ["test_gpu_golden", "test_gpu_step", "test_gpu_fullwidth", "test_gpu_api", "test_gpu_cabi_host", "test_gpu_dp",
+                     "test_gpu_ops", "test_gpu_guardband", "test_gpu_properties"]
+_LAST = ("test_bf16_stored_operands_equal_rounding_in_the_kernel",)
+
+
+def pytest_collection_modifyitems(config, items):
+    def key(entry):
+        idx, item = entry
+        mod = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        if mod not in _GPU_MODULE_ORDER:
+            return (0, 0, idx)                                    # CPU modules keep their place in front
+        last = any(item.name.startswith(n) for n in _LAST)
+        return (2 if last else 1, _GPU_MODULE_ORDER.index(mod), idx)
+    items[:] = [it for _, it in sorted(enumerate(items), key=key)]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _fresh_tuning_state():
+    """No module inherits tuner state from an earlier one: train.main() (called in-process by the API tests) switches the tile
+    tuner on with the shipped table, and a timing-dependent tuner under the op tests means different kernels on different boxes."""
+    import mocogan_chainer_amd.hiplib as hiplib
+    hiplib.reset_tuning()
+    yield
+    hiplib.reset_tuning()

@@ -191,27 +191,33 @@ class _RawSynthetic(__import__('datasets').SyntheticDataset):        # (module l
 
 
 def test_sharded_dataset_partitions_the_data():
-    """datasets.ShardedDataset (train.py --dp_shard, data parallel): the ranks' shards are disjoint, cover the dataset, differ in
-    length by at most one, survive pickling (the prefetching loader ships the dataset to its workers) and forward the raw accessor."""
+    """datasets.ShardedDataset (train.py --dp_shard, data parallel): the ranks' shards cover the dataset, ALL have the same length
+    ceil(N / world) (the short shards wrap around to the front: ChainerMN scatter_dataset(force_equal_length=True)) so that every
+    rank runs the same number of iterations per epoch, survive pickling (the prefetching loader ships the dataset to its workers)
+    and forward the raw accessor."""
     import pickle
     from datasets import ShardedDataset, SyntheticDataset
     ds = SyntheticDataset(11, num_labels=6, video_length=2, img_size=8)
     shards = [ShardedDataset(ds, r, 3) for r in range(3)]
-    assert sorted(len(s_) for s_ in shards) == [3, 4, 4]
+    assert [len(s_) for s_ in shards] == [4, 4, 4]
     seen = []
     for r, sh in enumerate(shards):
         for i in range(len(sh)):
             v, lab = sh[i]
-            j = r + 3 * i
+            j = (r + 3 * i) % 11
             assert np.array_equal(v, ds[j][0]) and lab == ds[j][1] and np.array_equal(sh.get_example(i)[0], v)
             seen.append(j)
         with pytest.raises(IndexError):
             sh[len(sh)]
-    assert sorted(seen) == list(range(11))
+    assert sorted(set(seen)) == list(range(11)) and len(seen) == 12            # one item (index 0, via rank 2) is seen twice
     assert not hasattr(shards[0], 'get_example_raw')              # (the synthetic dataset has no raw frames)
+    for n, world in ((1001, 8), (8, 8), (3, 8), (16, 4)):                     # the advisor's example; exact division; fewer items than ranks
+        lens = {len(ShardedDataset(SyntheticDataset(n, video_length=1, img_size=8), r, world)) for r in range(world)}
+        assert lens == {-(-n // world)}
 
     sh = pickle.loads(pickle.dumps(ShardedDataset(_RawSynthetic(11, video_length=2, img_size=8), 2, 3)))
-    assert hasattr(sh, 'get_example_raw') and sh.get_example_raw(1) == ('raw', 5) and len(sh) == 3
+    assert hasattr(sh, 'get_example_raw') and sh.get_example_raw(1) == ('raw', 5) and len(sh) == 4
+    assert sh.get_example_raw(3) == ('raw', 0)
     with pytest.raises(ValueError):
         ShardedDataset(ds, 3, 3)
 
@@ -359,3 +365,51 @@ def test_bench_self_launches_its_ranks(tmp_path):
         r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'], capture_output=True, text=True,
                            env=env, timeout=600)
         assert r.returncode == 2 and 'GPU(s) visible' in r.stderr
+
+
+def test_bench_stdout_line_stays_small():
+    """The driver parses ONE stdout line; round 3's grew to 51 KB (tile table, per-layer tables of four workloads) and was not
+    parsed.  compact_line() keeps the contract fields + config + roofline + cpu_baseline + one short record per secondary
+    workload within bench.LINE_LIMIT bytes, whatever the size of the detailed record (which goes to bench_detail.json)."""
+    import json
+    import bench
+    by_layer = {"D_V.fprop N=%d T=16 H=64 Ci=%d Co=%d" % (n, c, 2 * c): {"launches_per_step": 2.0, "ms_per_launch": 0.123456789, "tflops": 123.456789}
+                for n in (32, 64) for c in (4, 64, 128, 256) for _ in range(1)}
+
+    def rec(dtype, wl, value):
+        return {"metric": "training clips/sec (16×3×64×64)", "value": value, "unit": "clips/s", "n_gpus": 1, "steps": 20, "warmup": 5,
+                "ms_per_step": 14.987654321, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+                "config": {"workload": "MUG-shape synthetic (B,3,16,64,64) U(-1,1), one update_core iteration per step (BASELINE.json %s)" % wl,
+                           "variant": "normal", "per_gpu_batch": 32, "global_batch": 32, "n_filters": 64, "dim_zl": 6, "parallelism": "dp1",
+                           "side_streams": True, "sync_bn": False},
+                "roofline": {"bound": "mfma", "achieved": 123.0123456, "peak": 157.3, "unit": "TFLOP/s", "frac": 0.782123456, "traffic": 7.43e9,
+                             "algorithmic_bytes": 2.47e9, "traffic_source": "profiles/r03_dv_conv_traffic.json (PMC, batch 32)",
+                             "kernel": "VideoDiscriminator Conv3d implicit-GEMM family (gemm_kernel<FpropP|DgradP|WgradP>), dc1..dc4, all launches of one step",
+                             "algorithmic_gflop_per_step": 1315.3, "kernel_ms_per_step": 10.7,
+                             "by_pass": {k: {"launches_per_step": 8.0, "ms_per_step": 3.3, "tflops": 120.123456} for k in ("fprop", "wgrad", "dgrad")},
+                             "by_layer": by_layer, "by_network_and_pass_ms_per_step": {"x" * 20 + str(i): 1.0 for i in range(40)},
+                             "measured": "m" * 400},
+                "dist": {"backend": None, "world_size": 1, "per_rank_ms_per_step": {"min": 1.0, "median": 1.0, "max": 1.0}},
+                "losses": {"image_dis/loss": 0.71234567, "video_dis/loss": 0.6923456, "image_gen/loss": 1.4123456}}
+    out = rec("f32", "configs[1]", 2142.123456)
+    secondary = [rec("bf16", "configs[2]", 11000.5), rec("f32", "configs[3]", 2100.25), rec("f32x3", "configs[1], fp32 products on the bf16 pipe", 2840.0),
+                 {"config": {"workload": "normal f32 batch 128"}, "dtype": "f32", "error": "E" * 1000}]
+    cpu = {"value": 1.234567, "unit": "clips/s", "cores": 8, "kind": "port", "batch": 8, "timed_iterations": 5, "sample": "s" * 600,
+           "c1_moving_mnist_shape": {"value": 2.0}}
+    text = bench.compact_line(out, secondary, cpu, "/somewhere/bench_detail.json")
+    assert len(text) <= bench.LINE_LIMIT <= 4096 and "\n" not in text
+    line = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(line["roofline"]) and "by_layer" not in line["roofline"]
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(line["cpu_baseline"])
+    assert "configs[1]" in line["config"]["workload"] and line["dtype"] == "f32"
+    assert [s["dtype"] for s in line["secondary"]] == ["bf16", "f32", "f32x3", "f32"] and "error" in line["secondary"][3]
+    assert all({"value", "ms_per_step", "frac"} <= set(s) for s in line["secondary"][:3])
+    assert line["detail"] == "bench_detail.json"
+    # an absurdly long record still respects the bound (optional parts are dropped, never the contract fields)
+    big = [rec("bf16", "w" * 3000, 1.0) for _ in range(6)]
+    text = bench.compact_line(out, big, cpu, None)
+    assert len(text) <= bench.LINE_LIMIT and json.loads(text)["value"] == round(2142.123456, 4)
+    assert bench.PEAK_F32X3_TFLOPS == pytest.approx(2516.8 / 6)

@@ -101,3 +101,62 @@ def test_rank_streams_are_disjoint_and_frame_index_is_shared():
         seed = 3
     ts = [TS.frame_index(Dummy(), it, 16) for it in range(50)]
     assert ts == [TS.frame_index(Dummy(), it, 16) for it in range(50)] and 0 <= min(ts) and max(ts) < 16 and len(set(ts)) > 5
+
+
+def _epoch_worker(rank, world, port, q, n_items, batch, max_epoch):
+    """The product's Trainer + SerialIterator + ShardedDataset under a stand-in updater whose update() performs the one thing that
+    couples the ranks: an all-reduce per iteration (the gradient exchange of step.TrainStep.run)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import tempfile
+    from datasets import ShardedDataset, SyntheticDataset
+    from mocogan_chainer_amd import trainer as T
+
+    np.random.seed(100 + rank)                                   # per-rank data order, as train.py seeds it
+    it = T.SerialIterator(ShardedDataset(SyntheticDataset(n_items, 6, video_length=1, img_size=8), rank, world), batch)
+
+    class U:
+        iteration = 0
+        observation = {}
+
+        def update(self):
+            it.next()
+            t = torch.ones(1)
+            dist.all_reduce(t)                                   # blocks until EVERY rank has reached this iteration
+            assert float(t) == world
+            self.iteration += 1
+
+        epoch = property(lambda s: it.epoch)
+        is_new_epoch = property(lambda s: it.is_new_epoch)
+
+        def get_iterator(self, name):
+            return it
+
+    u = U()
+    with tempfile.TemporaryDirectory() as out:
+        T.Trainer(u, (max_epoch, 'epoch'), out=out).run()
+    q.put((rank, u.iteration, it.epoch))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_items,world,batch,max_epoch", [(11, 2, 2, 3), (7, 2, 4, 5)])
+def test_ranks_reach_max_epoch_together_when_world_does_not_divide_the_dataset(n_items, world, batch, max_epoch):
+    """train.py --dp_shard stops on (max_epoch, 'epoch') of each rank's OWN iterator (reference train.py:128-132); with shards of
+    unequal length the short ranks would leave first and the long one would wait in the gradient all-reduce forever (advisor,
+    round 3).  Equal-length shards: every rank runs the same number of iterations and the run ends."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000 + n_items
+    procs = [ctx.Process(target=_epoch_worker, args=(r, world, port, q, n_items, batch, max_epoch)) for r in range(world)]
+    [p.start() for p in procs]
+    try:
+        res = sorted(q.get(timeout=120) for _ in procs)
+    finally:
+        [p.join(30) for p in procs]
+        [p.kill() for p in procs if p.is_alive()]
+    assert all(p.exitcode == 0 for p in procs)
+    shard = -(-n_items // world)
+    want_iters = -(-shard * max_epoch // batch)                   # SerialIterator: epoch e is complete after ceil(e * len / batch) batches
+    assert [r[1] for r in res] == [want_iters] * world and [r[2] for r in res] == [max_epoch] * world

@@ -747,7 +747,10 @@ def test_bf16_stored_operands_equal_rounding_in_the_kernel(hl, case, tile):
     assert rel_l2(lay.act_from_dev(res['bf16s'][1], Ci), gx_ref) < BWD_TOL
     assert rel_l2(lay.conv_w_from_dev(res['bf16s'][2], Ci, 3), gW_ref) < BWD_TOL
     assert torch.equal(res['bf16'][0], res['bf16s'][0]) and torch.equal(res['bf16'][1], res['bf16s'][1])
-    assert rel_l2(res['bf16s'][2], res['bf16'][2].cpu().double().numpy()) < 1e-5
+    if not rel_l2(res['bf16s'][2], res['bf16'][2].cpu().double().numpy()) < 1e-5:      # (seen once, on the driver's box in round 3: leave evidence)
+        from guard import describe_diff
+        ref_dev = lay.conv_w_to_dev(dev(gW_ref)).cpu().double().numpy()
+        raise AssertionError(describe_diff(res['bf16s'][2], res['bf16'][2], ref_dev, names=("bf16s", "bf16")))
     # a stats epilogue rides on a 'bf16s' launch too; host tensors / wrong dtypes are refused
     g = hl.make_geom(N, Ti, H, H, Ci, Co, kt, precision='bf16s')
     g.tile = tile
