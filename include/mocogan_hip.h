@@ -115,7 +115,7 @@ typedef struct mcg_conv_geom {
 
 /* ABI revision of this header: a host built against another revision must not call in (argument lists differ).
  * 3 = round 3 (mcg_randint, bf16 tensors in the synchronised-BatchNorm backward; round 2 changed mcg_bn_act_fwd / mcg_bn_act_bwd / mcg_adam_wd / mcg_conv_geom). */
-#define MCG_ABI_VERSION 4
+#define MCG_ABI_VERSION 5
 int mcg_version(void);
 
 /* ---- implicit-GEMM convolution on the fp32 MFMA (v_mfma_f32_32x32x2_f32) ------------------- */
@@ -289,6 +289,11 @@ int mcg_colsum_acc(int64_t M, int C, const float* g, float* db, void* workspace,
 int mcg_pack_clip(int N, int C, int Cp, int T, int HW, const float* x, int64_t x_stride_n,
                   int64_t x_stride_c, const float* addend,
                   float sigma, uint64_t seed, uint64_t stream_id, float* out, void* stream);
+/* cgan (model/updater.py:65-76, concat_label_video): out[n][p][0..Cq) = x[n][p][0..C), then dl label planes -- +1 at channel
+ * C + labels[n], -1 at the others -- then zeros; x is [N][P][Cp], out [N][P][Cq], Cq % 4 == 0, labels int32 [N] in [0, dl).
+ * dl == 0 (labels may be NULL): a channel slice into another row width -- the way back, where label planes carry no gradient. */
+int mcg_concat_label_planes(int N, int64_t P, int C, int Cp, int dl, int Cq, const float* x, const int32_t* labels, float* out,
+                            void* stream);
 /* x[N][C][T][HW] = in[N][T][HW][Cp] (first C channels) */
 int mcg_unpack_clip(int N, int C, int Cp, int T, int HW, const float* in, float* x, void* stream);
 /* g_frames[(t*N+n)][HW][Cp] = g_clip[n][t][HW][Cp] * (1 - x_clip^2): tanh backward fused with the

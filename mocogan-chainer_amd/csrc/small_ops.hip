@@ -541,6 +541,26 @@ __global__ __launch_bounds__(NT) void pack_clip_kernel(int N, int C, int Cp, int
     }
 }
 
+// cgan (model/updater.py:65-76): the first C channels of every pixel, then dl label planes (+1 on the item's label, -1 elsewhere),
+// then zero padding.  dl == 0: a plain channel slice into another row width (the way back: label planes carry no gradient).
+__global__ __launch_bounds__(NT) void concat_label_planes_kernel(long long npix, long long P, int C, int Cp, int dl, int Cq,
+                                                                 const float* __restrict__ x, const int32_t* __restrict__ labels,
+                                                                 float* __restrict__ out) {
+    const int Cq4 = Cq >> 2;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < npix * Cq4; i += (long long)gridDim.x * NT) {
+        const long long p = i / Cq4;
+        const int c0 = (int)(i - p * Cq4) * 4;
+        const int lab = dl ? labels[p / P] : 0;
+        f32x4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + k;
+            v[k] = c < C ? x[p * Cp + c] : (c < C + dl ? (c - C == lab ? 1.f : -1.f) : 0.f);
+        }
+        *reinterpret_cast<f32x4*>(out + i * 4) = v;
+    }
+}
+
 __global__ __launch_bounds__(NT) void unpack_clip_kernel(int N, int C, int Cp, int T, int HW, const float* __restrict__ in,
                                                          float* __restrict__ x) {
     const long long npix = (long long)N * T * HW;
@@ -1342,6 +1362,15 @@ extern "C" int mcg_pack_clip(int N, int C, int Cp, int T, int HW, const float* x
     long long npix = (long long)N * T * HW;
     hipLaunchKernelGGL(pack_clip_kernel, dim3(ew_grid(npix)), dim3(NT), 0, (hipStream_t)stream, N, C, Cp, T, HW, x,
                        (long long)x_stride_n, (long long)x_stride_c, addend, sigma, seed, stream_id, out);
+    return launch_status();
+}
+
+extern "C" int mcg_concat_label_planes(int N, int64_t P, int C, int Cp, int dl, int Cq, const float* x, const int32_t* labels, float* out,
+                                       void* stream) {
+    if (!x || !out || N <= 0 || P <= 0 || C <= 0 || Cp < C || dl < 0 || Cq < C + dl || (Cq & 3) || (dl && !labels)) return MCG_ERR_BAD_ARG;
+    const long long npix = (long long)N * P;
+    hipLaunchKernelGGL(concat_label_planes_kernel, dim3(ew_grid(npix * (Cq >> 2))), dim3(NT), 0, (hipStream_t)stream, npix, (long long)P, C, Cp,
+                       dl, Cq, x, labels, out);
     return launch_status();
 }
 

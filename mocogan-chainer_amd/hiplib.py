@@ -75,6 +75,7 @@ SIGNATURES = {
     "mcg_colsum_acc": (_I, [_I64, _I, _P, _P, _P, _P]),
     "mcg_pack_clip": (_I, [_I, _I, _I, _I, _I, _P, _I64, _I64, _P, _F, _U64, _U64, _P, _P]),
     "mcg_unpack_clip": (_I, [_I, _I, _I, _I, _I, _P, _P, _P]),
+    "mcg_concat_label_planes": (_I, [_I, _I64, _I, _I, _I, _I, _P, _P, _P, _P]),
     "mcg_tanh_bwd_to_frames": (_I, [_I, _I, _I64, _P, _P, _P, _P]),
     "mcg_gru_seq_fwd": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mcg_gru_seq_bwd": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
@@ -86,7 +87,7 @@ SIGNATURES = {
     "mcg_split_planes": (_I, [_I64, _I64, _P, _P, _P]),
 }
 
-ABI_VERSION = 4          # MCG_ABI_VERSION of include/mocogan_hip.h these prototypes were written against
+ABI_VERSION = 5          # MCG_ABI_VERSION of include/mocogan_hip.h these prototypes were written against
 
 _lib = None
 
@@ -348,6 +349,9 @@ def split_pays(kind, g, run_plain, run_split):
         return mode == 'always'
     key = _geom_key('split-' + kind, g)
     c = _tile_cache.get(key)
+    if c is None and not _autotune:
+        return False                # tuner off (tests, train.py --autotune 0): nothing is timed -- the table's entries, else the fp32 form.
+                                    # (Under data parallelism per-rank timing could also leave the ranks on different forms.)
     if c is None:
         global _timing
         saved, _timing = _timing, None
@@ -728,6 +732,17 @@ def pack_clip(N, Cn, Cp, T, HW, x, out, addend=None, sigma=0.0, seed=0, stream_i
     stride_c = T * HW if stride_c is None else stride_c
     _check(load().mcg_pack_clip(N, Cn, Cp, T, HW, _p(x), stride_n, stride_c, _p(_dense(addend)), sigma, seed, stream_id,
                                 _p(_dense(out)), _stream()), "mcg_pack_clip")
+
+
+def concat_label_planes(x, c, dl, labels, out):
+    """x [N][..][Cp] -> out [N][..][Cq]: the first c channels, dl label planes (+1 / -1), zero padding (model/updater.py:65-76);
+    dl = 0: a channel slice into another row width."""
+    N = x.shape[0]
+    P = x[0].numel() // x.shape[-1]
+    assert out.shape[:-1] == x.shape[:-1]
+    _check(load().mcg_concat_label_planes(N, P, c, x.shape[-1], dl, out.shape[-1], _p(_dense(x)), _p(labels, torch.int32) if dl else None,
+                                          _p(_dense(out)), _stream()), "mcg_concat_label_planes")
+    return out
 
 
 def unpack_clip(N, Cn, Cp, T, HW, inp, x):

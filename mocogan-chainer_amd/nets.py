@@ -140,8 +140,12 @@ class _Net:
             cache[(name, form)] = ent = (self.fp.version, hl.split_planes(w, run=run, out=ent[1] if ent else None))
         return ent[1]
 
-    def _cfprop(self, g, x, wname, w, b, y, ep=None, must_fuse=False, xs=None):
-        """hl.conv_fprop of this network (w = the filter operand the caller would pass; xs: callable returning the split form of x)"""
+    def _cfprop(self, g, x, wname, w, b, y, ep=None, must_fuse=False, xs=None, force=False):
+        """hl.conv_fprop of this network (w = the filter operand the caller would pass; xs: callable returning the split form of x).
+        force: x exists in its split form ONLY (its producer relied on _split_only): the split launch is the only correct one."""
+        if force:
+            assert self.precision == 'f32x3' and hl.split_covers('fprop', g) and xs is not None, "an operand written in the split form only needs the split launch"
+            return hl.conv_fprop(hl.with_precision(g, 'f32x3'), xs(), self._wsplit(wname, 'f'), b, y, ep=ep, must_fuse=must_fuse)
         if self.precision == 'f32x3' and hl.split_covers('fprop', g):
             gs = hl.with_precision(g, 'f32x3')
 
@@ -175,7 +179,10 @@ class _Net:
     def _split_only(self, *launches):
         """'f32x3': may the producer of a tensor write its split form ONLY?  Yes when every GEMM that reads it -- launches:
         (pass, geometry) pairs -- is known to take the split form (hl.split_decided); the fp32 tensor then stays allocated (shapes,
-        slicing) but is never written nor read."""
+        slicing) but is never written nor read.  The caller RECORDS the decision (saved['only'] / a local flag) and passes it to
+        _cfprop / _cdgrad / _cwgrad as force=True: a reader never consults the table again, so nothing that happens between the
+        producer and the reader (another geometry key for a selected group, a cleared or replaced table, MCG_SPLIT changing) can make
+        it read the unwritten fp32 tensor."""
         return (self.precision == 'f32x3' and self.sync_bn is None and os.environ.get('MCG_SPLIT_ONLY', '1') == '1'
                 and all(hl.split_decided(kind, g) for kind, g in launches))
 
@@ -189,8 +196,12 @@ class _Net:
             s = store[key] = hl.split_planes(t)
         return s
 
-    def _cwgrad(self, g, x, y, dw, xs=None, ys=None):
-        """self._wgrad (dw += ...); xs / ys: callables returning the split form of x / y"""
+    def _cwgrad(self, g, x, y, dw, xs=None, ys=None, force=False):
+        """self._wgrad (dw += ...); xs / ys: callables returning the split form of x / y; force: as _cfprop (x or y has no fp32 form)"""
+        if force:
+            assert self.precision == 'f32x3' and hl.split_covers('wgrad', g) and xs is not None and ys is not None, \
+                "an operand written in the split form only needs the split launch"
+            return self._wgrad(hl.with_precision(g, 'f32x3'), xs(), ys(), dw)
         if self.precision == 'f32x3' and hl.split_covers('wgrad', g):
             gs = hl.with_precision(g, 'f32x3')
             xs = xs or (lambda: hl.split_planes(x))
@@ -212,8 +223,11 @@ class _Net:
             sc = self.__dict__['_wgs'] = torch.zeros(dw.numel(), device=dw.device)
         return sc[:dw.numel()].view(dw.shape)
 
-    def _cdgrad(self, g, y, wname, w, b, x, ep=None, must_fuse=False, ys=None):
-        """hl.conv_dgrad of this network (no activation, not accumulating: the launches that have a split form)"""
+    def _cdgrad(self, g, y, wname, w, b, x, ep=None, must_fuse=False, ys=None, force=False):
+        """hl.conv_dgrad of this network (no activation, not accumulating: the launches that have a split form); force: as _cfprop"""
+        if force:
+            assert self.precision == 'f32x3' and hl.split_covers('dgrad', g) and ys is not None, "an operand written in the split form only needs the split launch"
+            return hl.conv_dgrad(hl.with_precision(g, 'f32x3'), ys(), self._wsplit(wname, 'd'), b, x, ep=ep, must_fuse=must_fuse)
         if self.precision == 'f32x3' and hl.split_covers('dgrad', g):
             gs = hl.with_precision(g, 'f32x3')
 
@@ -464,7 +478,7 @@ class DisNet(_Net):
 
         fuse_stats = train and 'stats' in FUSE and self.sync_bn is None
         fuse_dc1 = 'dc1' in FUSE
-        saved = {'n': n, 'G': G, 'a': {}, 'y': {}, 'stats': {}, 'mask1': None, 'split': {}}
+        saved = {'n': n, 'G': G, 'a': {}, 'y': {}, 'stats': {}, 'mask1': None, 'split': {}, 'only': set()}
         t, h = self._extents(1)
         a = torch.empty((N, t, h, h, self.cp0), device=dev)
         for gi, grp in enumerate(groups):
@@ -503,10 +517,10 @@ class DisNet(_Net):
             if l >= 2 and fuse_stats:
                 part = self._part_buf(g, 'fprop', G)
                 ep = hl.epilogue(sums=hl.SUMS_STATS, groups=G, part=part, out_bf16=y16)
-                if not self._cfprop(g, a, 'dc%d/W' % l, w, b, y, ep=ep, xs=lambda: self._sp(saved['split'], l, saved['a'][l])):
+                if not self._cfprop(g, a, 'dc%d/W' % l, w, b, y, ep=ep, xs=lambda: self._sp(saved['split'], l, saved['a'][l]), force=l in saved['only']):
                     ep = None                                    # split-K tile: the stand-alone statistics pass below
             else:
-                self._cfprop(g, a, 'dc%d/W' % l, w, b, y, xs=lambda: self._sp(saved['split'], l, saved['a'][l]))
+                self._cfprop(g, a, 'dc%d/W' % l, w, b, y, xs=lambda: self._sp(saved['split'], l, saved['a'][l]), force=l in saved['only'])
             saved['y'][l] = y
             a = torch.empty_like(y, dtype=adt)
             a_split = None                                       # 'f32x3': layer l + 1's GEMMs both read the split form -> written directly
@@ -514,6 +528,7 @@ class DisNet(_Net):
                 gn = self._geom(l + 1, N)
                 if self._split_only(('fprop', gn), ('wgrad', gn)):
                     a_split = saved['split'][l + 1] = torch.empty(y.shape[:-1] + (4 * co,), device=dev, dtype=torch.bfloat16)
+                    saved['only'].add(l + 1)                     # saved['a'][l + 1] stays unwritten
             if l >= 2:
                 saved['stats'][l] = []
             for gi, grp in enumerate(groups):
@@ -559,7 +574,7 @@ class DisNet(_Net):
             mask = mask[gi * rows:(gi + 1) * rows]
         return {'n': n, 'G': 1, 'a': {l: v[sl] for l, v in saved['a'].items()}, 'split': {l: v[sl] for l, v in saved.get('split', {}).items()},
                 'y': {l: (None if v is None else v[sl]) for l, v in saved['y'].items()},
-                'stats': {l: [v[gi]] for l, v in saved['stats'].items()}, 'mask1': mask}
+                'stats': {l: [v[gi]] for l, v in saved['stats'].items()}, 'mask1': mask, 'only': set(saved.get('only', ()))}
 
     def _test_scale_shift(self, name):
         """fixed_batch_normalization (test mode, reference util.py:92): scale/shift from running stats."""
@@ -574,12 +589,13 @@ class DisNet(_Net):
         o = self.fp.offsets
         return o['dc4/W'], o['bn2/gamma']
 
-    def backward(self, saved, g_logits, param_grads, gx=None, gx_geom=None, gx_accumulate=False, on_late_bucket=None):
+    def backward(self, saved, g_logits, param_grads, gx=None, gx_geom=None, gx_accumulate=False, on_late_bucket=None, defer_gx=False):
         """g_logits [G*n][out] for the G groups of `saved`.  param_grads: accumulate dW/db/dgamma/dbeta into
         the flat gradient (D's own loss: all groups in one set of launches).  gx (single group only): the
         gradient w.r.t. the first conv's input is written (or accumulated) there through gx_geom (G's loss
         through this D, current weights: Q5).  on_late_bucket: called once the gradients of dc5 and dc4
-        are final (see grad_bucket_late)."""
+        are final (see grad_bucket_late).  defer_gx: the launch that writes gx is not queued but returned as a
+        callable -- the caller runs it on the stream (and after the work) gx belongs to."""
         n, G = saved['n'], saved['G']
         N = n * G
         fp = self.fp
@@ -594,6 +610,7 @@ class DisNet(_Net):
         hl.fc_dgrad(N, k, co5, g_logits, fp.param('dc5/W').view(co5, k), None, 0, g.view(N, k))
         mask1 = saved.get('mask1')
         pending = None            # (epilogue, partial sums) the GEMM that produced g left for the layer processed next
+        deferred = None
         for l in (4, 3, 2, 1):
             geom = self._geom(l, N)
             co = self.chans[l]
@@ -628,7 +645,8 @@ class DisNet(_Net):
                     hl.bn_act_bwd(m, co, gg, yg, None, None, hl.ACT_LRELU, gg, None, None, self.ws)
             # (l == 1 with a stored mask: dc2's input-gradient GEMM applied leaky_relu's backward in its epilogue)
             gsp = {}                                             # 'f32x3': the split form of g, shared by the two GEMMs that read it
-            if l >= 2 and gy_split is not None:
+            g_only = l >= 2 and gy_split is not None             # ... which is the ONLY form of g that was written
+            if g_only:
                 gsp[0] = gy_split
 
             def gys():
@@ -640,7 +658,8 @@ class DisNet(_Net):
                     else:
                         hl.colsum_acc(m * G, co, g, fp.grad('dc1/b'), self.ws)
                 # dc2..dc4 feed BatchNorm: sum_m gx == 0 exactly (see _Net.BIAS_NOTE), nothing to add
-                self._cwgrad(geom, saved['a'][l], g, fp.grad('dc%d/W' % l), xs=lambda: self._sp(saved.get('split'), l, saved['a'][l]), ys=gys)
+                self._cwgrad(geom, saved['a'][l], g, fp.grad('dc%d/W' % l), xs=lambda: self._sp(saved.get('split'), l, saved['a'][l]), ys=gys,
+                             force=g_only or l in saved.get('only', ()))
                 if l == 4 and on_late_bucket is not None:
                     self._after_wgrads(on_late_bucket)
             pending = None
@@ -652,22 +671,30 @@ class DisNet(_Net):
                 if l == 2 and mask1 is not None:
                     part = self._part_buf(geom, 'dgrad', 1) if param_grads else None
                     ep = hl.epilogue(mask_in=mask1, sums=hl.SUMS_COL if param_grads else hl.SUMS_NONE, groups=1, part=part)
-                    self._cdgrad(geom, g, 'dc%d/W' % l, w, None, ga, ep=ep, must_fuse=True, ys=gys)
+                    self._cdgrad(geom, g, 'dc%d/W' % l, w, None, ga, ep=ep, must_fuse=True, ys=gys, force=g_only)
                     pending = (ep, part) if param_grads else None
                 elif l > 2 and self._fuse_bwd_sums(s16, 'dgrad', geom):
                     part = self._part_buf(geom, 'dgrad', G)
                     ep = hl.epilogue(sums=hl.SUMS_BN_BWD, groups=G, part=part, bn_y=saved['y'][l - 1], bn_stats=saved['stats'][l - 1],
                                      bn_act=hl.ACT_LRELU, out_bf16=g16)
-                    if self._with_bwd_sums(lambda e: self._cdgrad(geom, g, 'dc%d/W' % l, w, None, ga, ep=e, ys=gys), ep):
+                    if self._with_bwd_sums(lambda e: self._cdgrad(geom, g, 'dc%d/W' % l, w, None, ga, ep=e, ys=gys, force=g_only), ep):
                         pending = (ep, part)
                 else:
-                    self._cdgrad(geom, g, 'dc%d/W' % l, w, None, ga, ys=gys)
+                    self._cdgrad(geom, g, 'dc%d/W' % l, w, None, ga, ys=gys, force=g_only)
                 g = ga
             elif gx is not None:
-                hl.conv_dgrad(gx_geom if gx_geom is not None else geom, g, fp.param('dc1/W'), None, gx,
-                              accumulate=gx_accumulate)
+                def write_gx(g=g, geom=geom):
+                    hl.set_tag(self.tag)
+                    hl.conv_dgrad(gx_geom if gx_geom is not None else geom, g, fp.param('dc1/W'), None, gx, accumulate=gx_accumulate)
+                    if defer_gx:                                 # g was allocated under the stream this pass ran on: the allocator must
+                        g.record_stream(torch.cuda.current_stream())     # not hand its block out before the caller's stream is done
+                if defer_gx:
+                    deferred = write_gx
+                else:
+                    write_gx()
         if param_grads:
             self._wgrad_join()
+        return deferred
 
 
 # ==========================================================================================
@@ -798,7 +825,7 @@ class GenNet(_Net):
         fp = self.fp
         train = config.train
         hl.set_tag('G')
-        saved = {'n': n, 'draw': draw, 'y': {}, 'a': {}, 'stats': {}, 'split': {}}
+        saved = {'n': n, 'draw': draw, 'y': {}, 'a': {}, 'stats': {}, 'split': {}, 'only': set()}
         z = torch.empty((frames, dc + dz), device=dev)
         gsaved = torch.empty((T, n, 4 * dz), device=dev)
         hl.gru_seq_fwd(n, T, dz, dl, dc, fp.param('g0'), draw['h0'], draw['e'], draw['labels'], draw['zc'], z, gsaved)
@@ -837,6 +864,7 @@ class GenNet(_Net):
             gn = self._geom(l + 1, frames) if l < 4 else None
             if gn is not None and self._split_only(('dgrad', gn), ('wgrad', gn)):      # 'f32x3': both readers take the split form
                 saved['split'][l + 1] = torch.empty(y.shape[:-1] + (4 * co,), device=dev, dtype=torch.bfloat16)
+                saved['only'].add(l + 1)                         # saved['a'][l + 1] stays unwritten
                 hl.bn_act_fwd(m, co, y, ss, hl.ACT_RELU, saved['split'][l + 1], split_out=True)
             else:
                 hl.bn_act_fwd(m, co, y, ss, hl.ACT_RELU, a)
@@ -854,10 +882,12 @@ class GenNet(_Net):
                 if fuse_stats:
                     part = self._part_buf(geom, 'dgrad', 1)
                     ep = hl.epilogue(sums=hl.SUMS_STATS, groups=1, part=part, out_bf16=y16)
-                    if self._cdgrad(geom, a, 'dc%d/W' % (l + 1), w, b, y, ep=ep, ys=lambda: self._sp(saved['split'], l + 1, saved['a'][l + 1])):
+                    if self._cdgrad(geom, a, 'dc%d/W' % (l + 1), w, b, y, ep=ep, ys=lambda: self._sp(saved['split'], l + 1, saved['a'][l + 1]),
+                                    force=l + 1 in saved['only']):
                         pending = (ep, part)
                 else:
-                    self._cdgrad(geom, a, 'dc%d/W' % (l + 1), w, b, y, ys=lambda: self._sp(saved['split'], l + 1, saved['a'][l + 1]))
+                    self._cdgrad(geom, a, 'dc%d/W' % (l + 1), w, b, y, ys=lambda: self._sp(saved['split'], l + 1, saved['a'][l + 1]),
+                                 force=l + 1 in saved['only'])
         x = torch.empty((n, T, IMG, IMG, self.cp_out), device=dev)
         g5 = self._geom(5, frames, clip_order_n=n)
         if hl.dgrad_c4_mfma_covers(g5):
@@ -918,7 +948,9 @@ class GenNet(_Net):
 
             def gxs():
                 return self._sp(gsp, 0, g)
-            self._cwgrad(geom, g, saved['a'][l], fp.grad('dc%d/W' % l), xs=gxs, ys=lambda: self._sp(saved.get('split'), l, saved['a'][l]))
+            g_only = gy_split is not None                        # g exists in its split form only
+            self._cwgrad(geom, g, saved['a'][l], fp.grad('dc%d/W' % l), xs=gxs, ys=lambda: self._sp(saved.get('split'), l, saved['a'][l]),
+                         force=g_only or l in saved.get('only', ()))
             if l == 2 and on_late_bucket is not None:
                 self._after_wgrads(on_late_bucket)
             wl = self._w('dc%d/W' % l, s16)
@@ -930,10 +962,10 @@ class GenNet(_Net):
                 part = self._part_buf(geom, 'fprop', 1)
                 ep = hl.epilogue(sums=hl.SUMS_BN_BWD, groups=1, part=part, bn_y=saved['y'][l - 1], bn_stats=[saved['stats'][l - 1]],
                                  bn_act=hl.ACT_RELU, out_bf16=g16)
-                if self._with_bwd_sums(lambda e: self._cfprop(geom, g, 'dc%d/W' % l, wl, None, ga, ep=e, xs=gxs), ep):
+                if self._with_bwd_sums(lambda e: self._cfprop(geom, g, 'dc%d/W' % l, wl, None, ga, ep=e, xs=gxs, force=g_only), ep):
                     pending = (ep, part)
             else:
-                self._cfprop(geom, g, 'dc%d/W' % l, wl, None, ga, xs=gxs)
+                self._cfprop(geom, g, 'dc%d/W' % l, wl, None, ga, xs=gxs, force=g_only)
             g = ga
         c1 = self.chans[1]
         k1 = 16 * c1

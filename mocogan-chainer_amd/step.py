@@ -60,9 +60,9 @@ class GradExchange:
             return None
         return (self.dist.all_reduce(flat_grad, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True), flat_grad)
 
-    def finish(self, handle, flat_grad=None):
-        """Wait for the collective (stream-ordered on RCCL: the current stream waits, the host does not).  The
-        buffer then holds the SUM over the ranks; adam_update(..., grad_scale=self.grad_scale) makes it the mean."""
+    def finish(self, handle):
+        """Wait for the collective start() returned the handle of (stream-ordered on RCCL: the current stream waits, the host
+        does not).  Its buffer then holds the SUM over the ranks; adam_update(..., grad_scale=self.grad_scale) makes it the mean."""
         if handle is None:
             return
         work, _ = handle
@@ -118,15 +118,11 @@ class TrainStep:
 
     # ---- cgan label planes (model/updater.py:65-76) -------------------------------------------------
     def _concat_label_clip(self, x_dev, labels):
-        """x_dev [n][T][H][W][4] with C=3 -> [n][T][H][W][pad4(3+dim_zl)] with -1/+1 label planes."""
+        """x_dev [n][T][H][W][4] with C=3 -> [n][T][H][W][pad4(3+dim_zl)] with -1/+1 label planes (one launch)."""
         n, T, H, W, _ = x_dev.shape
         c, dl = self.gen.out_channels, self.gen.dim_zl
-        out = torch.zeros((n, T, H, W, lay.pad4(c + dl)), device=x_dev.device)
-        out[..., :c] = x_dev[..., :c]
-        planes = -torch.ones((n, dl), device=x_dev.device)
-        planes[torch.arange(n, device=x_dev.device), labels.long()] = 1.0
-        out[..., c:c + dl] = planes.view(n, 1, 1, 1, dl)
-        return out
+        out = torch.empty((n, T, H, W, lay.pad4(c + dl)), device=x_dev.device)
+        return hl.concat_label_planes(x_dev, c, dl, labels, out)
 
     # ---- perf-mode randomness bookkeeping ----------------------------------------------------------
     STREAMS_PER_RANK = 64        # Philox stream ids one rank may consume per iteration (uses 5 x 8)
@@ -252,26 +248,23 @@ class TrainStep:
         hl.loss_gen(n, cd, y_fake_i, y_fake_v, t_fake, with_ce, self.loss[2:3], gi, gv)
         gx = torch.empty_like(xf)
         s_fake_v, s_fake_i = dv.select_group(s_v, 1), di.select_group(s_i, 1)
+        gi_geom = hl.make_geom(n, 1, H, W, cp, di.chans[1], 1, x_stride0=T * hw * cp, precision=di.gemm_precision, ci_valid=di.chans[0])
         if self.side is not None:
             # the two discriminators' input gradients are independent until they meet in frame t of the clip gradient:
-            # D_I's (small kernels) runs on the side stream beside D_V's and lands in a buffer of its own
-            gxi = torch.empty((n, 1, H, W, cp), device=self.device)
+            # D_I's layers 5..2 (small kernels) run on the side stream beside D_V's; its LAST launch -- the input gradient of
+            # dc1, accumulated onto frame t of what D_V's pass wrote -- follows on the main stream once both are done
             self.side.wait_stream(main)                              # loss_gen's gradients
             with torch.cuda.stream(self.side):
-                di.backward(s_fake_i, gi, False, gx=gxi)
-            for tns in (gi, gxi):
-                tns.record_stream(self.side)
+                last_i = di.backward(s_fake_i, gi, False, gx=gx[:, t], gx_geom=gi_geom, gx_accumulate=True, defer_gx=True)
+            gi.record_stream(self.side)
             dv.backward(s_fake_v, gv, False, gx=gx)                  # new D_V weights, old activations (Q5)
             main.wait_stream(self.side)
-            gx[:, t].add_(gxi[:, 0])                                 # the same two addends as the accumulating launch below
+            last_i()
         else:
             dv.backward(s_fake_v, gv, False, gx=gx)                  # new D_V weights, old activations (Q5)
-            gi_geom = hl.make_geom(n, 1, H, W, cp, di.chans[1], 1, x_stride0=T * hw * cp, precision=di.gemm_precision, ci_valid=di.chans[0])
             di.backward(s_fake_i, gi, False, gx=gx[:, t], gx_geom=gi_geom, gx_accumulate=True)
-        if cgan:
-            gxg = torch.zeros_like(x_fake)
-            gxg[..., :c_img] = gx[..., :c_img]                       # label planes carry no gradient to G
-            gx = gxg
+        if cgan:                                                     # label planes carry no gradient to G: the clip's channels alone
+            gx = hl.concat_label_planes(gx, c_img, 0, None, torch.empty_like(x_fake))
         late_g = []
         lo_g, hi_g = gen.grad_bucket_late()
         gen.backward(s_gen, gx, on_late_bucket=(lambda: late_g.append(ex.start(gen.fp.g[lo_g:hi_g]))) if ex else None)

@@ -67,3 +67,43 @@ def randn_rowquad(M, C, sigma, seed, stream_id):
     assert M % 4 == 0
     z = randn(M * C, sigma, seed, stream_id).reshape(M // 4, C, 4)          # counter (mq, c) -> its 4 normals
     return np.ascontiguousarray(z.transpose(0, 2, 1)).reshape(M, C)
+
+
+# ---- the randomness of one perf-mode iteration (what bench.py times and Updater.update_core runs) ------------------------------
+# Written from the SPECIFICATION of the ids, independently of step.py / nets.py:
+#   base(it, rank) = (it * 64 + rank + 1) * 64; call k of the iteration owns ids base + 8 k ..: k = 0 D_I(real), 1 D_V(real),
+#   2 the generator's latent draw, 3 D_I(fake), 4 D_V(fake); a discriminator call uses id + l - 1 for the add_noise in front of layer
+#   l = 1..4 (model/net.py:148-154,189-195), the latent draw id + 0 / 1 / 2 / 3 for h0 / e / zc / labels (model/net.py:66,71,102,92).
+# Used by tests/test_gpu_step.py and __graft_entry__.smoke() to feed the oracle the draws the device makes in-kernel.
+def perf_mode_randomness(seed, it, rank, model, n, nf, dim_zl, c_img=3, T=16, dim_zc=50, dim_zm=10, sigma=0.2):
+    base = (it * 64 + rank + 1) * 64
+    cd = c_img + (dim_zl if model == 'cgan' else 0)
+    cp = (cd + 3) // 4 * 4
+
+    def to_ref(z, ndim):                                  # [n][T][H][W][C] -> (n,C,T,H,W) / (n,C,H,W)
+        z = z.transpose(0, 4, 1, 2, 3)
+        return np.ascontiguousarray(z[:, :, 0] if ndim == 2 else z)
+
+    def dis_noise(ndim, k):
+        sid = base + 8 * k
+        t = T if ndim == 3 else 1
+        out = [to_ref(randn(n * t * 64 * 64 * cp, sigma, seed, sid).reshape(n, t, 64, 64, cp)[..., :cd], ndim)]
+        t = t - 3 if ndim == 3 else 1
+        out.append(to_ref(randn_rowquad(n * t * 32 * 32, nf, sigma, seed, sid + 1).reshape(n, t, 32, 32, nf), ndim))
+        for l, (h, c) in ((3, (16, 2 * nf)), (4, (8, 4 * nf))):
+            t = t - 3 if ndim == 3 else 1
+            out.append(to_ref(randn(n * t * h * h * c, sigma, seed, sid + l - 1).reshape(n, t, h, h, c), ndim))
+        return out
+
+    import torch                                          # (the frame index is a torch host generator draw)
+    g = torch.Generator()
+    g.manual_seed(seed * 7919 + it)                       # the frame index: one host draw per iteration, shared by all ranks (Q7)
+    rnd = {'t': int(torch.randint(0, T, (1,), generator=g))}
+    rnd['noise_i_real'], rnd['noise_v_real'] = dis_noise(2, 0), dis_noise(3, 1)
+    sid = base + 16
+    rnd['gen'] = {'h0': randn(n * dim_zm, 0.33, seed, sid).reshape(n, dim_zm),
+                  'e': randn(T * n * dim_zm, 0.33, seed, sid + 1).reshape(T, n, dim_zm),
+                  'zc': randn(n * dim_zc, 0.33, seed, sid + 2).reshape(n, dim_zc),
+                  'labels': randint(n, dim_zl, seed, sid + 3) if dim_zl else None}
+    rnd['noise_i_fake'], rnd['noise_v_fake'] = dis_noise(2, 3), dis_noise(3, 4)
+    return rnd

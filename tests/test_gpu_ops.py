@@ -1223,3 +1223,25 @@ def test_patch_stationary_input_gradient(hl, case):
     with pytest.raises(hl.McgError):
         hl.conv_dgrad(gn, torch.zeros((2, 2, 8, 8, 128), device="cuda", dtype=torch.bfloat16),
                       torch.zeros((128, 4, 4, 4, 64), device="cuda", dtype=torch.bfloat16), None, torch.zeros((2, 5, 16, 16, 64), device="cuda"))
+
+
+def test_concat_label_planes(hl):
+    """mcg_concat_label_planes against Updater.concat_label_video's arithmetic (model/updater.py:65-76): the clip's channels, +1 on
+    the item's label plane and -1 on the others, zero padding; dl = 0 is the channel slice used on the way back."""
+    rng = np.random.RandomState(3)
+    n, T, H, c, dl = 3, 2, 8, 3, 6
+    x = dev(rng.randn(n, T, H, H, 4))
+    labels = dev(np.array([5, 0, 2]), torch.int32)
+    out = hl.concat_label_planes(x, c, dl, labels, torch.full((n, T, H, H, 12), 7.0, device="cuda"))
+    want = torch.zeros((n, T, H, H, 12), device="cuda")
+    want[..., :c] = x[..., :c]
+    want[..., c:c + dl] = -1.0
+    for i, lab in enumerate((5, 0, 2)):
+        want[i, ..., c + lab] = 1.0
+    assert torch.equal(out, want)
+    back = hl.concat_label_planes(out, c, 0, None, torch.full((n, T, H, H, 4), 7.0, device="cuda"))
+    want_b = torch.zeros_like(back)
+    want_b[..., :c] = x[..., :c]
+    assert torch.equal(back, want_b)
+    with pytest.raises(hl.McgError):
+        hl.concat_label_planes(x, c, dl, labels, torch.empty((n, T, H, H, 8), device="cuda"))      # 3 + 6 channels do not fit 8
