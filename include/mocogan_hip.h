@@ -67,7 +67,12 @@ enum { MCG_PREC_F32 = 0, MCG_PREC_BF16 = 1,
         * w for dgrad) groups of 16 channels x 4 planes (hi, mid, lo, padding) of bf16, i.e. 4 * C uint16_t per pixel / filter row
         * (for dgrad's w: 16 filters x 4 planes, see mcg_split_planes).
         * Outputs stay fp32.  LDS-DMA kernels only (tile 0, 7 or 8); channel counts along the sum powers of two >= 16. */
-       MCG_PREC_SPLIT = 3 };
+       MCG_PREC_SPLIT = 3,
+       /* as MCG_PREC_BF16, with the y-side tensor bf16 IN MEMORY while x and w stay fp32: the clip-side layers of bf16 networks
+        * (Ci = 4: D's first layer, G's last), whose 64-channel neighbour tensor -- dc1's output gradient, G's last activation -- is
+        * 16x the size of the 4-channel clip.  mcg_conv_wgrad (x fp32, y bf16 -> dw fp32) and mcg_conv_dgrad (y bf16, w fp32 -> x fp32);
+        * mcg_conv_fprop treats it as MCG_PREC_BF16 (its INPUTS are x and w; a bf16 y OUTPUT is mcg_conv_epilogue.out_bf16).  Co a multiple of 8. */
+       MCG_PREC_BF16_Y16 = 4 };
 
 /* Geometry of one 4x4(x4) stride-(1,2,2) pad-(0,1,1) convolution, i.e. every strided layer of
  * the reference: L.ConvolutionND / L.Convolution2D dc1..dc4 (model/net.py:133-136,174-177) and,
@@ -83,7 +88,7 @@ typedef struct mcg_conv_geom {
     int32_t To, Ho, Wo, Co;
     int32_t kt;
     int32_t x_perm_n;
-    int32_t precision;         /* MCG_PREC_F32 or MCG_PREC_BF16 */
+    int32_t precision;         /* MCG_PREC_* */
     int32_t tile;              /* GEMM block tile for this call: 0 = library heuristic; 1 = 128x128, 2 = 128x64,
                                 * 3 = 64x64, 4 = 256x64, 5 = 64x256 (the last two with K-steps of 32 in fp32 mode);
                                 * 6 = the patch-in-LDS kernels of the Ci = 4, Co = 64 layers (refused elsewhere; what

@@ -57,7 +57,8 @@ struct Geom {
     u32 x_bytes, y_bytes, w_bytes;   // buffer extents for the hardware range check
     u32 magic_To;      // floor(2^32 / To) + 1:  q / To == umulhi(q, magic_To) for q < 2^32 / To
     u32 magic_N;       // the same for the batch size N
-    int prec;          // MCG_PREC_F32 / MCG_PREC_BF16
+    int prec;          // MCG_PREC_F32 / MCG_PREC_BF16 / MCG_PREC_BF16_STORE (MCG_PREC_BF16_Y16 arrives as MCG_PREC_BF16 + y16)
+    int y16;           // MCG_PREC_BF16_Y16: the y tensor is bf16 in memory (x, w fp32)
     int tile, bk;      // caller's choice (mcg_conv_geom.tile): tile 0 = library heuristic, 1/2/3; bk 0 = heuristic, 32/64
     int ksplit;        // fprop / dgrad: number of K splits (1, 2 or 4) from mcg_conv_geom.tile / 1000
     int cv;            // channels of x that carry data (mcg_conv_geom.ci_valid; == Ci when unspecified)
@@ -145,7 +146,7 @@ template <int BM, int BN, int BK, int E_ = 4, bool ST = false, int NT = NTHREADS
 struct FpropP {
     static constexpr bool A_KC = true, B_KC = true;
     static constexpr int ORDER = 0;
-    static constexpr int E = E_, ESZ = 16 / E_;
+    static constexpr int E = E_, ESZ = 16 / E_, EA = E_, EB = E_;
     static constexpr int NA = BM * BK / E / NT, NB = BN * BK / E / NT;
     static constexpr bool HAS_EPI = true;
     Geom g;
@@ -299,7 +300,7 @@ template <int BM, int BN, int BK, int E_ = 4, bool ST = false, int NT = NTHREADS
 struct DgradP {
     static constexpr bool A_KC = true, B_KC = false;
     static constexpr int ORDER = 1;
-    static constexpr int E = E_, ESZ = 16 / E_;
+    static constexpr int E = E_, ESZ = 16 / E_, EA = E_, EB = E_;
     static constexpr int NA = BM * BK / E / NT, NB = BN * BK / E / NT;
     static constexpr bool HAS_EPI = true;
     Geom g;
@@ -516,14 +517,17 @@ struct DgradP {
 // SPL (MCG_PREC_SPLIT, LDS-DMA kernels): x and y are in the split layout [pixel][C/16][4 planes][16]; the 64 k rows of a K-step are
 // 16 PIXELS x 4 planes (k row r = plane r >> 4 of pixel r & 15 of the step), so that k chunk kc of a tile is plane kc of the same
 // 16 pixels and the kernel's SPLIT phase forms the six products; k counts quarter pixels (K-steps of 64 = 16 pixels).
-template <int BM, int BN, int BK, int E_ = 4, int NT = NTHREADS, bool SW = false, bool SPL = false>
+// EA_ (MCG_PREC_BF16_Y16, register-staged kernels): elements per 16-byte slot of the A operand (y) when it differs from the B
+// operand's (x): 8 = y bf16 in memory beside an fp32 x.
+template <int BM, int BN, int BK, int E_ = 4, int NT = NTHREADS, bool SW = false, bool SPL = false, int EA_ = E_>
 struct WgradP {
     static constexpr bool HAS_EPI = false;
     static constexpr bool HAS_ROW_OFF = false;
     static constexpr bool A_KC = false, B_KC = false;
     static constexpr int ORDER = 2;
     static constexpr int E = E_, ESZ = 16 / E_;
-    static constexpr int NA = BM * BK / E / NT, NB = BN * BK / E / NT;
+    static constexpr int EA = EA_, EB = E_, ESZA = 16 / EA_;
+    static constexpr int NA = BM * BK / EA / NT, NB = BN * BK / E / NT;
     Geom g;
     const float* x; const float* y; float* dw;
     int Mpix, Kf, chunk;          // Kf = taps*Ci ; chunk = pixels per split (multiple of BK)
@@ -532,10 +536,10 @@ struct WgradP {
     bool bok; int bt, bkh, bkw, bci; int bkrow[NB];
 
     __device__ void init(int m0, int n0, int tid, int /*z*/) {
-        constexpr int AC4 = BM / E, BC4 = BN / E;
+        constexpr int AC4 = BM / EA, BC4 = BN / E;
         xr = make_srd(x, g.x_bytes); yr = make_srd(y, g.y_bytes);
-        int aco = m0 + (SW && E == 8 ? ((tid % AC4) ^ sw_cols(tid / AC4, AC4)) : tid % AC4) * E;
-        aoff = aco < g.Co ? (SPL ? (u32)((aco >> 4) * 64 + (aco & 8)) * 2u : (u32)aco * (u32)ESZ) : OOB;
+        int aco = m0 + (SW && EA == 8 ? ((tid % AC4) ^ sw_cols(tid / AC4, AC4)) : tid % AC4) * EA;
+        aoff = aco < g.Co ? (SPL ? (u32)((aco >> 4) * 64 + (aco & 8)) * 2u : (u32)aco * (u32)ESZA) : OOB;
 #pragma unroll
         for (int j = 0; j < NA; ++j) akrow[j] = tid / AC4 + (NT / AC4) * j;
         int bkf = n0 + (SW && E == 8 ? ((tid % BC4) ^ sw_cols(tid / BC4, BC4)) : tid % BC4) * E;
@@ -557,7 +561,7 @@ struct WgradP {
             if constexpr (SPL) {
                 const int plane = akrow[j] >> 4, pix = (k0 >> 2) + (akrow[j] & 15);
                 f(j, plane < 3 ? aoff + (u32)(pix * 4 * g.Co + plane * 16) * 2u : OOB, 0u);       // (pixels beyond Mpix: beyond the buffer)
-            } else f(j, aoff + (u32)((k0 + akrow[j]) * g.Co) * (u32)ESZ, 0u);
+            } else f(j, aoff + (u32)((k0 + akrow[j]) * g.Co) * (u32)ESZA, 0u);
         }
     }
     template <class F> __device__ void each_b(int k0, F&& f) const {
@@ -591,7 +595,7 @@ struct WgradP {
     __device__ void load_a(int k0, f32x4 (&r)[NA]) const {
         // rows beyond Mpix fall outside the buffer: the range check returns zeros
 #pragma unroll
-        for (int j = 0; j < NA; ++j) r[j] = bload(yr, aoff + (u32)((k0 + akrow[j]) * g.Co) * (u32)ESZ);
+        for (int j = 0; j < NA; ++j) r[j] = bload(yr, aoff + (u32)((k0 + akrow[j]) * g.Co) * (u32)ESZA);
     }
     // (An incremental per-slot pixel decode -- wo/ho/q advanced by BK with carries -- was measured 3-8 %
     // slower than re-decoding with shifts and the multiply-high division: it costs 12 VGPRs.)
@@ -1137,22 +1141,22 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(P p) {
     int k0 = p.next_valid(p.k_begin(z));
     if (k0 < kend) { p.load_a(k0, ra); p.load_b(k0, rb); }
 
-    constexpr int E = P::E;                               // 4: fp32 operands, rounded to bf16 here; 8: bf16 operands, stored as loaded
-    constexpr int A_C4 = A_C / E, B_C4 = B_C / E;
+    constexpr int EA = P::EA, EB = P::EB;                 // 4: fp32 operand, rounded to bf16 here; 8: bf16 operand, stored as loaded
+    constexpr int A_C4 = A_C / EA, B_C4 = B_C / EB;
     while (k0 < kend) {
         // registers (-> bf16) -> LDS
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             int q = tid + NTHREADS * j;
-            u16* d = &As[(q / A_C4) * A_LD + (q % A_C4) * E];
-            if constexpr (E == 4) *reinterpret_cast<bf16x4*>(d) = __builtin_convertvector(ra[j], bf16x4);
+            u16* d = &As[(q / A_C4) * A_LD + (q % A_C4) * EA];
+            if constexpr (EA == 4) *reinterpret_cast<bf16x4*>(d) = __builtin_convertvector(ra[j], bf16x4);
             else *reinterpret_cast<f32x4*>(d) = ra[j];
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             int q = tid + NTHREADS * j;
-            u16* d = &Bs[(q / B_C4) * B_LD + (q % B_C4) * E];
-            if constexpr (E == 4) *reinterpret_cast<bf16x4*>(d) = __builtin_convertvector(rb[j], bf16x4);
+            u16* d = &Bs[(q / B_C4) * B_LD + (q % B_C4) * EB];
+            if constexpr (EB == 4) *reinterpret_cast<bf16x4*>(d) = __builtin_convertvector(rb[j], bf16x4);
             else *reinterpret_cast<f32x4*>(d) = rb[j];
         }
         __syncthreads();
@@ -2112,8 +2116,10 @@ struct C4DgradP {
 
 // BF: the two GEMM operands are rounded to bf16 on their way into LDS and multiplied on v_mfma_f32_16x16x32_bf16
 // (networks in bf16 mode; y and w are fp32 in memory either way, Z and the accumulators stay fp32)
-template <int KT, int WO, bool BF>
+// Y16 (MCG_PREC_BF16_Y16, with BF): y is bf16 in memory -- a 16-byte chunk is 8 channels and goes to LDS as loaded
+template <int KT, int WO, bool BF, bool Y16 = false>
 __global__ __launch_bounds__(512) void dgrad_c4_mfma_kernel(C4DgradP p) {
+    static_assert(!Y16 || BF, "a bf16 y tensor feeds the bf16 MFMA");
     constexpr int PIX = 128, R = PIX / WO, WI = 2 * WO, XR = 2 * R + 2;       // y pixels per step; input rows of the window
     constexpr int YLD = BF ? 36 : 68, WLD = YLD, ZLD = 52;                   // LDS row strides in floats (bf16 rows: 64 + 8 elements)
     constexpr int NPX = XR * WI, PPT = (NPX + 511) / 512;                    // input pixels of the window; per thread
@@ -2150,17 +2156,18 @@ __global__ __launch_bounds__(512) void dgrad_c4_mfma_kernel(C4DgradP p) {
             gz[q][k] = ok ? (hol * WO + wo) * ZLD + (kh * 4 + kw) * 3 : -1;
         }
     }
-    // y tile loader: thread -> (pixel, 16-byte chunk)
-    u32 yoff[PIX * 16 / 512];
+    // y tile loader: thread -> (pixel, 16-byte chunk); a pixel's 64 channels are CPP chunks of YE elements
+    constexpr int YE = Y16 ? 8 : 4, CPP = 64 / YE, NY = PIX * CPP / 512, YB = 16 / YE;
+    u32 yoff[NY];
 #pragma unroll
-    for (int j = 0; j < PIX * 16 / 512; ++j) {
-        const int s = tid + 512 * j, pix = s >> 4, c4 = s & 15, hol = pix / WO, wo = pix - hol * WO;
-        yoff[j] = (u32)((((long long)n * g.To * g.Ho + h0 + hol) * WO + wo) * 64 + c4 * 4) * 4u;   // + to * Ho * WO * 256 per frame
+    for (int j = 0; j < NY; ++j) {
+        const int s = tid + 512 * j, pix = s / CPP, c4 = s % CPP, hol = pix / WO, wo = pix - hol * WO;
+        yoff[j] = (u32)((((long long)n * g.To * g.Ho + h0 + hol) * WO + wo) * 64 + c4 * YE) * (u32)YB;   // + to * Ho * WO * 64 * YB per frame
     }
-    const u32 yframe = (u32)g.Ho * WO * 256u;
-    f32x4 ystage[PIX * 16 / 512];
+    const u32 yframe = (u32)g.Ho * WO * 64u * (u32)YB;
+    f32x4 ystage[NY];
 #pragma unroll
-    for (int j = 0; j < PIX * 16 / 512; ++j) ystage[j] = bload(yr, yoff[j]);
+    for (int j = 0; j < NY; ++j) ystage[j] = bload(yr, yoff[j]);
 
     const int li = lane & 15, kq = lane >> 4;
     auto retire = [&](int t) {              // frame t has all its temporal taps: write its window rows, clear the accumulator
@@ -2182,15 +2189,16 @@ __global__ __launch_bounds__(512) void dgrad_c4_mfma_kernel(C4DgradP p) {
     for (int to = 0; to < g.To; ++to) {
         __syncthreads();                                          // previous step's readers of yl / accumulators are done
 #pragma unroll
-        for (int j = 0; j < PIX * 16 / 512; ++j) {
+        for (int j = 0; j < NY; ++j) {
             const int s = tid + 512 * j;
-            if constexpr (BF) *reinterpret_cast<bf16x4*>(reinterpret_cast<u16*>(yl) + (s >> 4) * (2 * YLD) + (s & 15) * 4) = __builtin_convertvector(ystage[j], bf16x4);
+            if constexpr (Y16) *reinterpret_cast<f32x4*>(reinterpret_cast<u16*>(yl) + (s / CPP) * (2 * YLD) + (s % CPP) * 8) = ystage[j];
+            else if constexpr (BF) *reinterpret_cast<bf16x4*>(reinterpret_cast<u16*>(yl) + (s >> 4) * (2 * YLD) + (s & 15) * 4) = __builtin_convertvector(ystage[j], bf16x4);
             else *reinterpret_cast<f32x4*>(yl + (s >> 4) * YLD + (s & 15) * 4) = ystage[j];
         }
         __syncthreads();
         if (to + 1 < g.To) {
 #pragma unroll
-            for (int j = 0; j < PIX * 16 / 512; ++j) ystage[j] = bload(yr, yoff[j] + (u32)(to + 1) * yframe);
+            for (int j = 0; j < NY; ++j) ystage[j] = bload(yr, yoff[j] + (u32)(to + 1) * yframe);
         }
         // A fragments of this wave's 16 pixels (all of K = 64).  fp32: element m of read gq is co = 16 gq + 4 kq + m (one
         // 16x16x4 MFMA per element); bf16: read s holds co = 32 s + 8 kq .. + 7 (one 16x16x32 MFMA per read)
@@ -2367,7 +2375,7 @@ bool c4_fprop_ok(const Geom& g, const Epi& e) {
     const long long frame = (long long)g.Ti * g.Hi * g.Wi * g.Ci;
     return g.Ci == 4 && g.Co == 64 && (g.Wo == 32 || g.Wo == 16) && g.Ho % (256 / g.Wo) == 0 && !g.perm_n && g.xs0 == frame &&
            g.prec != MCG_PREC_BF16_STORE && (e.mode == 0 || e.mode == EPI_ACT) &&        // (this layer's tensors are fp32 in memory)
-           (!e.out16 || e.mode == EPI_ACT);
+           (!e.out16 || e.mode == EPI_ACT || (e.mode == 0 && g.prec == MCG_PREC_BF16));      // (a plain bf16 output: G's dc5 read backwards)
 }
 
 template <int KT, int WO>
@@ -2400,7 +2408,7 @@ bool c4_dgrad_mfma_ok(const Geom& g, const Epi& e, const float* bias, int act, i
            !e.mode && !e.out16 && !bias && act == MCG_ACT_NONE && !accumulate;
 }
 
-template <int KT, int WO, bool BF>
+template <int KT, int WO, bool BF, bool Y16 = false>
 int launch_dgrad_c4_mfma(const Geom& g, const float* y, const float* w, float* x, hipStream_t s) {
     C4DgradP p;
     p.g = g; p.y = y; p.w = w; p.x = x;
@@ -2408,11 +2416,11 @@ int launch_dgrad_c4_mfma(const Geom& g, const float* y, const float* w, float* x
     const size_t lds = (size_t)(128 * LD + KT * 48 * LD + 128 * 52) * 4 + (size_t)KT * NPX * 16;
     static std::once_flag once;
     hipError_t attr = hipSuccess;
-    std::call_once(once, [&] { attr = hipFuncSetAttribute((const void*)dgrad_c4_mfma_kernel<KT, WO, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+    std::call_once(once, [&] { attr = hipFuncSetAttribute((const void*)dgrad_c4_mfma_kernel<KT, WO, BF, Y16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
     if (attr != hipSuccess) return MCG_ERR_LAUNCH;
     // the rows two neighbouring blocks share are ADDED (two addends, order-independent): x starts from zero
     if (hipMemsetAsync(x, 0, (size_t)g.N * g.Ti * g.Hi * g.Wi * 4 * sizeof(float), s) != hipSuccess) return MCG_ERR_LAUNCH;
-    hipLaunchKernelGGL((dgrad_c4_mfma_kernel<KT, WO, BF>), dim3(g.N * (g.Ho / R)), dim3(512), lds, s, p);
+    hipLaunchKernelGGL((dgrad_c4_mfma_kernel<KT, WO, BF, Y16>), dim3(g.N * (g.Ho / R)), dim3(512), lds, s, p);
     return MCG_OK;
 }
 
@@ -2667,6 +2675,8 @@ int make_geom(const mcg_conv_geom* c, Geom& g) {
     g.perm_n = c->x_perm_n; g.xs0 = c->x_stride0; g.xs1 = c->x_stride1;
     g.taps = c->kt * 16;
     g.prec = c->precision;
+    g.y16 = 0;
+    if (g.prec == MCG_PREC_BF16_Y16) { g.prec = MCG_PREC_BF16; g.y16 = 1; }
     g.split = 0;
     if (c->ci_valid < 0 || c->ci_valid > c->Ci) return MCG_ERR_BAD_ARG;
     g.cv = c->ci_valid ? c->ci_valid : c->Ci;
@@ -2692,7 +2702,8 @@ int make_geom(const mcg_conv_geom* c, Geom& g) {
     // (buffer extents of the INPUT operands of a pass: 2-byte elements when they are bf16 in memory)
     const int esz = g.prec == MCG_PREC_BF16_STORE ? 2 : 4;
     if (esz == 2 && ((g.Ci & 7) || (g.Co & 7))) return MCG_ERR_UNSUPPORTED;       // a 16-byte slot = 8 channels
-    g.x_bytes = (u32)(x_elems * esz); g.y_bytes = (u32)(y_elems * esz); g.w_bytes = (u32)(w_elems * esz);
+    if (g.y16 && (g.Co & 7)) return MCG_ERR_UNSUPPORTED;
+    g.x_bytes = (u32)(x_elems * esz); g.y_bytes = (u32)(y_elems * (g.y16 ? 2 : esz)); g.w_bytes = (u32)(w_elems * esz);
     g.magic_To = (u32)((1ull << 32) / (unsigned)g.To) + 1u;
     g.magic_N = (u32)((1ull << 32) / (unsigned)g.N) + 1u;
     return MCG_OK;
@@ -2776,7 +2787,7 @@ int launch_dgrad(const Geom& g, const float* y, const float* w, const float* bia
 
 template <int BM, int BN, int BK, int PM = 0>
 int launch_wgrad(const Geom& g, const float* x, const float* y, float* dw, hipStream_t s) {
-    using Pol = WgradP<BM, BN, BK, PM == 2 ? 8 : 4>;
+    using Pol = WgradP<BM, BN, BK, PM == 2 ? 8 : 4, NTHREADS, false, false, (PM == 2 || PM == 3) ? 8 : 4>;     // PM 3: y bf16 in memory, x fp32
     Pol p;
     p.g = g; p.x = x; p.y = y; p.dw = dw;
     p.Mpix = g.N * g.To * g.Ho * g.Wo; p.Kf = g.taps * g.Ci;
@@ -3151,7 +3162,10 @@ int conv_dgrad_impl(const mcg_conv_geom* c, const float* y, const float* w, cons
         return finish(st);
     }
     if ((t == 0 || t == 6) && g.prec != MCG_PREC_BF16_STORE && c4_dgrad_mfma_ok(g, e, bias, act, accumulate)) {      // (computes in fp32)
-        if (g.prec == MCG_PREC_BF16) {                           // bf16 networks: the same kernel on the bf16 MFMA
+        if (g.prec == MCG_PREC_BF16 && g.y16) {                  // ... reading a y tensor that is bf16 in memory (MCG_PREC_BF16_Y16)
+            if (g.kt == 4) st = g.Wo == 32 ? launch_dgrad_c4_mfma<4, 32, true, true>(g, y, w, x, s) : launch_dgrad_c4_mfma<4, 16, true, true>(g, y, w, x, s);
+            else st = g.Wo == 32 ? launch_dgrad_c4_mfma<1, 32, true, true>(g, y, w, x, s) : launch_dgrad_c4_mfma<1, 16, true, true>(g, y, w, x, s);
+        } else if (g.prec == MCG_PREC_BF16) {                    // bf16 networks: the same kernel on the bf16 MFMA
             if (g.kt == 4) st = g.Wo == 32 ? launch_dgrad_c4_mfma<4, 32, true>(g, y, w, x, s) : launch_dgrad_c4_mfma<4, 16, true>(g, y, w, x, s);
             else st = g.Wo == 32 ? launch_dgrad_c4_mfma<1, 32, true>(g, y, w, x, s) : launch_dgrad_c4_mfma<1, 16, true>(g, y, w, x, s);
         } else {
@@ -3160,6 +3174,7 @@ int conv_dgrad_impl(const mcg_conv_geom* c, const float* y, const float* w, cons
         }
         return finish(st);
     }
+    if (g.y16) return MCG_ERR_UNSUPPORTED;                       // (a bf16 y beside fp32 w: the first-layer kernel above only)
     if (t == 6) t = 0;                                           // elsewhere the first-layer code means "the kernel written for it"
     if (t == 9) {                                                // patch-stationary, four parity classes per block (Ci = 64, 16 x 16)
         if (!dgrad_patch_ok(g) || (e.mode & ~(EPI_STATS | EPI_COL | EPI_MASKMUL))) return MCG_ERR_UNSUPPORTED;
@@ -3240,6 +3255,7 @@ extern "C" int mcg_conv_wgrad(const mcg_conv_geom* c, const float* x, const floa
     // the 3-channel clip padded to 4: patch-in-LDS kernel.  Only on request (tile code 6): measured on the MI355X it equals the
     // generic kernel on D_V's first layer at 64 clips (0.250 ms) and loses below that -- its steps run at the MFMA rate, but all
     // blocks finish together and their 64 x kt * 48 device-scope atomics each (~80 us) are not hidden behind other blocks' work
+    if (g.y16 && (t == 6 || t == 7 || t == 8 || t == 9 || t == 10)) return MCG_ERR_UNSUPPORTED;      // (the register-staged tiles only)
     if (t == 6 && c4_wgrad_ok(g)) {
         if (g.kt == 4) st = g.Wo == 32 ? launch_wgrad_c4<4, 32>(g, x, y, dw, s) : launch_wgrad_c4<4, 16>(g, x, y, dw, s);
         else st = g.Wo == 32 ? launch_wgrad_c4<1, 32>(g, x, y, dw, s) : launch_wgrad_c4<1, 16>(g, x, y, dw, s);
@@ -3263,6 +3279,10 @@ extern "C" int mcg_conv_wgrad(const mcg_conv_geom* c, const float* x, const floa
     }
     if (!t) t = (g.Co <= 64 || Kf <= 64) ? 3 : 1;
     const bool bk64 = bk ? bk == 64 : g.prec != MCG_PREC_F32;
+    if (g.y16) {                                                 // y bf16 in memory beside an fp32 x (the clip-side layers of bf16 networks)
+        if (bk64) MCG_TILES(launch_wgrad, t, 64, 3, g, x, y, dw, s); else MCG_TILES(launch_wgrad, t, 32, 3, g, x, y, dw, s);
+        return finish(st);
+    }
     MCG_DISPATCH(launch_wgrad, t, bk64, g.prec, g, x, y, dw, s);
     return finish(st);
 }

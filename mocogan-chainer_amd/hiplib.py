@@ -162,15 +162,20 @@ def _dense(t):
     return t
 
 
-PREC_F32, PREC_BF16, PREC_BF16_STORE, PREC_SPLIT = 0, 1, 2, 3
+PREC_F32, PREC_BF16, PREC_BF16_STORE, PREC_SPLIT, PREC_BF16_Y16 = 0, 1, 2, 3, 4
 # 'bf16': bf16 MFMA on fp32 tensors (rounded in the kernel); 'bf16s': bf16 MFMA on operands that are bf16 in memory;
 # 'f32x3': fp32 values as three bf16 terms (split_planes), six bf16 products per fp32 product -- fp32 results on the bf16 pipe
-PRECISIONS = {"f32": PREC_F32, "fp32": PREC_F32, "bf16": PREC_BF16, "bf16s": PREC_BF16_STORE, "f32x3": PREC_SPLIT,
-              PREC_F32: PREC_F32, PREC_BF16: PREC_BF16, PREC_BF16_STORE: PREC_BF16_STORE, PREC_SPLIT: PREC_SPLIT}
+# 'bf16y': as 'bf16' with the y-side tensor bf16 in memory (x, w fp32): the clip-side layers of bf16 networks (wgrad, dgrad)
+PRECISIONS = {"f32": PREC_F32, "fp32": PREC_F32, "bf16": PREC_BF16, "bf16s": PREC_BF16_STORE, "f32x3": PREC_SPLIT, "bf16y": PREC_BF16_Y16,
+              PREC_F32: PREC_F32, PREC_BF16: PREC_BF16, PREC_BF16_STORE: PREC_BF16_STORE, PREC_SPLIT: PREC_SPLIT,
+              PREC_BF16_Y16: PREC_BF16_Y16}
 
 
-def _pin(g, t):
-    """device pointer of an INPUT operand of a conv launch: bf16 tensors for MCG_PREC_BF16_STORE geometries"""
+def _pin(g, t, side='x'):
+    """device pointer of an INPUT operand of a conv launch (side: 'x' | 'y' | 'w'): bf16 tensors for MCG_PREC_BF16_STORE / split
+    geometries, and for the y side of MCG_PREC_BF16_Y16"""
+    if g.precision == PREC_BF16_Y16:
+        return _p(t, torch.bfloat16 if side == 'y' else torch.float32)
     return _p(t, torch.bfloat16 if g.precision in (PREC_BF16_STORE, PREC_SPLIT) else torch.float32)
 
 
@@ -471,7 +476,7 @@ def _fprop(g, x, w, bias, y):
     if y.dtype == torch.bfloat16:                     # bf16 output: the flag travels in an (otherwise empty) epilogue
         return _fprop_ex(g, x, w, bias, y, epilogue(out_bf16=True), split_ok=True)
     g = _with_override(g)
-    _check(load().mcg_conv_fprop(C.byref(g), _pin(g, x), _pin(g, _dense(w)), _p(bias), _p(_dense(y)), _stream()), "mcg_conv_fprop")
+    _check(load().mcg_conv_fprop(C.byref(g), _pin(g, x), _pin(g, _dense(w), 'w'), _p(bias), _p(_dense(y)), _stream()), "mcg_conv_fprop")
 
 
 def _dgrad(g, y, w, bias, x, act, accumulate):
@@ -479,13 +484,13 @@ def _dgrad(g, y, w, bias, x, act, accumulate):
         assert act == ACT_NONE and not accumulate
         return _dgrad_ex(g, y, w, bias, x, epilogue(out_bf16=True), split_ok=True)
     g = _with_override(g)
-    _check(load().mcg_conv_dgrad(C.byref(g), _pin(g, _dense(y)), _pin(g, _dense(w)), _p(bias), _p(x), act, int(accumulate), _stream()),
+    _check(load().mcg_conv_dgrad(C.byref(g), _pin(g, _dense(y), 'y'), _pin(g, _dense(w), 'w'), _p(bias), _p(x), act, int(accumulate), _stream()),
            "mcg_conv_dgrad")
 
 
 def _wgrad(g, x, y, dw):
     g = _with_override(g)
-    _check(load().mcg_conv_wgrad(C.byref(g), _pin(g, x), _pin(g, _dense(y)), _p(_dense(dw)), _stream()), "mcg_conv_wgrad")
+    _check(load().mcg_conv_wgrad(C.byref(g), _pin(g, x), _pin(g, _dense(y), 'y'), _p(_dense(dw)), _stream()), "mcg_conv_wgrad")
 
 
 # ---- fused epilogues (mcg_conv_epilogue) ---------------------------------------------------------
@@ -532,14 +537,14 @@ def _fprop_ex(g, x, w, bias, y, ep, split_ok=False):
     g = _with_override(g) if split_ok else _no_split(_with_override(g))
     assert bool(ep.out_bf16) == (y.dtype == torch.bfloat16)
     yp = _p(_dense(y), torch.bfloat16) if ep.out_bf16 else _p(_dense(y))
-    _check(load().mcg_conv_fprop_ex(C.byref(g), _pin(g, x), _pin(g, _dense(w)), _p(bias), yp, C.byref(ep), _stream()), "mcg_conv_fprop_ex")
+    _check(load().mcg_conv_fprop_ex(C.byref(g), _pin(g, x), _pin(g, _dense(w), 'w'), _p(bias), yp, C.byref(ep), _stream()), "mcg_conv_fprop_ex")
 
 
 def _dgrad_ex(g, y, w, bias, x, ep, split_ok=False):
     g = _with_override(g) if split_ok else _no_split(_with_override(g))
     assert bool(ep.out_bf16) == (x.dtype == torch.bfloat16)
     xp = _p(_dense(x), torch.bfloat16) if ep.out_bf16 else _p(_dense(x))
-    _check(load().mcg_conv_dgrad_ex(C.byref(g), _pin(g, _dense(y)), _pin(g, _dense(w)), _p(bias), xp, C.byref(ep), _stream()),
+    _check(load().mcg_conv_dgrad_ex(C.byref(g), _pin(g, _dense(y), 'y'), _pin(g, _dense(w), 'w'), _p(bias), xp, C.byref(ep), _stream()),
            "mcg_conv_dgrad_ex")
 
 
@@ -549,7 +554,7 @@ def dgrad_c4_mfma_covers(g):
     frame = g.Ti * g.Hi * g.Wi * g.Ci
     whole = (g.x_stride1 == frame and g.x_stride0 == (g.N // g.x_perm_n) * frame) if g.x_perm_n else g.x_stride0 == frame
     return (g.Ci == 4 and 0 < g.ci_valid <= 3 and g.Co == 64 and g.Wo in (16, 32) and g.Ho % (128 // g.Wo) == 0 and whole
-            and g.precision != PREC_BF16_STORE and _with_override(g).tile in (0, 6))
+            and g.precision not in (PREC_BF16_STORE, PREC_SPLIT) and _with_override(g).tile in (0, 6))
 
 
 def fprop_tile(g, x, w, bias):

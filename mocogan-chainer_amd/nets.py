@@ -35,6 +35,8 @@ IMG = 64                      # output size hard-coded in the reference, model/n
 #          Off by default as well: measured at bf16 batch 256 the GEMMs grow by 0.58 ms and the removed pass took 0.6 (10883 against
 #          10894 clips/s); 'f32x3' batch 32: 2693 against 2681 -- with one block per CU nothing overlaps an epilogue's reads
 OUT16 = os.environ.get('MCG_OUT16', '1') == '1'        # bf16 networks: GEMM outputs in bf16 where the schedule allows (A/B switch)
+Y16 = os.environ.get('MCG_Y16', '1') == '1'            # bf16 networks: the 64-channel neighbours of the clip (dc1's output gradient in D, the last
+                                                       # layer's input and its gradient in G) stored in bf16, 'bf16y' launches read them (A/B switch)
 FUSE = set(filter(None, os.environ.get('MCG_FUSE', 'stats,dc1').split(',')))
 
 
@@ -658,7 +660,8 @@ class DisNet(_Net):
                     else:
                         hl.colsum_acc(m * G, co, g, fp.grad('dc1/b'), self.ws)
                 # dc2..dc4 feed BatchNorm: sum_m gx == 0 exactly (see _Net.BIAS_NOTE), nothing to add
-                self._cwgrad(geom, saved['a'][l], g, fp.grad('dc%d/W' % l), xs=lambda: self._sp(saved.get('split'), l, saved['a'][l]), ys=gys,
+                wgeom = hl.with_precision(geom, 'bf16y') if (l == 1 and g.dtype == torch.bfloat16) else geom      # (a bf16 y beside the fp32 clip)
+                self._cwgrad(wgeom, saved['a'][l], g, fp.grad('dc%d/W' % l), xs=lambda: self._sp(saved.get('split'), l, saved['a'][l]), ys=gys,
                              force=g_only or l in saved.get('only', ()))
                 if l == 4 and on_late_bucket is not None:
                     self._after_wgrads(on_late_bucket)
@@ -667,10 +670,17 @@ class DisNet(_Net):
                 w = self._w('dc%d/W' % l, s16)
                 # bf16 networks: the gradient BatchNorm's backward of layer l - 1 reads is bf16 as well (see forward_groups)
                 g16 = OUT16 and l > 2 and s16 and self.sync_bn is None and hl.dgrad_tile(geom, g, w, None) < 1000
+                if l == 2 and mask1 is not None and OUT16 and Y16 and s16 and self.precision == 'bf16':
+                    # ... and so is dc1's output gradient (16x the clip's size): its readers -- dc1's weight gradient and the MFMA
+                    # input-gradient kernel of the first layer -- take a bf16 y beside the fp32 clip ('bf16y' launches).  Not when
+                    # this pass ACCUMULATES onto a frame of the clip gradient (D_I under G's loss: the VALU kernel reads fp32).
+                    g1 = self._geom(1, N)
+                    ok_gx = gx is None or (not gx_accumulate and hl.dgrad_c4_mfma_covers(hl.with_precision(gx_geom if gx_geom is not None else g1, 'bf16y')))
+                    g16 = ok_gx and g1.Co % 8 == 0 and hl.dgrad_tile(geom, g, w, None) < 1000
                 ga = torch.empty_like(saved['a'][l], dtype=torch.bfloat16 if g16 else torch.float32)
                 if l == 2 and mask1 is not None:
                     part = self._part_buf(geom, 'dgrad', 1) if param_grads else None
-                    ep = hl.epilogue(mask_in=mask1, sums=hl.SUMS_COL if param_grads else hl.SUMS_NONE, groups=1, part=part)
+                    ep = hl.epilogue(mask_in=mask1, sums=hl.SUMS_COL if param_grads else hl.SUMS_NONE, groups=1, part=part, out_bf16=g16)
                     self._cdgrad(geom, g, 'dc%d/W' % l, w, None, ga, ep=ep, must_fuse=True, ys=gys, force=g_only)
                     pending = (ep, part) if param_grads else None
                 elif l > 2 and self._fuse_bwd_sums(s16, 'dgrad', geom):
@@ -685,7 +695,10 @@ class DisNet(_Net):
             elif gx is not None:
                 def write_gx(g=g, geom=geom):
                     hl.set_tag(self.tag)
-                    hl.conv_dgrad(gx_geom if gx_geom is not None else geom, g, fp.param('dc1/W'), None, gx, accumulate=gx_accumulate)
+                    gg = gx_geom if gx_geom is not None else geom
+                    if g.dtype == torch.bfloat16:
+                        gg = hl.with_precision(gg, 'bf16y')
+                    hl.conv_dgrad(gg, g, fp.param('dc1/W'), None, gx, accumulate=gx_accumulate)
                     if defer_gx:                                 # g was allocated under the stream this pass ran on: the allocator must
                         g.record_stream(torch.cuda.current_stream())     # not hand its block out before the caller's stream is done
                 if defer_gx:
@@ -860,7 +873,12 @@ class GenNet(_Net):
                 scale = fp.param(name + '/gamma') * inv
                 ss = torch.cat((scale, fp.param(name + '/beta') - self.running[name + '/avg_mean'] * scale))
             saved['y'][l] = y
-            a = torch.empty_like(y, dtype=torch.bfloat16 if self._s16(l + 1) else torch.float32)   # the operand of layer l + 1's GEMMs
+            a16 = self._s16(l + 1)
+            if l == 4 and OUT16 and Y16 and self.precision == 'bf16' and self._s16(4) and self.sync_bn is None:
+                # the last layer's input (64 channels, 16x the clip's size) is bf16 too when its readers take a bf16 y beside the
+                # fp32 clip: the MFMA kernel of the 4-channel layers forward, 'bf16y' weight gradient backward
+                a16 = hl.dgrad_c4_mfma_covers(hl.with_precision(self._geom(5, frames, clip_order_n=n), 'bf16y'))
+            a = torch.empty_like(y, dtype=torch.bfloat16 if a16 else torch.float32)   # the operand of layer l + 1's GEMMs
             gn = self._geom(l + 1, frames) if l < 4 else None
             if gn is not None and self._split_only(('dgrad', gn), ('wgrad', gn)):      # 'f32x3': both readers take the split form
                 saved['split'][l + 1] = torch.empty(y.shape[:-1] + (4 * co,), device=dev, dtype=torch.bfloat16)
@@ -890,6 +908,8 @@ class GenNet(_Net):
                                  force=l + 1 in saved['only'])
         x = torch.empty((n, T, IMG, IMG, self.cp_out), device=dev)
         g5 = self._geom(5, frames, clip_order_n=n)
+        if saved['a'][5].dtype == torch.bfloat16:
+            g5 = hl.with_precision(g5, 'bf16y')
         if hl.dgrad_c4_mfma_covers(g5):
             # the last deconvolution (64 -> 3 channels) on the matrix pipe; bias + tanh (model/net.py:114) follow as an
             # element-wise pass over the 4-channel clip (x = tanh(1 * x + b)), which the MFMA kernel cannot carry
@@ -949,13 +969,15 @@ class GenNet(_Net):
             def gxs():
                 return self._sp(gsp, 0, g)
             g_only = gy_split is not None                        # g exists in its split form only
-            self._cwgrad(geom, g, saved['a'][l], fp.grad('dc%d/W' % l), xs=gxs, ys=lambda: self._sp(saved.get('split'), l, saved['a'][l]),
-                         force=g_only or l in saved.get('only', ()))
+            a5_16 = l == 5 and saved['a'][5].dtype == torch.bfloat16      # (the 64-channel side of the last layer stored in bf16)
+            self._cwgrad(hl.with_precision(geom, 'bf16y') if a5_16 else geom, g, saved['a'][l], fp.grad('dc%d/W' % l), xs=gxs,
+                         ys=lambda: self._sp(saved.get('split'), l, saved['a'][l]), force=g_only or l in saved.get('only', ()))
             if l == 2 and on_late_bucket is not None:
                 self._after_wgrads(on_late_bucket)
             wl = self._w('dc%d/W' % l, s16)
             g16 = (OUT16 and 2 < l < 5 and s16 and self.sync_bn is None                        # (layer 1's gradient feeds the fp32 fully-connected layer)
                    and hl.fprop_tile(geom, g, wl, None) < 1000)                            # (as DisNet.backward)
+            g16 = g16 or (a5_16 and OUT16 and self.sync_bn is None)     # ... and its gradient likewise (BatchNorm's backward reads bf16)
             ga = torch.empty_like(saved['a'][l], dtype=torch.bfloat16 if g16 else torch.float32)
             pending = None
             if self._fuse_bwd_sums(s16, 'fprop', geom):     # ga is the gradient w.r.t. relu(bn_{l-1}(y_{l-1})): the sums of that BatchNorm's backward

@@ -103,11 +103,13 @@ def _operands(hl, prec, xd, wd, gyd, kt, Ci):
         return xd.to(torch.bfloat16), w16, w16, gyd.to(torch.bfloat16)
     if prec == 'f32x3':
         return hl.split_planes(xd), hl.split_planes(wd), hl.split_planes(wd, run=16 * kt * 16 * Ci), hl.split_planes(gyd)
+    if prec == 'bf16y':                                            # the clip-side layers of bf16 networks: y bf16 beside fp32 x and w
+        return xd, wd, wd, gyd.to(torch.bfloat16)
     return xd, wd, wd, gyd
 
 
 @pytest.mark.parametrize("case", GUARD_CASES)
-@pytest.mark.parametrize("prec", ['f32', 'bf16', 'bf16s', 'f32x3'])
+@pytest.mark.parametrize("prec", ['f32', 'bf16', 'bf16s', 'f32x3', 'bf16y'])
 def test_conv_launches_stay_inside_their_tensors(hl, arena, case, prec):
     N, Ti, H, Ci, Co, kt = case
     lay = L()
@@ -118,6 +120,8 @@ def test_conv_launches_stay_inside_their_tensors(hl, arena, case, prec):
         pytest.skip("the split form needs groups of 16 channels")
     if prec == 'bf16s' and (Cip % 8 or Co % 8):
         pytest.skip("a 16-byte slot of a bf16 tensor is 8 channels")
+    if prec == 'bf16y' and Co % 8:
+        pytest.skip("a 16-byte slot of the bf16 y tensor is 8 channels")
     ops0 = _operands(hl, prec, xd0, wd0, gyd0, kt, Cip)
     ran = []
     for tile in TILES:

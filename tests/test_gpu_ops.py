@@ -1245,3 +1245,47 @@ def test_concat_label_planes(hl):
     assert torch.equal(back, want_b)
     with pytest.raises(hl.McgError):
         hl.concat_label_planes(x, c, dl, labels, torch.empty((n, T, H, H, 8), device="cuda"))      # 3 + 6 channels do not fit 8
+
+
+@pytest.mark.parametrize("case", [(2, 5, 32, 3, 64, 4), (3, 1, 32, 3, 64, 1), (2, 6, 64, 3, 64, 4), (2, 7, 16, 8, 64, 4), (2, 4, 8, 64, 160, 4)])
+def test_bf16_y_beside_fp32_clip(hl, case):
+    """MCG_PREC_BF16_Y16 ('bf16y'): the y-side tensor bf16 in memory, x and w fp32 -- the clip-side layers of bf16 networks (dc1's output
+    gradient in D, the last layer's input in G are 16x the clip).  On bf16-representable values the launch must reproduce the 'bf16'
+    launch on fp32 tensors: bit for bit in the input gradient (same MFMA sequence), to summation order in the weight gradient; both
+    match the oracle.  Geometries without such a kernel are refused."""
+    N, Ti, H, Ci, Co, kt = case
+    rng = np.random.RandomState(7000 + Ci + H)
+    lay = L()
+    x, W = _bf16_round(rng.uniform(-1, 1, (N, Ci, Ti, H, H))), _bf16_round(rng.randn(Co, Ci, kt, 4, 4) * 0.1)
+    gy = _bf16_round(rng.randn(N, Co, Ti - kt + 1, H // 2, H // 2))
+    gx_ref, gW_ref, _ = F.conv3d_bwd(x, W, gy, (1, 2, 2), (0, 1, 1))
+    xd, wd, gyd = lay.act_to_dev(dev(x)), lay.conv_w_to_dev(dev(W)), lay.act_to_dev(dev(gy))
+    gy16 = gyd.to(torch.bfloat16)
+    Cip = xd.shape[-1]
+    cv = Ci if Cip != Ci else 0
+    g1, g2 = hl.make_geom(N, Ti, H, H, Cip, Co, kt, precision='bf16', ci_valid=cv), hl.make_geom(N, Ti, H, H, Cip, Co, kt, precision='bf16y', ci_valid=cv)
+    for tile in (0, 3, 103, 201):
+        g1.tile = g2.tile = tile
+        dw1, dw2 = torch.zeros_like(wd), torch.zeros_like(wd)
+        hl.conv_wgrad(g1, xd, gyd, dw1)
+        hl.conv_wgrad(g2, xd, gy16, dw2)
+        assert rel_l2(lay.conv_w_from_dev(dw2, Ci, 3), gW_ref) < BWD_TOL, tile
+        assert rel_l2(dw2, dw1.cpu().double().numpy()) < 1e-6, tile
+    g1.tile = g2.tile = 0
+    if hl.dgrad_c4_mfma_covers(g2):
+        gx1, gx2 = torch.full_like(xd, 7.0), torch.full_like(xd, 7.0)
+        hl.conv_dgrad(g1, gyd, wd, None, gx1)
+        hl.conv_dgrad(g2, gy16, wd, None, gx2)
+        assert torch.equal(gx1, gx2) and rel_l2(lay.act_from_dev(gx2, Ci), gx_ref) < BWD_TOL
+    else:
+        with pytest.raises(hl.McgError):                               # (no kernel reads a bf16 y beside fp32 filters there)
+            hl.conv_dgrad(g2, gy16, wd, None, torch.zeros_like(xd))
+    with pytest.raises(hl.McgError):
+        hl.conv_wgrad(g2, xd, gyd, torch.zeros_like(wd))                # an fp32 y where the geometry promises bf16
+    # a plain bf16 output of the 4-channel layers' forward kernel (G's last layer read backwards) equals the rounded fp32 output
+    if Cip == 4 and Co == 64:
+        y32 = torch.empty((N, g1.To, g1.Ho, g1.Wo, Co), device="cuda")
+        hl.conv_fprop(g1, xd, wd, None, y32)
+        y16 = torch.empty_like(y32, dtype=torch.bfloat16)
+        hl.conv_fprop(g1, xd, wd, None, y16)
+        assert torch.equal(y16, y32.to(torch.bfloat16))
