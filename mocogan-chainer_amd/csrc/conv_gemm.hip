@@ -1066,6 +1066,20 @@ template <int OFF0, int OFF1>
 __device__ __forceinline__ void tr16_issue(s16x4& lo, s16x4& hi, u32 addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4" : "=&v"(lo), "=&v"(hi) : "v"(addr), "n"(OFF0), "n"(OFF1));
 }
+// The 16-byte fragment read of a K-contiguous tile as inline asm too.  Round 4: with the transposing reads invisible to hipcc and
+// the ds_read_b128 of the OTHER operand visible, the compiler's own "s_waitcnt lgkmcnt(n)" in front of the MFMAs counted only its
+// reads -- and so waited for (nearly) everything in flight, including the chunk issued a moment ago: the fragments of chunk kc + 1
+// never overlapped the MFMAs of chunk kc in any kernel that mixes the two kinds (dgrad, the patch kernel; found in their .s).  With
+// EVERY fragment read in asm the completion count is ours alone: frag_wait<N> = all but the N youngest LDS reads have landed.
+template <int OFF>
+__device__ __forceinline__ void ds128_issue(bf16x8& d, u32 addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(d) : "v"(addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void ds128_wait(bf16x8& d) {
+    static_assert(N >= 0 && N < 16, "lgkmcnt is a 4-bit field");
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(d) : "n"(N));
+}
 template <int N>
 __device__ __forceinline__ bf16x8 tr16_wait(s16x4& lo, s16x4& hi) {
     static_assert(N >= 0 && N < 16, "lgkmcnt is a 4-bit field");
@@ -1559,7 +1573,9 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
         // operand fragments two deep: the reads of k chunk kc + 1 are in flight under the MFMAs of chunk kc
         typedef typename std::conditional<F32, f32x4, bf16x8>::type frag_t;
         constexpr bool TRA = !P::A_KC && !F32, TRB = !P::B_KC && !F32;          // operands read with the transposing read (inline asm)
-        constexpr int NTR = 2 * ((TRA ? TM : 0) + (TRB ? TN : 0));             // asm reads per k chunk
+        // bf16 tiles: EVERY fragment read is inline asm (see ds128_issue) and counted here; NRD = LDS reads per k chunk, in issue order
+        // A (TM rows x 1 or 2 reads) then B.  (fp32 tiles: plain loads, counted by the compiler.)
+        constexpr int NRD = F32 ? 0 : (TRA ? 2 * TM : TM) + (TRB ? 2 * TN : TN);
         frag_t fa[2][TM], fb[2][TN];
         s16x4 alo[2][TM], ahi[2][TM], blo[2][TN], bhi[2][TN];
         frag_t sfa[SPLIT ? 3 : 1][TM], sfb[SPLIT ? 3 : 1][TN];
@@ -1569,8 +1585,13 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
             constexpr int kc = decltype(kc_)::value, slot = kc & 1;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                if constexpr (P::A_KC) fa[slot][i] = *reinterpret_cast<const frag_t*>(sbase + a_row + xo[kc] + i * 4096);
-                else if constexpr (F32) {
+                if constexpr (P::A_KC && F32) fa[slot][i] = *reinterpret_cast<const frag_t*>(sbase + a_row + xo[kc] + i * 4096);
+                else if constexpr (P::A_KC) {
+                    if (i == 0) ds128_issue<0>(fa[slot][0], sb32 + a_row + xo[kc]);
+                    else if (i == 1) ds128_issue<4096>(fa[slot][i], sb32 + a_row + xo[kc]);
+                    else if (i == 2) ds128_issue<8192>(fa[slot][i], sb32 + a_row + xo[kc]);
+                    else ds128_issue<12288>(fa[slot][i], sb32 + a_row + xo[kc]);
+                } else if constexpr (F32) {
                     const float* b = reinterpret_cast<const float*>(sbase) + (kc * 8 + 4 * lh) * BM + wm0 + i * 32 + li;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) fa[slot][i][j] = b[j * BM];
@@ -1578,8 +1599,13 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
             }
 #pragma unroll
             for (int i = 0; i < TN; ++i) {
-                if constexpr (P::B_KC) fb[slot][i] = *reinterpret_cast<const frag_t*>(sbase + b_row + xo[kc] + i * 4096);
-                else if constexpr (F32) {
+                if constexpr (P::B_KC && F32) fb[slot][i] = *reinterpret_cast<const frag_t*>(sbase + b_row + xo[kc] + i * 4096);
+                else if constexpr (P::B_KC) {
+                    if (i == 0) ds128_issue<0>(fb[slot][0], sb32 + b_row + xo[kc]);
+                    else if (i == 1) ds128_issue<4096>(fb[slot][i], sb32 + b_row + xo[kc]);
+                    else if (i == 2) ds128_issue<8192>(fb[slot][i], sb32 + b_row + xo[kc]);
+                    else ds128_issue<12288>(fb[slot][i], sb32 + b_row + xo[kc]);
+                } else if constexpr (F32) {
                     const float* b = reinterpret_cast<const float*>(sbase + A_BYTES) + (kc * 8 + 4 * lh) * BN + wn0 + i * 32 + li;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) fb[slot][i][j] = b[j * BN];
@@ -1593,25 +1619,35 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
                 constexpr int pl = decltype(pl_)::value;
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    if constexpr (P::A_KC) sfa[pl][i] = *reinterpret_cast<const frag_t*>(sbase + a_row + xo[pl] + i * 4096);
-                    else tr16_issue<pl * 16 * (BM * 2), pl * 16 * (BM * 2) + 4 * (BM * 2)>(salo[pl][i], sahi[pl][i], sb32 + ta[i]);
+                    if constexpr (P::A_KC) {
+                        if (i == 0) ds128_issue<0>(sfa[pl][0], sb32 + a_row + xo[pl]);
+                        else if (i == 1) ds128_issue<4096>(sfa[pl][i], sb32 + a_row + xo[pl]);
+                        else if (i == 2) ds128_issue<8192>(sfa[pl][i], sb32 + a_row + xo[pl]);
+                        else ds128_issue<12288>(sfa[pl][i], sb32 + a_row + xo[pl]);
+                    } else tr16_issue<pl * 16 * (BM * 2), pl * 16 * (BM * 2) + 4 * (BM * 2)>(salo[pl][i], sahi[pl][i], sb32 + ta[i]);
                 }
 #pragma unroll
                 for (int i = 0; i < TN; ++i) {
-                    if constexpr (P::B_KC) sfb[pl][i] = *reinterpret_cast<const frag_t*>(sbase + b_row + xo[pl] + i * 4096);
-                    else tr16_issue<pl * 16 * (BN * 2), pl * 16 * (BN * 2) + 4 * (BN * 2)>(sblo[pl][i], sbhi[pl][i], sb32 + tb[i]);
+                    if constexpr (P::B_KC) {
+                        if (i == 0) ds128_issue<0>(sfb[pl][0], sb32 + b_row + xo[pl]);
+                        else if (i == 1) ds128_issue<4096>(sfb[pl][i], sb32 + b_row + xo[pl]);
+                        else if (i == 2) ds128_issue<8192>(sfb[pl][i], sb32 + b_row + xo[pl]);
+                        else ds128_issue<12288>(sfb[pl][i], sb32 + b_row + xo[pl]);
+                    } else tr16_issue<pl * 16 * (BN * 2), pl * 16 * (BN * 2) + 4 * (BN * 2)>(sblo[pl][i], sbhi[pl][i], sb32 + tb[i]);
                 }
             });
-            static_for<0, 3>([&](auto pl_) {                     // (asm reads: completion counted by hand; plane pl has 2 - pl planes behind it)
+            static_for<0, 3>([&](auto pl_) {                     // (completion counted by hand; plane pl has 2 - pl planes of NRD reads behind it)
                 constexpr int pl = decltype(pl_)::value;
-                constexpr int PER = 2 * ((TRA ? TM : 0) + (TRB ? TN : 0));
-                if constexpr (TRA) {
+                constexpr int BEHIND = (2 - pl) * NRD < 15 ? (2 - pl) * NRD : 15;
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) sfa[pl][i] = tr16_wait<((2 - pl) * PER < 15 ? (2 - pl) * PER : 15)>(salo[pl][i], sahi[pl][i]);
+                for (int i = 0; i < TM; ++i) {
+                    if constexpr (TRA) sfa[pl][i] = tr16_wait<BEHIND>(salo[pl][i], sahi[pl][i]);
+                    else ds128_wait<BEHIND>(sfa[pl][i]);
                 }
-                if constexpr (TRB) {
 #pragma unroll
-                    for (int i = 0; i < TN; ++i) sfb[pl][i] = tr16_wait<((2 - pl) * PER < 15 ? (2 - pl) * PER : 15)>(sblo[pl][i], sbhi[pl][i]);
+                for (int i = 0; i < TN; ++i) {
+                    if constexpr (TRB) sfb[pl][i] = tr16_wait<BEHIND>(sblo[pl][i], sbhi[pl][i]);
+                    else ds128_wait<BEHIND>(sfb[pl][i]);
                 }
             });
             static_for<0, 6>([&](auto c_) {
@@ -1632,14 +1668,18 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
             if constexpr (kc + 1 < 4) frags(std::integral_constant<int, kc + 1>{});
             issue_part(nbuf, kc);
             __builtin_amdgcn_sched_barrier(0);                   // (keeps this quarter of the loads in front of this MFMA group)
-            constexpr int YOUNGER = kc + 1 < 4 ? NTR : 0;         // asm reads of chunk kc + 1, issued after the ones used now
-            if constexpr (TRA) {
+            constexpr int YOUNGER = kc + 1 < 4 ? (NRD < 15 ? NRD : 15) : 0;     // the reads of chunk kc + 1, issued after the ones used now
+            if constexpr (!F32) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[kc & 1][i] = tr16_wait<YOUNGER>(alo[kc & 1][i], ahi[kc & 1][i]);
-            }
-            if constexpr (TRB) {
+                for (int i = 0; i < TM; ++i) {
+                    if constexpr (TRA) fa[kc & 1][i] = tr16_wait<YOUNGER>(alo[kc & 1][i], ahi[kc & 1][i]);
+                    else ds128_wait<YOUNGER>(fa[kc & 1][i]);
+                }
 #pragma unroll
-                for (int i = 0; i < TN; ++i) fb[kc & 1][i] = tr16_wait<YOUNGER>(blo[kc & 1][i], bhi[kc & 1][i]);
+                for (int i = 0; i < TN; ++i) {
+                    if constexpr (TRB) fb[kc & 1][i] = tr16_wait<YOUNGER>(blo[kc & 1][i], bhi[kc & 1][i]);
+                    else ds128_wait<YOUNGER>(fb[kc & 1][i]);
+                }
             }
             if constexpr (F32) {
 #pragma unroll
@@ -1747,6 +1787,9 @@ __global__ __launch_bounds__(NT2) void dgrad_patch_kernel(DgPatchPol p) {
         if (SPLIT && ((cp ^ kx) >> 1) == 3) poff[j] = OOB;                   // the zero plane: not fetched, never multiplied
     }
     auto issue_patch = [&](int s, int j0, int j1) {
+#ifdef MCG_PP_NOLOADS            // (timing ablations MCG_PP_*: tools/ab_patch.sh; results are garbage)
+        return;
+#endif
         const int a = a_lo + s / CC, cc = s - (s / CC) * CC;
         const u32 so = (u32)(((n * g.To + (t - a)) * g.Ho * g.Wo * g.Co + cc * 64) * 2);
         unsigned char* dst = patch + (s & 1) * PATCH + wave * 1024;
@@ -1756,17 +1799,18 @@ __global__ __launch_bounds__(NT2) void dgrad_patch_kernel(DgPatchPol p) {
     };
     // ---- filter slices: thread = (co row tid / 8, chunk tid % 8) of a [64 co][64 ci] slice
     const u32 boff = (SPLIT && (tid >> 7) == 3) ? OOB : (u32)(((tid >> 3) * g.taps * g.Ci + (((tid & 7) ^ sw_cols(tid >> 3, 8)) << 3)) * 2);
-    auto issue_b = [&](int G) {                                  // stage G = 8 s + q, q = (pw, bh, bw): the two slices ph = 0, 1
+    auto issue_b1 = [&](int G, int ph) {                         // stage G = 8 s + q, q = (pw, bh, bw): its slice of class row ph
+#ifdef MCG_PP_NOLOADS
+        return;
+#endif
         const int s = G >> 3, q = G & 7, pw = q >> 2, bh = (q >> 1) & 1, bw = q & 1;
         const int a = a_lo + s / CC, cc = s - (s / CC) * CC;
         unsigned char* dst = bst + (G & 3) * BSTG + wave * 1024;
-#pragma unroll
-        for (int ph = 0; ph < 2; ++ph) {
-            const int tap = a * 16 + ((1 - ph) + 2 * bh) * 4 + (1 - pw) + 2 * bw;
-            const u32 so = (u32)(((cc * 64 * g.taps + tap) * g.Ci) * 2);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, MCG_LDSP(dst + ph * 8192), 16, boff, so, 0, 0);
-        }
+        const int tap = a * 16 + ((1 - ph) + 2 * bh) * 4 + (1 - pw) + 2 * bw;
+        const u32 so = (u32)(((cc * 64 * g.taps + tap) * g.Ci) * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, MCG_LDSP(dst + ph * 8192), 16, boff, so, 0, 0);
     };
+    auto issue_b = [&](int G) { issue_b1(G, 0); issue_b1(G, 1); };     // (the two slices ph = 0, 1 of a stage)
 
     // Waves: two sets of four.  Set cg = wave >> 2 computes the classes with ph = cg (q = 2 cg + pw), its wave wr = wave & 3 the rows
     // 64 wr .. 64 wr + 63 of the frame: a wave owns 64 x 64 outputs of each of its two classes -- two A fragments feed two B
@@ -1807,16 +1851,33 @@ __global__ __launch_bounds__(NT2) void dgrad_patch_kernel(DgPatchPol p) {
             constexpr int q = decltype(q_)::value, pw = q >> 2, bh = (q >> 1) & 1, bw = q & 1;
             const int G = 8 * s + q;
             wait_vmcnt<4>();
+#ifndef MCG_PP_NOBAR
             __builtin_amdgcn_s_barrier();
+#endif
+            // This stage's loads -- one piece of the next patch (stages 0..5), the two filter pieces of stage G + 3 -- are NOT issued
+            // here in a burst: every LDS-DMA instruction holds its wave's issue for 60-180 cycles, and behind the barrier all eight
+            // waves would sit in that burst together with the matrix pipes idle.  They go between the MFMA groups below (same order
+            // of issue, so the vmcnt arithmetic is unchanged): the MFMAs of a group run while the wave issues the next load.
+            const int Gn = G + 3 < total ? G + 3 : G;             // (past the end: a harmless reload into the slot read one stage ago)
+#ifdef MCG_PATCH_BURST       // (timing A/B: round 3's placement)
             if (q < 6 && s + 1 < S) issue_patch(s + 1, q, q + 1);
-            issue_b(G + 3 < total ? G + 3 : G);                   // (past the end: a harmless reload into the slot read one stage ago)
+            issue_b(Gn);
+#endif
+            auto spread = [&](int part) {
+#ifndef MCG_PATCH_BURST
+                if (part == 0) { if (q < 6 && s + 1 < S) issue_patch(s + 1, q, q + 1); }
+                else if (part == 1) issue_b1(Gn, 0);
+                else if (part == 2) issue_b1(Gn, 1);
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+            };
             const unsigned char* bb = bst + (G & 3) * BSTG + cg * 8192;       // this set's slice (ph = cg)
             int p0 = prow[0], p1 = prow[1];
             asm volatile("" : "+v"(p0), "+v"(p1));               // (keeps the operand addresses of a super-step from being hoisted out of
                                                                  //  the loop: they would spill -- the accumulators take 128 registers)
             const int shift = (cg - bh) * PW + (pw - bw);         // ph = cg
             const int pr0 = p0 + shift, pr1 = p1 + shift;
-            const unsigned char* ap0 = pb + pr0 * 128; const unsigned char* ap1 = pb + pr1 * 128;
+            const u32 ap0 = lds_addr(pb) + (u32)(pr0 * 128), ap1 = lds_addr(pb) + (u32)(pr1 * 128);
             const int sw0 = ((pcol + (pw - bw)) >> 1) & 7, sw1 = sw0;        // (column-based key: see the patch loads)
             // (the filter fragments through the asm form of the transposing read: see tr16_issue; two k chunks in flight)
             const u32 bb32 = lds_addr(bb);
@@ -1825,15 +1886,18 @@ __global__ __launch_bounds__(NT2) void dgrad_patch_kernel(DgPatchPol p) {
                 bf16x8 sa[3][2], sb[3][2];
                 static_for<0, 3>([&](auto pl_) {
                     constexpr int pl = decltype(pl_)::value;
-                    sa[pl][0] = *reinterpret_cast<const bf16x8*>(ap0 + (((2 * pl + lh) ^ sw0) << 4));
-                    sa[pl][1] = *reinterpret_cast<const bf16x8*>(ap1 + (((2 * pl + lh) ^ sw1) << 4));
+                    // (every fragment read is asm and counted here: see ds128_issue; 6 reads per plane)
+                    ds128_issue<0>(sa[pl][0], ap0 + (u32)(((2 * pl + lh) ^ sw0) << 4));
+                    ds128_issue<0>(sa[pl][1], ap1 + (u32)(((2 * pl + lh) ^ sw1) << 4));
                     tr16_issue<pl * 16 * 128, pl * 16 * 128 + 4 * 128>(slo[pl][0], shi[pl][0], bb32 + tb[0]);
                     tr16_issue<pl * 16 * 128, pl * 16 * 128 + 4 * 128>(slo[pl][1], shi[pl][1], bb32 + tb[1]);
                 });
                 static_for<0, 3>([&](auto pl_) {
                     constexpr int pl = decltype(pl_)::value;
-                    sb[pl][0] = tr16_wait<(2 - pl) * 4>(slo[pl][0], shi[pl][0]);
-                    sb[pl][1] = tr16_wait<(2 - pl) * 4>(slo[pl][1], shi[pl][1]);
+                    ds128_wait<(2 - pl) * 6>(sa[pl][0]);
+                    ds128_wait<(2 - pl) * 6>(sa[pl][1]);
+                    sb[pl][0] = tr16_wait<(2 - pl) * 6>(slo[pl][0], shi[pl][0]);
+                    sb[pl][1] = tr16_wait<(2 - pl) * 6>(slo[pl][1], shi[pl][1]);
                 });
                 static_for<0, 6>([&](auto c_) {
                     constexpr int c = decltype(c_)::value;
@@ -1844,32 +1908,56 @@ __global__ __launch_bounds__(NT2) void dgrad_patch_kernel(DgPatchPol p) {
 #pragma unroll
                         for (int i = 0; i < 2; ++i)
                             acc[pw][a][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[pa][a], sb[pb_][i], acc[pw][a][i], 0, 0, 0);
+                    if constexpr (c < 3) spread(c);
                 });
                 return;
             }
+            // Fragments two chunks deep, EVERY read in asm and counted here (see ds128_issue): chunk kc + 1's six reads (2 A, 4 B) are
+            // issued before the MFMAs of chunk kc and stay in flight under them.
             s16x4 blo[2][2], bhi[2][2];
-            tr16_issue<0, 4 * 128>(blo[0][0], bhi[0][0], bb32 + tb[0]);
-            tr16_issue<0, 4 * 128>(blo[0][1], bhi[0][1], bb32 + tb[1]);
+            bf16x8 fa[2][2];
+            auto chunk = [&](auto kc_) {
+                constexpr int kc = decltype(kc_)::value, sl = kc & 1;
+                ds128_issue<0>(fa[sl][0], ap0 + (u32)(((2 * kc + lh) ^ sw0) << 4));
+                ds128_issue<0>(fa[sl][1], ap1 + (u32)(((2 * kc + lh) ^ sw1) << 4));
+                tr16_issue<kc * 16 * 128, kc * 16 * 128 + 4 * 128>(blo[sl][0], bhi[sl][0], bb32 + tb[0]);
+                tr16_issue<kc * 16 * 128, kc * 16 * 128 + 4 * 128>(blo[sl][1], bhi[sl][1], bb32 + tb[1]);
+            };
+            chunk(std::integral_constant<int, 0>{});
             static_for<0, 4>([&](auto kc_) {
                 constexpr int kc = decltype(kc_)::value;
-                bf16x8 fa[2], fb[2];
-                fa[0] = *reinterpret_cast<const bf16x8*>(ap0 + (((2 * kc + lh) ^ sw0) << 4));
-                fa[1] = *reinterpret_cast<const bf16x8*>(ap1 + (((2 * kc + lh) ^ sw1) << 4));
-                if constexpr (kc + 1 < 4) {
-                    tr16_issue<(kc + 1) * 16 * 128, (kc + 1) * 16 * 128 + 4 * 128>(blo[(kc + 1) & 1][0], bhi[(kc + 1) & 1][0], bb32 + tb[0]);
-                    tr16_issue<(kc + 1) * 16 * 128, (kc + 1) * 16 * 128 + 4 * 128>(blo[(kc + 1) & 1][1], bhi[(kc + 1) & 1][1], bb32 + tb[1]);
-                }
-                fb[0] = tr16_wait<(kc + 1 < 4 ? 4 : 0)>(blo[kc & 1][0], bhi[kc & 1][0]);
-                fb[1] = tr16_wait<(kc + 1 < 4 ? 4 : 0)>(blo[kc & 1][1], bhi[kc & 1][1]);
+                if constexpr (kc + 1 < 4) chunk(std::integral_constant<int, kc + 1>{});
+                constexpr int YOUNGER = kc + 1 < 4 ? 6 : 0;
+                bf16x8 fb[2];
+                ds128_wait<YOUNGER>(fa[kc & 1][0]);
+                ds128_wait<YOUNGER>(fa[kc & 1][1]);
+                fb[0] = tr16_wait<YOUNGER>(blo[kc & 1][0], bhi[kc & 1][0]);
+                fb[1] = tr16_wait<YOUNGER>(blo[kc & 1][1], bhi[kc & 1][1]);
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
-                        acc[pw][a][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[i], acc[pw][a][i], 0, 0, 0);
+                        acc[pw][a][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kc & 1][a], fb[i], acc[pw][a][i], 0, 0, 0);
+                if constexpr (kc < 3) spread(kc);
             });
         });
     }
     wait_vmcnt<0>();
+#ifdef MCG_PP_NOEPI
+    {
+        float keep = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) keep += acc[c][a][b][r];
+        if (keep == 123.456f) p.x[0] = keep;
+        return;
+    }
+#endif
     // ---- epilogue: the two sets store their class (ph = cg, pw) side by side through the row-wise store
     static_for<0, 2>([&](auto pw_) {
         constexpr int pw = decltype(pw_)::value;
