@@ -12,7 +12,10 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int NT = 256;
-constexpr int MAX_PART = 512;        // max partial-reduction blocks (workspace sizing)
+#ifndef MCG_MAX_PART
+#define MCG_MAX_PART 512
+#endif
+constexpr int MAX_PART = MCG_MAX_PART;        // max partial-reduction blocks (workspace sizing)
 constexpr float LRELU_SLOPE = 0.2f;  // model/net.py:149-155,190-196
 
 int launch_status() { return hipGetLastError() == hipSuccess ? MCG_OK : MCG_ERR_LAUNCH; }
@@ -501,9 +504,12 @@ __global__ __launch_bounds__(NT) void bn_act_bwd_apply8_kernel(long long n8, int
     }
 }
 
+#ifndef MCG_EW_GRID
+#define MCG_EW_GRID 2048
+#endif
 int ew_grid(long long n4) {
     long long b = (n4 + NT - 1) / NT;
-    if (b > 2048) b = 2048;
+    if (b > MCG_EW_GRID) b = MCG_EW_GRID;
     if (b < 1) b = 1;
     return (int)b;
 }

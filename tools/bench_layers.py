@@ -71,7 +71,7 @@ def main():
         if prec == 'f32x3' and (Ci % 16 or Co % 16):
             prec = 'f32'                                    # the 4-channel layers of an f32x3 network run the fp32 kernels
         if prec == 'bf16s' and (Ci % 8 or Co % 8):
-            prec = 'bf16'                                   # ... of a bf16 network: fp32 tensors, rounded in the kernel
+            prec = 'bf16y' if Co % 8 == 0 else 'bf16'       # ... of a bf16 network: the clip fp32, its 64-channel neighbour bf16 (round 4)
         g = hl.make_geom(N, T, H, H, Ci, Co, kt, precision=prec, ci_valid=ci_real)
         x = torch.randn((N, T, H, H, Ci), device='cuda')
         y = torch.randn((N, g.To, g.Ho, g.Wo, Co), device='cuda')
@@ -83,6 +83,8 @@ def main():
         elif prec == 'f32x3':                               # fp32 values as three bf16 terms (the split of the operands is not timed)
             xi, yi, wi = hl.split_planes(x), hl.split_planes(y), hl.split_planes(w)
             wd = hl.split_planes(w, run=16 * kt * 16 * Ci)      # the filter as dgrad reads it: planes of 16 filters
+        elif prec == 'bf16y':                               # y bf16 in memory beside the fp32 clip and filter (wgrad, dgrad read it)
+            xi, yi, wi = x, y.to(torch.bfloat16), w
         else:
             xi, yi, wi = x, y, w
         passes = [('fprop', lambda: hl.conv_fprop(g, xi, wi, None, y)),

@@ -70,7 +70,7 @@ def main():
             if ' N=' in name and name.split('.')[1].split()[0] == kind and ('N=%d T=%d H=%d Ci=%d Co=%d' % (k[1], k[2], k[3], k[5], k[6])) in name:
                 return ms
         return 0.0
-    precs = (hl.PRECISIONS['bf16'], hl.PRECISIONS['bf16s']) if args.dtype == 'bf16' else (hl.PRECISIONS['f32'], hl.PRECISIONS['f32x3']) if args.dtype == 'f32x3' else (hl.PRECISIONS[args.dtype],)   # bf16 networks: both operand forms
+    precs = (hl.PRECISIONS['bf16'], hl.PRECISIONS['bf16s'], hl.PRECISIONS['bf16y']) if args.dtype == 'bf16' else (hl.PRECISIONS['f32'], hl.PRECISIONS['f32x3']) if args.dtype == 'f32x3' else (hl.PRECISIONS[args.dtype],)   # bf16 networks: both operand forms
     keys = sorted([k for k in cache if k[9] in precs and k[1] in (args.batch, 2 * args.batch, 16 * args.batch)], key=key_cost, reverse=True)
     base = measure()
     print('baseline %.3f ms/iteration, %d geometries' % (base, len(keys)), flush=True)
