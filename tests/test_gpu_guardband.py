@@ -77,6 +77,7 @@ GUARD_CASES = [
     (2, 9, 8, 16, 20, 4),       # Co not a power of two
     (2, 7, 32, 64, 128, 4),     # D_V dc2's geometry: the patch-stationary input gradient
     (5, 1, 8, 128, 512, 1),     # four N tiles
+    (3, 5, 16, 128, 128, 4),    # 128 channels on both sides, ragged 256-row tiles, 3-D
 ]
 TILES = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 101, 203, 1103, 2203, 1007, 2010]
 _refs = {}
