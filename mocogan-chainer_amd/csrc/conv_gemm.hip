@@ -1850,7 +1850,9 @@ __global__ __launch_bounds__(NT2) void dgrad_patch_kernel(DgPatchPol p) {
         static_for<0, 8>([&](auto q_) {
             constexpr int q = decltype(q_)::value, pw = q >> 2, bh = (q >> 1) & 1, bw = q & 1;
             const int G = 8 * s + q;
+#ifndef MCG_PP_NOVMWAIT          // (ablation: loads issued but never waited for -- what a longer look-ahead could gain at most)
             wait_vmcnt<4>();
+#endif
 #ifndef MCG_PP_NOBAR
             __builtin_amdgcn_s_barrier();
 #endif
