@@ -2221,7 +2221,12 @@ __global__ __launch_bounds__(512) void dgrad_c4_mfma_kernel(C4DgradP p) {
     const Geom& g = p.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hblocks = g.Ho / R;
-    const int n = blockIdx.x / hblocks, h0 = (blockIdx.x - n * hblocks) * R;
+    // PERSISTENT over tiles (round 4): a block walks the tiles blockIdx.x, + gridDim.x, ... of (batch item n, R output rows from h0).
+    // The weights, the gather plan and the cleared accumulator ring are per BLOCK, and the y tile of the next step is prefetched across
+    // tile boundaries.  With one tile per block a 2-D layer (G's last layer forward: To = 1) was one step of work behind ~5 us of
+    // serial prologue per block -- 32768 of them at 256 clips.
+    const int ntiles = g.N * hblocks;
+    int n = 0, h0 = 0;
     const __amdgpu_buffer_rsrc_t yr = make_srd(p.y, g.y_bytes);
 
     // ---- weights -> LDS, transposed to [column][co]
@@ -2248,16 +2253,25 @@ __global__ __launch_bounds__(512) void dgrad_c4_mfma_kernel(C4DgradP p) {
     }
     // y tile loader: thread -> (pixel, 16-byte chunk); a pixel's 64 channels are CPP chunks of YE elements
     constexpr int YE = Y16 ? 8 : 4, CPP = 64 / YE, NY = PIX * CPP / 512, YB = 16 / YE;
-    u32 yoff[NY];
+    u32 yoff[NY];                                    // the lane's part of the address; the tile's and the frame's parts are wave-uniform
 #pragma unroll
     for (int j = 0; j < NY; ++j) {
         const int s = tid + 512 * j, pix = s / CPP, c4 = s % CPP, hol = pix / WO, wo = pix - hol * WO;
-        yoff[j] = (u32)((((long long)n * g.To * g.Ho + h0 + hol) * WO + wo) * 64 + c4 * YE) * (u32)YB;   // + to * Ho * WO * 64 * YB per frame
+        yoff[j] = (u32)((hol * WO + wo) * 64 + c4 * YE) * (u32)YB;
     }
     const u32 yframe = (u32)g.Ho * WO * 64u * (u32)YB;
+    auto tile_base = [&](int tl) -> u32 {            // byte offset of y[n][0][h0][0][0] of tile tl
+        const int tn = tl / hblocks, th0 = (tl - tn * hblocks) * R;
+        return (u32)(((long long)tn * g.To * g.Ho + th0) * WO * 64) * (u32)YB;
+    };
     f32x4 ystage[NY];
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;                      // (block-uniform; the grid never exceeds the tile count)
+    {
+        const u32 tb = tile_base(tile);
 #pragma unroll
-    for (int j = 0; j < NY; ++j) ystage[j] = bload(yr, yoff[j]);
+        for (int j = 0; j < NY; ++j) ystage[j] = bload_s(yr, yoff[j], tb);
+    }
 
     const int li = lane & 15, kq = lane >> 4;
     auto retire = [&](int t) {              // frame t has all its temporal taps: write its window rows, clear the accumulator
@@ -2276,6 +2290,9 @@ __global__ __launch_bounds__(512) void dgrad_c4_mfma_kernel(C4DgradP p) {
         }
     };
 
+    for (; tile < ntiles; tile += gridDim.x) {
+    n = tile / hblocks; h0 = (tile - n * hblocks) * R;
+    const u32 tbase = tile_base(tile);
     for (int to = 0; to < g.To; ++to) {
         __syncthreads();                                          // previous step's readers of yl / accumulators are done
 #pragma unroll
@@ -2286,9 +2303,14 @@ __global__ __launch_bounds__(512) void dgrad_c4_mfma_kernel(C4DgradP p) {
             else *reinterpret_cast<f32x4*>(yl + (s >> 4) * YLD + (s & 15) * 4) = ystage[j];
         }
         __syncthreads();
-        if (to + 1 < g.To) {
+        if (to + 1 < g.To) {                                      // the next frame of this tile ...
+            const u32 so = tbase + (u32)(to + 1) * yframe;
 #pragma unroll
-            for (int j = 0; j < NY; ++j) ystage[j] = bload(yr, yoff[j] + (u32)(to + 1) * yframe);
+            for (int j = 0; j < NY; ++j) ystage[j] = bload_s(yr, yoff[j], so);
+        } else if (tile + (int)gridDim.x < ntiles) {              // ... or the first frame of the block's next tile
+            const u32 so = tile_base(tile + gridDim.x);
+#pragma unroll
+            for (int j = 0; j < NY; ++j) ystage[j] = bload_s(yr, yoff[j], so);
         }
         // A fragments of this wave's 16 pixels (all of K = 64).  fp32: element m of read gq is co = 16 gq + 4 kq + m (one
         // 16x16x4 MFMA per element); bf16: read s holds co = 32 s + 8 kq .. + 7 (one 16x16x32 MFMA per read)
@@ -2345,7 +2367,8 @@ __global__ __launch_bounds__(512) void dgrad_c4_mfma_kernel(C4DgradP p) {
         retire(to);
     }
     __syncthreads();
-    for (int t = g.To; t < g.Ti; ++t) retire(t);                  // the last kt - 1 frames
+    for (int t = g.To; t < g.Ti; ++t) retire(t);                  // the last kt - 1 frames (every slot of the ring is clear again)
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2498,6 +2521,10 @@ bool c4_dgrad_mfma_ok(const Geom& g, const Epi& e, const float* bias, int act, i
            !e.mode && !e.out16 && !bias && act == MCG_ACT_NONE && !accumulate;
 }
 
+#ifndef MCG_C4_DGRAD_BLOCKS
+#define MCG_C4_DGRAD_BLOCKS 1024
+#endif
+constexpr int C4_DGRAD_MAX_BLOCKS = MCG_C4_DGRAD_BLOCKS;      // blocks of the persistent first-layer input-gradient kernel (4 per CU; each walks tiles)
 template <int KT, int WO, bool BF, bool Y16 = false>
 int launch_dgrad_c4_mfma(const Geom& g, const float* y, const float* w, float* x, hipStream_t s) {
     C4DgradP p;
@@ -2510,7 +2537,8 @@ int launch_dgrad_c4_mfma(const Geom& g, const float* y, const float* w, float* x
     if (attr != hipSuccess) return MCG_ERR_LAUNCH;
     // the rows two neighbouring blocks share are ADDED (two addends, order-independent): x starts from zero
     if (hipMemsetAsync(x, 0, (size_t)g.N * g.Ti * g.Hi * g.Wi * 4 * sizeof(float), s) != hipSuccess) return MCG_ERR_LAUNCH;
-    hipLaunchKernelGGL((dgrad_c4_mfma_kernel<KT, WO, BF, Y16>), dim3(g.N * (g.Ho / R)), dim3(512), lds, s, p);
+    const int ntiles = g.N * (g.Ho / R);
+    hipLaunchKernelGGL((dgrad_c4_mfma_kernel<KT, WO, BF, Y16>), dim3(ntiles < C4_DGRAD_MAX_BLOCKS ? ntiles : C4_DGRAD_MAX_BLOCKS), dim3(512), lds, s, p);
     return MCG_OK;
 }
 
