@@ -2211,7 +2211,10 @@ template <int KT, int WO, bool BF, bool Y16 = false>
 __global__ __launch_bounds__(512) void dgrad_c4_mfma_kernel(C4DgradP p) {
     static_assert(!Y16 || BF, "a bf16 y tensor feeds the bf16 MFMA");
     constexpr int PIX = 128, R = PIX / WO, WI = 2 * WO, XR = 2 * R + 2;       // y pixels per step; input rows of the window
-    constexpr int YLD = BF ? 36 : 68, WLD = YLD, ZLD = 52;                   // LDS row strides in floats (bf16 rows: 64 + 8 elements)
+    // LDS row strides in floats.  bf16 rows: 64 + 16 elements = 40 dwords: a ds_read_b128 lane group takes rows {0-3, 12-15} of one
+    // 16-byte k chunk and rows {4-11} of the next, and r * 40 mod 64 = {0, 40, 16, 56, 32, 8, 48, 24} (period 8) keeps those sixteen
+    // 4-bank slots distinct; with 64 + 8 elements (36 dwords, rounds 2-3) seven of the sixteen collided (PMC: a third of the LDS cycles).
+    constexpr int YLD = BF ? 40 : 68, WLD = YLD, ZLD = 52;
     constexpr int NPX = XR * WI, PPT = (NPX + 511) / 512;                    // input pixels of the window; per thread
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* yl = sm;                                  // [PIX][YLD]
@@ -2529,7 +2532,7 @@ template <int KT, int WO, bool BF, bool Y16 = false>
 int launch_dgrad_c4_mfma(const Geom& g, const float* y, const float* w, float* x, hipStream_t s) {
     C4DgradP p;
     p.g = g; p.y = y; p.w = w; p.x = x;
-    constexpr int R = 128 / WO, NPX = (2 * R + 2) * 2 * WO, LD = BF ? 36 : 68;
+    constexpr int R = 128 / WO, NPX = (2 * R + 2) * 2 * WO, LD = BF ? 40 : 68;
     const size_t lds = (size_t)(128 * LD + KT * 48 * LD + 128 * 52) * 4 + (size_t)KT * NPX * 16;
     static std::once_flag once;
     hipError_t attr = hipSuccess;
