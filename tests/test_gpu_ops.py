@@ -1289,3 +1289,30 @@ def test_bf16_y_beside_fp32_clip(hl, case):
         y16 = torch.empty_like(y32, dtype=torch.bfloat16)
         hl.conv_fprop(g1, xd, wd, None, y16)
         assert torch.equal(y16, y32.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("case", [(160, 1, 64, 3, 64, 1), (130, 5, 64, 3, 64, 4)])
+def test_first_layer_input_gradient_walks_more_tiles_than_blocks(hl, case):
+    """The first-layer input-gradient kernel is persistent (round 4): at most 1024 blocks walk the (batch item, 4 output rows) tiles.
+    These geometries have 1280 / 1040 tiles, so blocks process a SECOND tile -- ring cleared by the first one's last frames, y
+    prefetched across the tile boundary -- and the rows two tiles share are completed by atomics from different blocks.  fp32,
+    bf16 MFMA and a bf16 y tensor against the float64 oracle; G's last layer forward (model/net.py:114) and D's first layer
+    backwards (model/updater.py:113) at batch sizes the other tests do not reach."""
+    N, Ti, H, Ci, Co, kt = case
+    rng = np.random.RandomState(8100 + kt)
+    lay = L()
+    W = _bf16_round(rng.randn(Co, Ci, kt, 4, 4) * 0.1)
+    gy = _bf16_round(rng.randn(N, Co, Ti - kt + 1, H // 2, H // 2))
+    x0 = np.zeros((N, Ci, Ti, H, H))
+    gx_ref, _, _ = F.conv3d_bwd(x0, W, gy, (1, 2, 2), (0, 1, 1))
+    wd, gyd = lay.conv_w_to_dev(dev(W)), lay.act_to_dev(dev(gy))
+    for prec, ga in (('f32', gyd), ('bf16', gyd), ('bf16y', gyd.to(torch.bfloat16))):
+        g = hl.make_geom(N, Ti, H, H, 4, Co, kt, precision=prec, ci_valid=Ci)
+        assert hl.dgrad_c4_mfma_covers(g)
+        gxd = torch.full((N, Ti, H, H, 4), 7.0, device="cuda")
+        hl.conv_dgrad(g, ga, wd, None, gxd)
+        assert rel_l2(lay.act_from_dev(gxd, Ci), gx_ref) < BWD_TOL, prec
+        assert float(gxd[..., 3].abs().max()) == 0.0
+        gx2 = torch.full_like(gxd, -3.0)
+        hl.conv_dgrad(g, ga, wd, None, gx2)
+        assert torch.equal(gx2, gxd), prec                           # (two addends per shared element: the order cannot matter)
