@@ -272,10 +272,10 @@ def main():
     ap.add_argument('--tiles', default='', help='JSON of tile choices to start from (e.g. for a profiler pass without tuning launches)')
     ap.add_argument('--save-tiles', default='', help='write the tile choices of this run to this JSON file')
     ap.add_argument('--overlap', type=int, default=None,
-                    help='1: the headline pass places the ImageDiscriminator update and the weight-gradient GEMMs on side '
-                         'HIP streams; 0: one stream throughout.  Default: 1, except 0 for the bf16 mode at batch >= 128, where '
-                         'the step is dominated by bandwidth-bound passes that only contend (measured: 5178 vs 4768 clips/s '
-                         'at batch 256).  The roofline pass is always one-stream.')
+                    help='1 (default): the headline pass places the ImageDiscriminator update and the weight-gradient GEMMs on side '
+                         'HIP streams; 0: one stream throughout.  (Rounds 1-3 defaulted to 0 for bf16 at batch >= 128, where side '
+                         'streams lost with the kernels of that time; re-measured in round 4 at batch 256: 12.1 k against 11.6 k '
+                         'clips/s with them.)  The roofline pass is always one-stream.')
     ap.add_argument('--secondary', type=int, default=1,
                     help='1 (default): when the headline workload is configs[1] (no --model/--dtype/--batch), also time '
                          'configs[2] (bf16, batch 256) and configs[3] (infogan) -- or, on 8 GPUs, configs[4] (128 clips per GPU) -- '
@@ -286,7 +286,7 @@ def main():
     ap.add_argument('--cpu-sample-warmup', type=int, default=3)
     args = ap.parse_args()
     if args.overlap is None:
-        args.overlap = int(os.environ.get('MCG_OVERLAP', '0' if (args.dtype == 'bf16' and args.batch >= 128) else '1'))
+        args.overlap = int(os.environ.get('MCG_OVERLAP', '1'))
 
     if os.environ.get('MCG_DEBUG_HANG'):
         import faulthandler
@@ -364,7 +364,9 @@ def main():
         # Pass 2 (headline): un-instrumented, EXACTLY `steps` iterations between barrier + synchronize, with the
         # side-stream placement unless --overlap 0.  Same kernels, same arithmetic, same results.
         ts.set_overlap(bool(overlap))
-        for _ in range(warmup if overlap else 0):
+        # (untimed: the side streams' first iterations allocate -- blocks handed to another stream return to the caching allocator only
+        #  after that stream's work, so the pools take ~10 iterations to settle; with 3 of them the batch-256 line scattered 9.9-12.1 k)
+        for _ in range(max(warmup, 10) if overlap else 0):
             ts.run(x_real, t_real)
         barrier()
         t0 = time.perf_counter()
@@ -456,7 +458,7 @@ def main():
         }
 
     def default_overlap(dtype, B):
-        return int(os.environ.get('MCG_OVERLAP', '0' if (dtype == 'bf16' and B >= 128) else '1'))
+        return int(os.environ.get('MCG_OVERLAP', '1'))          # (rounds 1-3: off for bf16 at batch >= 128; re-measured in round 4: on is +4 %)
 
     def all_ranks_ok(ok):
         """MIN over the ranks of a local success flag (one small all-reduce every rank reaches)"""
