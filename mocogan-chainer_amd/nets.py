@@ -284,6 +284,56 @@ class _Net:
         if self.wgrad_stream is not None:
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
 
+    # ---- two chains of one network on two streams (round 4) ----------------------------------------------------------------
+    # The real and the fake call of a discriminator are independent except for what they ACCUMULATE INTO: the running BatchNorm
+    # statistics (two updates per iteration, real first: model/updater.py:97-98,107-108), the gradients of gamma / beta / the
+    # logit layer / dc1's bias (read-modify-write kernels) and the weight gradients (float atomics: no order needed).  step.py may
+    # therefore run the two calls as two chains on two HIP streams -- one chain's element-wise passes then run beside the other's
+    # GEMMs -- if (a) each chain has its own scratch (BatchNorm workspace, partial sums, weight-gradient stream) and (b) the
+    # read-modify-write kernels keep the reference's order.  `with net.chain(i):` swaps the scratch in while chain i's launches are
+    # ENQUEUED (enqueueing is sequential on the host) and `_ordered(key, fn)` gives (b): chain 0 records an event behind fn, chain 1
+    # (enqueued after chain 0) makes its stream wait for that event in front of its own fn.  Without a chain: plain calls.
+    _chain = None
+
+    class _Chain:
+        def __init__(self, net, idx, events, wgrad_stream):
+            self.net, self.idx, self.events, self.wgrad_stream = net, idx, events, wgrad_stream
+            self.ws = torch.empty_like(net.ws)
+            self.part = None
+
+        def __enter__(self):
+            n = self.net
+            assert n._chain is None
+            self._saved = (n.ws, n._part, n.wgrad_stream)
+            n.ws, n._part, n.wgrad_stream, n._chain = self.ws, self.part, self.wgrad_stream, self
+            return self
+
+        def __exit__(self, *exc):
+            n = self.net
+            self.part = n._part                                  # (grown on demand while the chain ran)
+            n.ws, n._part, n.wgrad_stream = self._saved
+            n._chain = None
+            return False
+
+    def make_chains(self, wgrad_streams):
+        """two chain contexts (see above) sharing one table of ordering events; wgrad_streams: a stream (or None) per chain"""
+        events = {}
+        return [self._Chain(self, i, events, wgrad_streams[i]) for i in range(2)]
+
+    def _ordered(self, key, fn):
+        ch = self._chain
+        if ch is None:
+            return fn()
+        if ch.idx == 0:
+            r = fn()
+            ev = ch.events.get(key)
+            if ev is None:
+                ev = ch.events[key] = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            return r
+        torch.cuda.current_stream().wait_event(ch.events[key])    # (recorded: chain 0 of this pass has been enqueued)
+        return fn()
+
     def _alloc(self, specs, device):
         self.device = torch.device(device)
         self.fp = FlatParams(specs, self.device)
@@ -542,12 +592,15 @@ class DisNet(_Net):
                         stats = torch.empty(4 * co, device=dev)
                         rm = self.running[name + '/avg_mean'] if update_stats else None
                         rv = self.running[name + '/avg_var'] if update_stats else None
+                        # (the running averages are read-modify-write state shared by the two calls of an iteration: ordered)
                         if ep is not None:
-                            hl.bn_stats_from_partials(m, co, part[gi * 2 * co:], ep.n_slots, ep.slot_stride, self.fp.param(name + '/gamma'),
-                                                      self.fp.param(name + '/beta'), stats, rm, rv, self.ws)
+                            self._ordered(('stats', l), lambda: hl.bn_stats_from_partials(
+                                m, co, part[gi * 2 * co:], ep.n_slots, ep.slot_stride, self.fp.param(name + '/gamma'),
+                                self.fp.param(name + '/beta'), stats, rm, rv, self.ws))
                         else:
-                            hl.bn_stats(m, co, yg, self.fp.param(name + '/gamma'), self.fp.param(name + '/beta'), stats, rm, rv,
-                                        self.ws, sync=self.sync_bn)
+                            self._ordered(('stats', l), lambda: hl.bn_stats(
+                                m, co, yg, self.fp.param(name + '/gamma'), self.fp.param(name + '/beta'), stats, rm, rv,
+                                self.ws, sync=self.sync_bn))
                         if update_stats:
                             self.bn_count[name] += 1
                         saved['stats'][l].append(stats)
@@ -568,6 +621,8 @@ class DisNet(_Net):
     @staticmethod
     def select_group(saved, gi):
         """The saved state of group gi alone (views, no copies)."""
+        if 'chains' in saved:                                    # (two-chain schedule: each group was a forward of its own)
+            return saved['chains'][gi]
         n = saved['n']
         sl = slice(gi * n, (gi + 1) * n)
         mask = saved.get('mask1')
@@ -607,7 +662,7 @@ class DisNet(_Net):
         k = a5[0].numel()
         co5 = self.out_channels
         if param_grads:
-            hl.fc_wgrad(N, k, co5, a5.view(N, k), g_logits, fp.grad('dc5/W').view(co5, k), fp.grad('dc5/b'))
+            self._ordered(('g', 5), lambda: hl.fc_wgrad(N, k, co5, a5.view(N, k), g_logits, fp.grad('dc5/W').view(co5, k), fp.grad('dc5/b')))
         g = torch.empty_like(a5)
         hl.fc_dgrad(N, k, co5, g_logits, fp.param('dc5/W').view(co5, k), None, 0, g.view(N, k))
         mask1 = saved.get('mask1')
@@ -632,14 +687,19 @@ class DisNet(_Net):
                         go = gy_split[gi * n:(gi + 1) * n]
                     dg = fp.grad(name + '/gamma') if param_grads else None
                     db = fp.grad(name + '/beta') if param_grads else None
+                    # (gamma's / beta's gradients are added by a read-modify-write kernel: ordered between the chains when they are asked for)
                     if pending is not None:
                         ep, part = pending
-                        hl.bn_act_bwd_from_partials(m, co, gg, yg, saved['stats'][l][gi], fp.param(name + '/gamma'), hl.ACT_LRELU,
-                                                    part[gi * 2 * co:], ep.n_slots, ep.slot_stride, go, dg, db, self.ws,
-                                                    split_out=gy_split is not None)
+                        bwd = lambda: hl.bn_act_bwd_from_partials(m, co, gg, yg, saved['stats'][l][gi], fp.param(name + '/gamma'), hl.ACT_LRELU,
+                                                                  part[gi * 2 * co:], ep.n_slots, ep.slot_stride, go, dg, db, self.ws,
+                                                                  split_out=gy_split is not None)
                     else:
-                        hl.bn_act_bwd(m, co, gg, yg, saved['stats'][l][gi], fp.param(name + '/gamma'), hl.ACT_LRELU, go, dg, db, self.ws,
-                                      sync=self.sync_bn, split_out=gy_split is not None)
+                        bwd = lambda: hl.bn_act_bwd(m, co, gg, yg, saved['stats'][l][gi], fp.param(name + '/gamma'), hl.ACT_LRELU, go, dg, db,
+                                                    self.ws, sync=self.sync_bn, split_out=gy_split is not None)
+                    if param_grads:
+                        self._ordered(('g', l), bwd)
+                    else:
+                        bwd()
                 g = gy
             elif mask1 is None:
                 for gi in range(G):
@@ -656,9 +716,10 @@ class DisNet(_Net):
             if param_grads:
                 if l == 1:
                     if pending is not None:
-                        hl.colsum_from_partials(co, pending[1], pending[0].n_slots, pending[0].slot_stride, fp.grad('dc1/b'), self.ws)
+                        self._ordered(('g', 1), lambda: hl.colsum_from_partials(co, pending[1], pending[0].n_slots, pending[0].slot_stride,
+                                                                                fp.grad('dc1/b'), self.ws))
                     else:
-                        hl.colsum_acc(m * G, co, g, fp.grad('dc1/b'), self.ws)
+                        self._ordered(('g', 1), lambda: hl.colsum_acc(m * G, co, g, fp.grad('dc1/b'), self.ws))
                 # dc2..dc4 feed BatchNorm: sum_m gx == 0 exactly (see _Net.BIAS_NOTE), nothing to add
                 wgeom = hl.with_precision(geom, 'bf16y') if (l == 1 and g.dtype == torch.bfloat16) else geom      # (a bf16 y beside the fp32 clip)
                 self._cwgrad(wgeom, saved['a'][l], g, fp.grad('dc%d/W' % l), xs=lambda: self._sp(saved.get('split'), l, saved['a'][l]), ys=gys,

@@ -18,6 +18,14 @@ from . import layout as lay
 from . import nets
 
 
+import os
+
+CHAINS = os.environ.get('MCG_CHAINS', '1') == '1'          # the VideoDiscriminator's real / fake calls as two chains on two streams (A/B switch)
+CHAINS_MIN_N = int(os.environ.get('MCG_CHAINS_MIN_N', '64'))  # ... from this many clips per call on (measured on one MI355X, clips/s with / without:
+                                                              # fp32 batch 32 2120 / 2138, 64 2206 / 2140, 128 2284 / 2257; bf16 128 11.89 / 11.80 k, 256 12.19 / 11.94 k)
+chain_iterations = 0                                          # iterations that took the two-chain schedule (tests assert that it really ran)
+
+
 class AdamHyper:
     """train.py:93-101 -- Chainer Adam(alpha=2e-4, beta1=5e-5) (beta2 0.999 / eps 1e-8 defaults)
     plus the WeightDecay(1e-5) hook."""
@@ -105,6 +113,8 @@ class TrainStep:
         # beside the input-gradient GEMM of the same layer.  Same kernels, same results; only placement in time.
         self.side = None
         self._wstreams = None
+        self._chain_stream = None
+        self._dv_chains = None
         self.set_overlap(overlap)
 
     def set_overlap(self, on):
@@ -112,6 +122,10 @@ class TrainStep:
         if on and self._wstreams is None:
             self._side = torch.cuda.Stream(device=self.device)
             self._wstreams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
+            # the VideoDiscriminator's real and fake calls as two chains (nets._Net.chain): a second compute stream and a
+            # weight-gradient stream of its own for the real chain
+            self._chain_stream = torch.cuda.Stream(device=self.device)
+            self._dv_chains = self.dis_v.make_chains([torch.cuda.Stream(device=self.device), self._wstreams[2]])
         self.side = self._side if on else None
         for i, net in enumerate((self.gen, self.dis_i, self.dis_v)):
             net.wgrad_stream = self._wstreams[i] if on else None
@@ -188,6 +202,16 @@ class TrainStep:
             def first_real_i(out, na):
                 hl.pack_clip(n, c_img, cp, 1, hw, x_real[:, :, t], out, stride_n=c_img * T * hw, stride_c=T * hw, **na)
 
+        # ------------------------------------------------ forward: D_V on the real clips, as a chain of its own beside G's forward
+        ex = self.exchange
+        main = torch.cuda.current_stream()
+        real_chain = None
+        if CHAINS and self.side is not None and ex is None and dv.sync_bn is None and dv.precision != 'f32x3' and n >= CHAINS_MIN_N:
+            cs = self._chain_stream
+            cs.wait_stream(main)                                     # x_real (and whatever produced it)
+            with torch.cuda.stream(cs), self._dv_chains[0]:
+                real_chain = dv.forward(n, first_real_v, noise=nz('noise_v_real'), rng=rngs(1))
+            x_real.record_stream(cs)
         # ------------------------------------------------ forward: fake (G needs nothing from D)
         draw = inject['gen'] if inject is not None else gen.draw(n, (seed, base + 8 * 2))
         x_fake, s_gen = gen.forward(n, draw)
@@ -205,9 +229,7 @@ class TrainStep:
         # ------------------------------------------------ forward: both discriminators on [real | fake]
         # (model/updater.py:97-98,107-108 as one 2n batch per net; per-call BatchNorm statistics, real first)
         cd = di.out_channels
-        ex = self.exchange
         gs = ex.grad_scale if ex else 1.0
-        main = torch.cuda.current_stream()
         side = self.side if self.side is not None else main
         side.wait_stream(main)                                        # x_fake is ready
         # ------------------------------------------------ image_dis_optimizer.update(loss_dis, ...)   :111
@@ -221,17 +243,48 @@ class TrainStep:
             di.backward(s_i, g_i, True)
             work_i = ex.start(di.fp.g) if ex else None
         # ------------------------------------------------ video_dis_optimizer.update(loss_dis, ...)   :112
-        y_v, s_v = dv.forward_groups(n, [dict(first_input=first_real_v, noise=nz('noise_v_real'), rng=rngs(1)),
-                                         dict(first_input=first_fake_v, noise=nz('noise_v_fake'), rng=rngs(4))])
-        y_real_v, y_fake_v = y_v[:n], y_v[n:]
-        g_v = torch.empty((2 * n, cd), device=self.device)
-        dv.zero_grad()
-        hl.loss_dis(n, cd, y_real_v, y_fake_v, t_real, t_fake, with_ce, self.loss[1:2], g_v[:n], g_v[n:])
-        # D_V's gradient is exchanged in two buckets: dc4/W..dc5/b (76 % of the bytes) is final after the
-        # first two layers of the backward pass and travels while dc3..dc1 are still being computed
+        two_chains = (CHAINS and self.side is not None and ex is None and dv.sync_bn is None and dv.precision != 'f32x3'
+                      and real_chain is not None)
         late = []
         lo, hi = dv.grad_bucket_late()
-        dv.backward(s_v, g_v, True, on_late_bucket=(lambda: late.append(ex.start(dv.fp.g[lo:hi]))) if ex else None)
+        if two_chains:
+            # The real and the fake call as TWO CHAINS on two streams (round 4): the real call needs nothing from G and was queued on
+            # the chain stream BEFORE G's forward (real_chain below); the fake call follows G on the main stream.  One chain's
+            # BatchNorm / activation passes (HBM-bound, 3.3 of 21.5 ms exposed at batch 256 in the one-batch schedule) run beside the
+            # other's GEMMs.  Same kernels on n instead of 2n samples; what the calls share is kept in the reference's order by events
+            # (nets._Net._ordered: running statistics real -> fake, gradient accumulators real -> fake).
+            global chain_iterations
+            chain_iterations += 1
+            cs, (ch_r, ch_f) = self._chain_stream, self._dv_chains
+            y_real_v, s_real = real_chain
+            with ch_f:
+                y_fake_v, s_fake = dv.forward(n, first_fake_v, noise=nz('noise_v_fake'), rng=rngs(4))
+            main.wait_stream(cs)                                     # the real logits
+            y_real_v.record_stream(main)
+            g_v = torch.empty((2 * n, cd), device=self.device)
+            dv.zero_grad()
+            hl.loss_dis(n, cd, y_real_v, y_fake_v, t_real, t_fake, with_ce, self.loss[1:2], g_v[:n], g_v[n:])
+            cs.wait_stream(main)                                     # the loss gradients (and the cleared gradient buffer)
+            g_v.record_stream(cs)
+            with torch.cuda.stream(cs), ch_r:
+                dv.backward(s_real, g_v[:n], True)
+            with ch_f:
+                dv.backward(s_fake, g_v[n:], True)
+            main.wait_stream(cs)
+            s_v = {'n': n, 'G': 2, 'chains': [s_real, s_fake]}
+            del s_real
+        else:
+            if real_chain is not None:                              # (decided before G's forward; cannot happen)
+                raise RuntimeError('the real chain ran but the two-chain schedule was not taken')
+            y_v, s_v = dv.forward_groups(n, [dict(first_input=first_real_v, noise=nz('noise_v_real'), rng=rngs(1)),
+                                             dict(first_input=first_fake_v, noise=nz('noise_v_fake'), rng=rngs(4))])
+            y_real_v, y_fake_v = y_v[:n], y_v[n:]
+            g_v = torch.empty((2 * n, cd), device=self.device)
+            dv.zero_grad()
+            hl.loss_dis(n, cd, y_real_v, y_fake_v, t_real, t_fake, with_ce, self.loss[1:2], g_v[:n], g_v[n:])
+            # D_V's gradient is exchanged in two buckets: dc4/W..dc5/b (76 % of the bytes) is final after the
+            # first two layers of the backward pass and travels while dc3..dc1 are still being computed
+            dv.backward(s_v, g_v, True, on_late_bucket=(lambda: late.append(ex.start(dv.fp.g[lo:hi]))) if ex else None)
         with torch.cuda.stream(side):
             if ex:
                 ex.finish(work_i)                                    # D_I's exchange overlapped D_V's backward

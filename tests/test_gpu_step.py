@@ -273,6 +273,26 @@ def test_update_core_with_side_streams(pkg):
     _run_steps(pkg, "normal", 6, nf=16, n=3, steps=2, seed=77, min_tight_steps=0, overlap=True)
 
 
+def test_update_core_with_the_two_chain_schedule(pkg, monkeypatch):
+    """The VideoDiscriminator's real and fake calls as two chains on two HIP streams (step.CHAINS; default from 64 clips per call on):
+    the real call is queued before G's forward, both backward passes run side by side with their own scratch and weight-gradient
+    streams, and what the calls share -- running BatchNorm statistics, the gradient accumulators -- keeps the reference's order
+    (real, then fake: model/updater.py:97-98,107-108,112) through events.  Same kernels on n instead of 2n samples: the teacher-forced
+    and the perf-mode parity must hold unchanged, for fp32 and bf16 networks, and the running statistics (two updates per iteration,
+    order-dependent) are part of the compared state."""
+    step = pkg[3]
+    monkeypatch.setattr(step, 'CHAINS_MIN_N', 1)
+    before = step.chain_iterations
+    _run_steps(pkg, "infogan", 6, nf=4, n=2, steps=3, seed=313, overlap=True)
+    _run_steps(pkg, "normal", 6, nf=16, n=3, steps=2, seed=77, min_tight_steps=0, overlap=True)
+    _run_steps(pkg, "cgan", 6, nf=4, n=2, steps=2, seed=320, min_tight_steps=0, overlap=True)
+    _run_steps(pkg, "normal", 6, nf=4, n=2, steps=3, seed=1311, overlap=True, perf=(PERF_SEEDS[("normal", 6, 0)], 0), min_tight_steps=2)
+    assert step.chain_iterations - before == 3 + 2 + 2 + 3, "the two-chain schedule did not run"
+    monkeypatch.setattr(step, 'CHAINS', False)                     # ... and the switch really switches
+    _run_steps(pkg, "normal", 6, nf=4, n=2, steps=1, seed=1311, overlap=True, min_tight_steps=0)
+    assert step.chain_iterations - before == 10
+
+
 def test_update_core_with_split_fp32_convolutions(pkg, monkeypatch):
     """precision 'f32x3': the wide convolutions' forward and input-gradient GEMMs on the bf16 matrix pipe, operands as three bf16
     terms (six bf16 products per fp32 product, fp32 accumulation) -- an fp32 computation, held to the SAME tolerances as the
@@ -416,8 +436,10 @@ def test_update_core_full_width_with_the_devices_activation_decisions(pkg, preci
     check_params(G.export_reference_params(), gen, 'gen', 1e-4, 'G', ref['grads_gen'])
 
 
-def test_update_core_bf16_mfma_one_step(pkg):
-    """BASELINE configs[2] arithmetic: conv operands rounded to bf16 inside the kernels, fp32 accumulation,
+@pytest.mark.parametrize("chains", [False, True])
+def test_update_core_bf16_mfma_one_step(pkg, chains, monkeypatch):
+    """(chains: the same iteration in the two-chain schedule on side streams, as the batch-256 bench line runs it.)
+    BASELINE configs[2] arithmetic: conv operands rounded to bf16 inside the kernels, fp32 accumulation,
     parameters / BN statistics / Adam in fp32.  The oracle stays the float64 restatement; tolerances are the
     bf16 ones of SURVEY 8c (loss abs <= 5e-2, forward rel-L2 <= 2e-2).  Gradients pass through thousands of
     ReLU decisions that bf16 rounding moves, so they are held to direction (cosine) rather than to digits;
@@ -431,7 +453,10 @@ def test_update_core_bf16_mfma_one_step(pkg):
     G = nets.GenNet(dim_zl=dim_zl, n_filters=nf)
     DI = nets.DisNet(2, 3, 1, nf, use_noise=True)
     DV = nets.DisNet(3, 3, 1, nf, use_noise=True)
-    ts = step.TrainStep(model, G, DI, DV, precision='bf16')
+    if chains:
+        monkeypatch.setattr(step, 'CHAINS_MIN_N', 1)
+    before = step.chain_iterations
+    ts = step.TrainStep(model, G, DI, DV, precision='bf16', overlap=chains)
     assert G.precision == DI.precision == DV.precision == 'bf16'
     og, oi, ov = (oupd.new_adam_state(q) for q in (gen, di, dv))
     for net, p, st in ((G, gen, og), (DI, di, oi), (DV, dv, ov)):
@@ -445,6 +470,7 @@ def test_update_core_bf16_mfma_one_step(pkg):
     for k in ('noise_i_real', 'noise_v_real', 'noise_i_fake', 'noise_v_fake'):
         inject[k] = noise_to_dev(lay, rnd[k])
     out = ts.run(dev(x_real), dev(t_real, torch.int32), inject)
+    assert step.chain_iterations - before == int(chains)
     losses = ts.losses()
     report = {}
     for k, r in (('image_dis/loss', 'loss_dis_i'), ('video_dis/loss', 'loss_dis_v'), ('image_gen/loss', 'loss_gen')):
