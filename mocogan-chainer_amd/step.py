@@ -206,6 +206,7 @@ class TrainStep:
         ex = self.exchange
         main = torch.cuda.current_stream()
         real_chain = None
+        # (not for 'f32x3': measured 2-3 % SLOWER at 32 / 64 / 128 clips -- its launches are tuned, form by form, at the 2n batch)
         if CHAINS and self.side is not None and ex is None and dv.sync_bn is None and dv.precision != 'f32x3' and n >= CHAINS_MIN_N:
             cs = self._chain_stream
             cs.wait_stream(main)                                     # x_real (and whatever produced it)
@@ -243,8 +244,7 @@ class TrainStep:
             di.backward(s_i, g_i, True)
             work_i = ex.start(di.fp.g) if ex else None
         # ------------------------------------------------ video_dis_optimizer.update(loss_dis, ...)   :112
-        two_chains = (CHAINS and self.side is not None and ex is None and dv.sync_bn is None and dv.precision != 'f32x3'
-                      and real_chain is not None)
+        two_chains = CHAINS and self.side is not None and ex is None and dv.sync_bn is None and real_chain is not None
         late = []
         lo, hi = dv.grad_bucket_late()
         if two_chains:

@@ -288,6 +288,11 @@ def test_update_core_with_the_two_chain_schedule(pkg, monkeypatch):
     _run_steps(pkg, "cgan", 6, nf=4, n=2, steps=2, seed=320, min_tight_steps=0, overlap=True)
     _run_steps(pkg, "normal", 6, nf=4, n=2, steps=3, seed=1311, overlap=True, perf=(PERF_SEEDS[("normal", 6, 0)], 0), min_tight_steps=2)
     assert step.chain_iterations - before == 3 + 2 + 2 + 3, "the two-chain schedule did not run"
+    # ('f32x3' networks keep the one-batch schedule: measured slower in two chains)
+    monkeypatch.setenv('MCG_SPLIT', 'always')
+    _run_steps(pkg, "normal", 6, nf=16, n=3, steps=1, seed=77, min_tight_steps=0, overlap=True, precision='f32x3')
+    monkeypatch.delenv('MCG_SPLIT')
+    assert step.chain_iterations - before == 10
     monkeypatch.setattr(step, 'CHAINS', False)                     # ... and the switch really switches
     _run_steps(pkg, "normal", 6, nf=4, n=2, steps=1, seed=1311, overlap=True, min_tight_steps=0)
     assert step.chain_iterations - before == 10

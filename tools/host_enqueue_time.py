@@ -2,7 +2,7 @@ import sys, time, torch
 sys.path.insert(0, '.')
 import mocogan_chainer_amd.hiplib as hl, mocogan_chainer_amd.step as mstep
 hl.load(); hl.set_autotune(True)
-for prec in ('f32', 'bf16'):
+for prec in (sys.argv[1:] or ('f32', 'bf16', 'f32x3')):
     gen, di, dv = mstep.make_models('normal', num_labels=6, seed=0)
     ts = mstep.TrainStep('normal', gen, di, dv, seed=1, precision=prec, overlap=True)
     x = torch.rand((32, 3, 16, 64, 64), device='cuda') * 2 - 1
