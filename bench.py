@@ -340,7 +340,7 @@ def main():
             for net in (gen, di, dv):
                 exchange.broadcast_params([net.fp.p, net.fp.m, net.fp.v] + list(net.running.values()))
         ts = mstep.TrainStep(model, gen, di, dv, exchange=exchange, seed=1234, rank=rank, precision=dtype, overlap=False,
-                              sync_bn=bool(args.sync_bn))
+                              sync_bn=bool(args.sync_bn), input_ready_early=os.environ.get('MCG_INPUT_EARLY', '1') == '1')   # (the batch is resident)
         g = torch.Generator(device='cuda')
         g.manual_seed(rank)
         x_real = torch.rand((B, 3, 16, 64, 64), device='cuda', generator=g) * 2 - 1   # synthetic U(-1,1), resident in HBM

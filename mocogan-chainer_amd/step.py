@@ -91,7 +91,8 @@ class GradExchange:
 class TrainStep:
     """Holds the three networks, their Adam hyper-parameters and runs update_core on device data."""
 
-    def __init__(self, model, gen, dis_i, dis_v, hyper=None, exchange=None, seed=0, rank=0, precision=None, overlap=False, sync_bn=False):
+    def __init__(self, model, gen, dis_i, dis_v, hyper=None, exchange=None, seed=0, rank=0, precision=None, overlap=False, sync_bn=False,
+                 input_ready_early=False):
         assert model in ('normal', 'cgan', 'infogan')
         self.model, self.gen, self.dis_i, self.dis_v = model, gen, dis_i, dis_v
         if precision is not None:                                 # 'f32' | 'bf16': MFMA operand type of every conv GEMM
@@ -105,6 +106,14 @@ class TrainStep:
         for net in (gen, dis_i, dis_v):
             net.sync_bn = exchange if (sync_bn and exchange is not None) else None
         self.seed, self.rank = seed, rank
+        # input_ready_early (two-chain schedule only): the caller guarantees that x_real / t_real of run() were complete BEFORE the
+        # previous run() was queued (resident synthetic data; a loader that stays one batch ahead).  The real chain of the
+        # VideoDiscriminator then waits only for what it really needs -- the VideoDiscriminator's Adam update of the previous
+        # iteration -- instead of for everything queued so far, and runs beside the END of the previous iteration (G's backward pass):
+        # the host is several milliseconds ahead of the GPU, so the launches are there to overlap.  Off by default: a caller that
+        # writes parameters or inputs on the current stream between two iterations (the teacher-forced tests do) needs the full wait.
+        self.input_ready_early = bool(input_ready_early)
+        self._ev_dv_updated = None
         self.iteration = 0
         self.device = gen.device
         self.loss = torch.zeros(3, device=self.device)            # loss_dis_i, loss_dis_v, loss_gen
@@ -209,7 +218,10 @@ class TrainStep:
         # (not for 'f32x3': measured 2-3 % SLOWER at 32 / 64 / 128 clips -- its launches are tuned, form by form, at the 2n batch)
         if CHAINS and self.side is not None and ex is None and dv.sync_bn is None and dv.precision != 'f32x3' and n >= CHAINS_MIN_N:
             cs = self._chain_stream
-            cs.wait_stream(main)                                     # x_real (and whatever produced it)
+            if self.input_ready_early and self._ev_dv_updated is not None and not cgan:
+                cs.wait_event(self._ev_dv_updated)                   # the previous iteration's Adam(D_V); x_real is ready by contract
+            else:
+                cs.wait_stream(main)                                 # x_real (and whatever produced it)
             with torch.cuda.stream(cs), self._dv_chains[0]:
                 real_chain = dv.forward(n, first_real_v, noise=nz('noise_v_real'), rng=rngs(1))
             x_real.record_stream(cs)
@@ -294,6 +306,10 @@ class TrainStep:
             for h in late + rest:
                 ex.finish(h)
         adam_update(dv, self.hyper['video_dis'], gs)
+        if self._dv_chains is not None:                               # (what the next iteration's real chain has to wait for)
+            if self._ev_dv_updated is None:
+                self._ev_dv_updated = torch.cuda.Event()
+            self._ev_dv_updated.record(main)
         main.wait_stream(side)                                        # D_I's logits and updated weights (Q5)
         # ------------------------------------------------ image_gen_optimizer.update(loss_gen, ...)   :113
         gen.zero_grad()

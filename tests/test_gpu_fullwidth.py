@@ -136,11 +136,19 @@ def _params_rel_l2(net, ref):
     return (num / den) ** 0.5
 
 
-def test_free_running_three_iterations_stay_within_1e4(pkg):
+@pytest.mark.parametrize("schedule", ["one stream", "two chains, inputs ready early"])
+def test_free_running_three_iterations_stay_within_1e4(pkg, schedule, monkeypatch):
     """The device keeps its own parameters, Adam moments and BatchNorm statistics for three iterations (no teacher
     forcing); oracle and device see the same randomness.  SURVEY 8c: weights rel-L2 <= 1e-4 after 3 steps; losses and
-    the generated clip at the forward tolerance."""
+    the generated clip at the forward tolerance.
+    Second schedule: what bench.py runs from 64 clips per call on -- side streams, the VideoDiscriminator's real / fake calls as two
+    chains, and TrainStep(input_ready_early=True): the real chain of iteration i + 1 waits only for iteration i's Adam(D_V) and may
+    run beside the end of iteration i.  The inputs of ALL iterations are therefore complete before the first run() and nothing
+    synchronises with the host until the last iteration is queued (so the iterations really overlap)."""
     hl, lay, nets, step = pkg
+    early = schedule != "one stream"
+    if early:
+        monkeypatch.setattr(step, 'CHAINS_MIN_N', 1)
     model, nf, n, dim_zl = 'infogan', 8, 4, 6
     rng = np.random.RandomState(3)
     gen = _f64(onet.init_generator(rng, dim_zl=dim_zl, n_filters=nf))
@@ -151,17 +159,26 @@ def test_free_running_three_iterations_stay_within_1e4(pkg):
     for net, p, st in ((G, gen, og), (DI, di, oi), (DV, dv, ov)):       # identical START only
         net.load_reference_params(p)
         net.load_adam_state(st)
-    ts = step.TrainStep(model, G, DI, DV)
-    for it in range(3):
+    ts = step.TrainStep(model, G, DI, DV, overlap=early, input_ready_early=early)
+    before = step.chain_iterations
+    refs, inputs = [], []
+    for it in range(3):                                               # oracle first; device inputs of every iteration made up front
         x_real = rng.uniform(-1, 1, (n, 3, 16, 64, 64))
         t_real = rng.randint(0, 6, n)
         rnd = oupd.draw_step_randomness(rng, model, n, 3, nf, dim_zl=dim_zl, dtype=F64)
-        ref = oupd.update_core(model, gen, di, dv, og, oi, ov, x_real, t_real, rnd, dim_zl=dim_zl, keep=True)
-        out = ts.run(dev(x_real), dev(t_real, torch.int32), _inject(lay, rnd))
-        l = ts.losses()
-        assert abs(l['image_dis/loss'] - ref['loss_dis_i']) < 1e-5 and abs(l['video_dis/loss'] - ref['loss_dis_v']) < 1e-5, it
-        assert abs(l['image_gen/loss'] - ref['loss_gen']) < 1e-5, it
-        assert rel_l2(lay.act_from_dev(out['x_fake'], 3), ref['x_fake'][:, :3]) < 1e-5, it
+        refs.append(oupd.update_core(model, gen, di, dv, og, oi, ov, x_real, t_real, rnd, dim_zl=dim_zl, keep=True))
+        inputs.append((dev(x_real), dev(t_real, torch.int32), _inject(lay, rnd)))
+    torch.cuda.synchronize()
+    got = []
+    for it in range(3):
+        out = ts.run(*inputs[it])
+        got.append((ts.loss.clone(), out['x_fake']))                  # (device copies: no host synchronisation between iterations)
+    assert step.chain_iterations - before == (3 if early else 0)
+    for it, ((loss, x_fake), ref) in enumerate(zip(got, refs)):
+        l = loss.cpu().tolist()
+        assert abs(l[0] - ref['loss_dis_i']) < 1e-5 and abs(l[1] - ref['loss_dis_v']) < 1e-5, it
+        assert abs(l[2] - ref['loss_gen']) < 1e-5, it
+        assert rel_l2(lay.act_from_dev(x_fake, 3), ref['x_fake'][:, :3]) < 1e-5, it
     errs = {name: _params_rel_l2(net, p) for name, net, p in (('G', G, gen), ('D_I', DI, di), ('D_V', DV, dv))}
     print('free-running parameters rel-L2 after 3 iterations:', errs)
     assert all(e < 1e-4 for e in errs.values()), errs
