@@ -280,7 +280,8 @@ def main():
                     help='1 (default): when the headline workload is configs[1] (no --model/--dtype/--batch), also time '
                          'configs[2] (bf16, batch 256) and configs[3] (infogan) -- or, on 8 GPUs, configs[4] (128 clips per GPU) -- '
                          'for a few steps each and report them under "secondary" on the same line')
-    ap.add_argument('--secondary-steps', type=int, default=8)
+    ap.add_argument('--secondary-steps', type=int, default=20, help='timed iterations of each secondary workload (20: as the headline; with 8 the fill\n'
+                    '                    and drain of the first / last iteration cost the short runs 2-4 %%)')
     ap.add_argument('--cpu-sample-batch', type=int, default=8, help='BASELINE.md section 3: batch 8')
     ap.add_argument('--cpu-sample-steps', type=int, default=5, help='timed iterations (median reported)')
     ap.add_argument('--cpu-sample-warmup', type=int, default=3)

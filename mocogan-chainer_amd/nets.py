@@ -139,15 +139,8 @@ class _Net:
         if ent is None or ent[0] != self.fp.version:
             w = self.fp.param(name)
             run = 16 if form == 'f' else 16 * (w.numel() // w.shape[0])
-            cur = torch.cuda.current_stream()
-            if ent is not None:
-                cur.wait_event(ent[2])                           # (the buffer is rewritten: readers queued on another stream first)
             out = hl.split_planes(w, run=run, out=ent[1] if ent else None)
-            ev = ent[2] if ent else torch.cuda.Event()
-            ev.record(cur)
-            cache[(name, form)] = ent = (self.fp.version, out, ev)
-        else:
-            torch.cuda.current_stream().wait_event(ent[2])       # built on another stream, perhaps (two chains): its launch comes first
+            cache[(name, form)] = ent = (self.fp.version, out)
         return ent[1]
 
     def _cfprop(self, g, x, wname, w, b, y, ep=None, must_fuse=False, xs=None, force=False):

@@ -26,6 +26,20 @@ CHAINS_MIN_N = int(os.environ.get('MCG_CHAINS_MIN_N', '64'))  # ... from this ma
 chain_iterations = 0                                          # iterations that took the two-chain schedule (tests assert that it really ran)
 
 
+_STREAMS = {}
+
+
+def _side_streams(device):
+    """the process's six side streams on `device`: [D_I's, three weight-gradient streams (G, D_I, D_V), D_V's chain, its weight-gradient]"""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _STREAMS:
+        # (MCG_STREAM_MAP="a,b,c,d,e,f": tuning aid -- which of twelve streams, in creation order, plays each role)
+        m = [int(v) for v in os.environ.get('MCG_STREAM_MAP', '0,1,2,3,4,5').split(',')]
+        pool = [torch.cuda.Stream(device=device) for _ in range(max(m) + 1)]
+        _STREAMS[key] = [pool[i] for i in m]
+    return _STREAMS[key]
+
+
 class AdamHyper:
     """train.py:93-101 -- Chainer Adam(alpha=2e-4, beta1=5e-5) (beta2 0.999 / eps 1e-8 defaults)
     plus the WeightDecay(1e-5) hook."""
@@ -129,12 +143,18 @@ class TrainStep:
     def set_overlap(self, on):
         """Switch the side-stream placement on or off (between iterations)."""
         if on and self._wstreams is None:
-            self._side = torch.cuda.Stream(device=self.device)
-            self._wstreams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
+            # ONE set of side streams per process and device (not per TrainStep): the runtime deals hardware queues to streams in
+            # creation order (four queues by default), and which streams share a queue decides what really overlaps -- a second
+            # TrainStep with fresh streams got another assignment and ran 4-5 % slower than the first (bench.py's secondary
+            # workloads against the same workloads run alone).  (More hardware queues are not better: GPU_MAX_HW_QUEUES=8 cost
+            # the batch-32 iteration 22 %.)
+            st = _side_streams(self.device)
+            self._side = st[0]
+            self._wstreams = st[1:4]
             # the VideoDiscriminator's real and fake calls as two chains (nets._Net.chain): a second compute stream and a
             # weight-gradient stream of its own for the real chain
-            self._chain_stream = torch.cuda.Stream(device=self.device)
-            self._dv_chains = self.dis_v.make_chains([torch.cuda.Stream(device=self.device), self._wstreams[2]])
+            self._chain_stream = st[4]
+            self._dv_chains = self.dis_v.make_chains([st[5], self._wstreams[2]])
         self.side = self._side if on else None
         for i, net in enumerate((self.gen, self.dis_i, self.dis_v)):
             net.wgrad_stream = self._wstreams[i] if on else None
