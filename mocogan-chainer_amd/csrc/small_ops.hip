@@ -652,20 +652,42 @@ __global__ __launch_bounds__(NT) void fc_dgrad_rows_kernel(int K, int Co, const 
     for (int r = 0; r < R; ++r) *reinterpret_cast<f32x4*>(x + (long long)(m0 + r) * K + k) = s[r] + b;
 }
 
+// dw[co][k] += sum_m y[m][co] x[m][k] (the discriminators' last layer: Co = 1 + dim_zl rows of K = 8 k .. 32 k inputs, M = the batch).
+// Block = FCW_Q k quads x FCW_S row slices: thread (q, sl) sums rows sl, sl + FCW_S, .. of its quad, the slices are combined through
+// LDS in slice order (fixed order, no atomics); block x = 0 also reduces the bias gradient.  (Round 4: the first form gave a thread
+// one quad and ALL rows -- 32 blocks for K = 32768, 512 dependent steps each, and db as one thread's serial loop: 154 us per call at
+// 512 clips where the 67 MB of x take 17.)
+constexpr int FCW_Q = 32, FCW_S = NT / FCW_Q;
 __global__ __launch_bounds__(NT) void fc_wgrad_kernel(int M, int K, int Co, const float* __restrict__ x, const float* __restrict__ y,
                                                       float* __restrict__ dw, float* db) {
+    __shared__ f32x4 red[FCW_S][FCW_Q];
+    __shared__ float redb[NT];
     const int co = blockIdx.y;
+    const int q = threadIdx.x % FCW_Q, sl = threadIdx.x / FCW_Q;
+    const int k = (blockIdx.x * FCW_Q + q) * 4;
+    f32x4 s = {0, 0, 0, 0};
+    if (k < K) {
+#pragma unroll 4
+        for (int m = sl; m < M; m += FCW_S) s += y[(long long)m * Co + co] * *reinterpret_cast<const f32x4*>(x + (long long)m * K + k);
+    }
+    red[sl][q] = s;
+    if (db && blockIdx.x == 0) {
+        float t = 0.f;
+        for (int m = threadIdx.x; m < M; m += NT) t += y[(long long)m * Co + co];
+        redb[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (sl == 0 && k < K) {
+#pragma unroll
+        for (int j = 1; j < FCW_S; ++j) s += red[j][q];
+        f32x4* d = reinterpret_cast<f32x4*>(dw + (long long)co * K + k);
+        *d = *d + s;
+    }
     if (db && blockIdx.x == 0 && threadIdx.x == 0) {
         float t = 0.f;
-        for (int m = 0; m < M; ++m) t += y[(long long)m * Co + co];
+        for (int j = 0; j < NT; ++j) t += redb[j];
         db[co] += t;
     }
-    const int k = (blockIdx.x * NT + threadIdx.x) * 4;
-    if (k >= K) return;
-    f32x4 s = {0, 0, 0, 0};
-    for (int m = 0; m < M; ++m) s += y[(long long)m * Co + co] * *reinterpret_cast<const f32x4*>(x + (long long)m * K + k);
-    f32x4* d = reinterpret_cast<f32x4*>(dw + (long long)co * K + k);
-    *d = *d + s;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1424,7 +1446,7 @@ extern "C" int mcg_fc_wgrad(int M, int K, int Co, const float* x, const float* y
         int st = mcg_detail_fc_wgrad_gemm(M, K, Co, x, y, dw, stream);
         if (st != MCG_ERR_UNSUPPORTED) return st;
     }
-    hipLaunchKernelGGL(fc_wgrad_kernel, dim3((K / 4 + NT - 1) / NT, Co), dim3(NT), 0, (hipStream_t)stream, M, K, Co, x, y, dw, db);
+    hipLaunchKernelGGL(fc_wgrad_kernel, dim3((K / 4 + FCW_Q - 1) / FCW_Q, Co), dim3(NT), 0, (hipStream_t)stream, M, K, Co, x, y, dw, db);
     return launch_status();
 }
 

@@ -244,7 +244,8 @@ def test_conv_rejects_bad_geometry(hl):
 
 @pytest.mark.parametrize("M,K,Co", [(4, 512, 1), (3, 2048, 7), (32, 1024, 60),
                                     (512, 8192, 60), (100, 1024, 60), (77, 2048, 20),     # M >= 64, Co >= 16: the MFMA GEMM path
-                                    (64, 32768, 7), (64, 8192, 7), (64, 32768, 1)])       # D_V / D_I dc5 at the batch-32 step's 2n rows (infogan: 7)
+                                    (64, 32768, 7), (64, 8192, 7), (64, 32768, 1),        # D_V / D_I dc5 at the batch-32 step's 2n rows (infogan: 7)
+                                    (512, 32768, 1), (5, 64, 3)])                         # ... at the batch-256 step's; fewer rows than slices
 def test_fc_ops(hl, M, K, Co):
     rng = np.random.RandomState(M * 7 + Co)
     x, w, b, gy = rng.randn(M, K), rng.randn(Co, K) * 0.05, rng.randn(Co), rng.randn(M, Co)
@@ -259,6 +260,9 @@ def test_fc_ops(hl, M, K, Co):
     dwd = torch.ones((Co, K), device="cuda")
     hl.fc_wgrad(M, K, Co, xd, gyd, dwd)
     assert rel_l2(dwd, gy.T @ x + 1) < BWD_TOL
+    dwd, dbd = torch.ones((Co, K), device="cuda"), torch.ones(Co, device="cuda")      # with the bias gradient (the row-sliced kernel)
+    hl.fc_wgrad(M, K, Co, xd, gyd, dwd, dbd)
+    assert rel_l2(dwd, gy.T @ x + 1) < BWD_TOL and rel_l2(dbd, gy.sum(0) + 1) < BWD_TOL
 
 
 @pytest.mark.parametrize("C,M,act", [(64, 5000, 2), (128, 777, 1), (512, 64, 2), (256, 4096, 1)])
