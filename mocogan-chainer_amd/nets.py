@@ -38,6 +38,7 @@ OUT16 = os.environ.get('MCG_OUT16', '1') == '1'        # bf16 networks: GEMM out
 Y16 = os.environ.get('MCG_Y16', '1') == '1'            # bf16 networks: the 64-channel neighbours of the clip (dc1's output gradient in D, the last
                                                        # layer's input and its gradient in G) stored in bf16, 'bf16y' launches read them (A/B switch)
 FUSE = set(filter(None, os.environ.get('MCG_FUSE', 'stats,dc1').split(',')))
+WGRAD_AFTER = os.environ.get('MCG_WGRAD_AFTER', '0') == '1'    # side-stream weight gradients start AFTER the layer's input-gradient GEMM (A/B switch, off: see _Net._hold_wgrads)
 
 
 class Config:
@@ -256,8 +257,30 @@ class _Net:
     wgrad_stream = None
     sync_bn = None                 # step.GradExchange when BatchNorm is synchronised over the data-parallel ranks
 
+    _held = None                   # weight-gradient launches held back until the layer's input-gradient GEMM is queued (_hold_wgrads)
+
+    def _hold_wgrads(self):
+        """Round 4: two big GEMMs side by side only share the machine (a trace of the batch-256 bf16 iteration: 11.8 of 19.7 ms with
+        two or more GEMMs running, the SUM of their durations twice the one-stream sum), while the element-wise passes of the main
+        chain -- BatchNorm's backward of the next layer, which depends on the input gradient -- ran alone for 2.5 ms.  So a layer's
+        weight gradient can be queued behind its input-gradient GEMM (MCG_WGRAD_AFTER=1): that GEMM runs alone, the weight gradient
+        starts together with the element-wise passes that follow it.  Measured (alternating, one box): bf16 batch 256 12.51-12.67 k
+        against 12.70-12.71 k clips/s, fp32 batch 32 2099-2105 against 2131-2140, 'f32x3' 2747-2789 against 2752-2799 -- the one-block-
+        per-CU weight gradient then holds the CUs the NEXT input-gradient GEMM of the main chain wants, and that costs what the hidden
+        element-wise passes gain.  Off by default."""
+        if WGRAD_AFTER and self.wgrad_stream is not None:
+            self._held = []
+
+    def _flush_wgrads(self):
+        held, self._held = self._held, None
+        for args in held or ():
+            self._wgrad(*args)
+
     def _wgrad(self, geom, x, y, dw):
         """conv_wgrad on wgrad_stream (after everything queued so far on the current stream)."""
+        if self._held is not None:
+            self._held.append((geom, x, y, dw))
+            return
         ws = self.wgrad_stream
         if ws is None:
             hl.conv_wgrad(geom, x, y, dw)
@@ -658,6 +681,7 @@ class DisNet(_Net):
         N = n * G
         fp = self.fp
         hl.set_tag(self.tag)
+        self._held = None
         assert gx is None or G == 1
         a5 = saved['a'][5]
         k = a5[0].numel()
@@ -723,9 +747,11 @@ class DisNet(_Net):
                         self._ordered(('g', 1), lambda: hl.colsum_acc(m * G, co, g, fp.grad('dc1/b'), self.ws))
                 # dc2..dc4 feed BatchNorm: sum_m gx == 0 exactly (see _Net.BIAS_NOTE), nothing to add
                 wgeom = hl.with_precision(geom, 'bf16y') if (l == 1 and g.dtype == torch.bfloat16) else geom      # (a bf16 y beside the fp32 clip)
+                if l > 1:
+                    self._hold_wgrads()                          # ... queued once the input-gradient GEMM below is (see _hold_wgrads)
                 self._cwgrad(wgeom, saved['a'][l], g, fp.grad('dc%d/W' % l), xs=lambda: self._sp(saved.get('split'), l, saved['a'][l]), ys=gys,
                              force=g_only or l in saved.get('only', ()))
-                if l == 4 and on_late_bucket is not None:
+                if l == 4 and on_late_bucket is not None and self._held is None:
                     self._after_wgrads(on_late_bucket)
             pending = None
             if l > 1:
@@ -753,6 +779,10 @@ class DisNet(_Net):
                         pending = (ep, part)
                 else:
                     self._cdgrad(geom, g, 'dc%d/W' % l, w, None, ga, ys=gys, force=g_only)
+                if self._held is not None:
+                    self._flush_wgrads()
+                    if l == 4 and on_late_bucket is not None:
+                        self._after_wgrads(on_late_bucket)
                 g = ga
             elif gx is not None:
                 def write_gx(g=g, geom=geom):
@@ -1000,6 +1030,7 @@ class GenNet(_Net):
         fp = self.fp
         dev = self.device
         hl.set_tag('G')
+        self._held = None
         g = torch.empty((frames, IMG, IMG, self.cp_out), device=dev)
         hl.tanh_bwd_to_frames(n, T, IMG * IMG * self.cp_out, gx_clip, saved['x'], g)
         pending = None               # (epilogue, partial sums) the GEMM that produced g left for BatchNorm's backward
@@ -1032,9 +1063,10 @@ class GenNet(_Net):
                 return self._sp(gsp, 0, g)
             g_only = gy_split is not None                        # g exists in its split form only
             a5_16 = l == 5 and saved['a'][5].dtype == torch.bfloat16      # (the 64-channel side of the last layer stored in bf16)
+            self._hold_wgrads()                                  # (queued once the input-gradient GEMM below is: see _hold_wgrads)
             self._cwgrad(hl.with_precision(geom, 'bf16y') if a5_16 else geom, g, saved['a'][l], fp.grad('dc%d/W' % l), xs=gxs,
                          ys=lambda: self._sp(saved.get('split'), l, saved['a'][l]), force=g_only or l in saved.get('only', ()))
-            if l == 2 and on_late_bucket is not None:
+            if l == 2 and on_late_bucket is not None and self._held is None:
                 self._after_wgrads(on_late_bucket)
             wl = self._w('dc%d/W' % l, s16)
             g16 = (OUT16 and 2 < l < 5 and s16 and self.sync_bn is None                        # (layer 1's gradient feeds the fp32 fully-connected layer)
@@ -1050,6 +1082,10 @@ class GenNet(_Net):
                     pending = (ep, part)
             else:
                 self._cfprop(geom, g, 'dc%d/W' % l, wl, None, ga, xs=gxs, force=g_only)
+            if self._held is not None:
+                self._flush_wgrads()
+                if l == 2 and on_late_bucket is not None:
+                    self._after_wgrads(on_late_bucket)
             g = ga
         c1 = self.chans[1]
         k1 = 16 * c1
