@@ -315,17 +315,21 @@ def main():
     rehearsal = os.environ.get('MCG_SINGLE_DEVICE') == '1'
     torch.cuda.set_device(0 if rehearsal else local_rank)
     exchange = None
-    if world > 1:
+    # MCG_DP_REHEARSE_NCCL=1 (one GPU, one rank): the data-parallel code path -- process group over nccl (= RCCL), tile-table broadcast,
+    # bucketed gradient all-reduce on its stream, the timing collectives -- with a world of ONE; never used for reported numbers.
+    dp = world > 1 or os.environ.get('MCG_DP_REHEARSE_NCCL') == '1'
+    if dp:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group(os.environ.get('MCG_DIST_BACKEND', 'nccl'), rank=rank, world_size=world)
-        exchange = mstep.GradExchange()
+        exchange = mstep.GradExchange(force=world == 1)
     hl.load()
     hl.set_autotune(bool(args.autotune))
     if args.tiles:
         hl.load_tile_choices(args.tiles)
 
     def barrier():
-        if world > 1:
+        if dp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -377,7 +381,7 @@ def main():
         dt_local = time.perf_counter() - t0
         tall = torch.tensor([dt_local], device='cuda', dtype=torch.float64)
         per_rank = [dt_local]
-        if world > 1:
+        if dp:
             gathered = [torch.zeros_like(tall) for _ in range(world)]
             dist.all_gather(gathered, tall)
             per_rank = [float(t) for t in gathered]
@@ -452,7 +456,7 @@ def main():
                                         "overlaps independent kernels on side streams, which stretches individual launches"
                                         if overlap else "is one-stream too"),
                          "dv_conv_share_of_step_time": dv_total_ms / (dt_serial_instr / steps * 1e3)},
-            "dist": {"backend": dist.get_backend() if world > 1 else None, "world_size": dist.get_world_size() if world > 1 else 1,
+            "dist": {"backend": dist.get_backend() if dp else None, "world_size": dist.get_world_size() if dp else 1,
                      "per_rank_ms_per_step": {"min": per_rank_ms[0], "median": per_rank_ms[len(per_rank_ms) // 2],
                                               "max": per_rank_ms[-1]}},
             "losses": losses,
@@ -463,7 +467,7 @@ def main():
 
     def all_ranks_ok(ok):
         """MIN over the ranks of a local success flag (one small all-reduce every rank reaches)"""
-        if world == 1:
+        if not dp:
             return ok
         f = torch.tensor([1.0 if ok else 0.0], device='cuda')
         dist.all_reduce(f, op=dist.ReduceOp.MIN)
@@ -496,7 +500,7 @@ def main():
         """a secondary workload must never cost the headline its line.  One GPU: a failure is recorded in its place.  N > 1: the
         workload only starts when every rank has run it once locally (preflight); after that an exception is a real bug and is
         raised -- swallowing it on one rank would leave the others in a collective."""
-        if world > 1:
+        if dp:
             if not preflight(model, dtype, B):
                 if rank == 0:
                     secondary.append({"config": {"workload": "%s %s batch %d" % (model, dtype, B)}, "dtype": dtype,
@@ -534,7 +538,7 @@ def main():
             sys.stderr.write('bench.py: could not write %s: %r\n' % (detail_path, exc))
             detail_path = None
         print(compact_line(out, secondary, cpu, detail_path))
-    if world > 1:
+    if dp:
         dist.destroy_process_group()
 
 

@@ -69,16 +69,18 @@ class GradExchange:
     the same Adam update and the replicas stay bit-identical.  The collective SUMS; the division by the world
     size happens inside the Adam kernel (``grad_scale``), not in a pass of its own."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, force=False):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.grad_scale = 1.0 / self.world
+        # force: a world of ONE still goes through the collectives (a one-GPU rehearsal of the RCCL path: bench.py MCG_DP_REHEARSE_NCCL)
+        self.active = self.world > 1 or (force and dist.is_available() and dist.is_initialized())
 
     def start(self, flat_grad):
         """Asynchronous SUM all-reduce of a (slice of a) flat gradient; returns a handle for finish()."""
-        if self.world == 1:
+        if not self.active:
             return None
         return (self.dist.all_reduce(flat_grad, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True), flat_grad)
 
@@ -92,11 +94,11 @@ class GradExchange:
 
     def all_reduce_sum(self, t):
         """In-place SUM over the ranks, ordered on the current stream (synchronised BatchNorm's per-channel sums)."""
-        if self.world > 1:
+        if self.active:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
     def broadcast_params(self, tensors, src=0):
-        if self.world == 1:
+        if not self.active:
             return
         for t in tensors:
             self.dist.broadcast(t, src=src, group=self.group)
@@ -396,7 +398,7 @@ def pretune_and_share_tiles(exchange, model, precision, batch, rank, **model_kw)
     Adam consumes the all-reduced gradient; but a rank with a slower choice sets the step time).  Here every rank runs ONE
     local iteration (no exchange) on throw-away networks, which tunes whatever is missing, then rank 0's table replaces
     everyone's.  No reference counterpart (the reference is single-device, train.py:87-91)."""
-    if exchange is None or exchange.world == 1:
+    if exchange is None or not exchange.active:
         return
     if hl._autotune:
         model_kw.setdefault('num_labels', 6)

@@ -35,7 +35,7 @@ def _worker(rank, world, port, q, sync_bn=False, precision='f32', nf=NF, backend
         G = nets.GenNet(dim_zl=DIM_ZL, n_filters=nf)
         DI = nets.DisNet(2, 3, 7, nf, use_noise=True)
         DV = nets.DisNet(3, 3, 7, nf, use_noise=True)
-        ts = step.TrainStep(MODEL, G, DI, DV, exchange=step.GradExchange(), rank=rank, overlap=True, sync_bn=sync_bn,
+        ts = step.TrainStep(MODEL, G, DI, DV, exchange=step.GradExchange(force=world == 1), rank=rank, overlap=True, sync_bn=sync_bn,
                             precision=precision)
         assert dist.get_backend() == backend
         for net, p in ((G, gen), (DI, di), (DV, dv)):
@@ -58,17 +58,17 @@ def _worker(rank, world, port, q, sync_bn=False, precision='f32', nf=NF, backend
         dist.destroy_process_group()
 
 
-def _run_ranks(sync_bn, port_base, precision='f32', nf=NF, backend='gloo'):
+def _run_ranks(sync_bn, port_base, precision='f32', nf=NF, backend='gloo', world=2):
     import queue
     import time
     import torch.multiprocessing as mp
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = port_base + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, sync_bn, precision, nf, backend)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, sync_bn, precision, nf, backend)) for r in range(world)]
     [p.start() for p in procs]
     res, t0 = [], time.time()
-    while len(res) < 2:
+    while len(res) < world:
         try:
             res.append(q.get(timeout=10))
         except queue.Empty:
@@ -222,3 +222,37 @@ def test_two_rank_rccl_matches_the_sharded_oracle():
     finally:
         oupd.update_core = orig
     print('RCCL: worst relative update error', _update_errors(res, nets, ref))
+
+
+def test_one_rank_rccl_matches_the_oracle():
+    """One GPU cannot hold two RCCL ranks, but a world of ONE over the nccl backend (= RCCL) runs the product's whole exchange path --
+    GradExchange(force=True): the late bucket's all_reduce issued from the weight-gradient stream, work.wait() on the main stream,
+    the parameter broadcast -- and a SUM over one rank with grad_scale 1 must leave the teacher-forced iteration equal to the oracle's."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import dp_common
+    from oracle import updater as oupd
+    res = _run_ranks(False, 38600, backend='nccl', world=1)
+    nets, shards = dp_common.setup(nf=NF, n=N, seed=11, model=MODEL, dim_zl=DIM_ZL, world=1)
+    orig = oupd.update_core
+    oupd.update_core = lambda model, gen, di, dv, og, oi, ov, x, t_real, rnd, **kw: orig(
+        model, gen, di, dv, og, oi, ov, x, np.zeros(N, dtype=np.int64), rnd, **kw)
+    try:
+        ref = dp_common.emulate(nets, shards, model=MODEL, dim_zl=DIM_ZL)
+    finally:
+        oupd.update_core = orig
+    print('RCCL, one rank: worst relative update error', _update_errors(res, nets, ref))
+
+
+def test_one_rank_rccl_rehearsal_of_the_bench_line():
+    """bench.py's data-parallel code path with a world of ONE over nccl (MCG_DP_REHEARSE_NCCL): process group, tile-table broadcast,
+    bucketed gradient all-reduce, the timing collectives, the compact line naming the backend."""
+    import json
+    import math
+    import subprocess
+    env = dict(os.environ, MCG_DP_REHEARSE_NCCL='1', MASTER_PORT='37711', MCG_BENCH_DETAIL=os.devnull)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '2', '--batch', '4', '--no-cpu-baseline', '--secondary', '0']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line['dist']['backend'] == 'nccl' and line['dist']['world_size'] == 1 and line['value'] > 0
+    assert all(math.isfinite(v) for v in line['losses'].values()), line['losses']
