@@ -303,6 +303,12 @@ def main():
         raise SystemExit('bench.py --gpus %d was started with WORLD_SIZE=%d' % (args.gpus, world))
     if os.environ.get('MCG_BENCH_DRYRUN') == '1':
         raise SystemExit(dry_run(args, world, rank))
+    # The contract is ONE line on stdout.  Native libraries write to file descriptor 1 behind Python's back -- RCCL prints a five-line
+    # version banner when its first communicator is created (seen in the one-rank rehearsal) -- so until the line is ready everything
+    # that goes to descriptor 1 lands on stderr.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     import mocogan_chainer_amd.hiplib as hl
@@ -537,7 +543,10 @@ def main():
         except OSError as exc:
             sys.stderr.write('bench.py: could not write %s: %r\n' % (detail_path, exc))
             detail_path = None
-        print(compact_line(out, secondary, cpu, detail_path))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(compact_line(out, secondary, cpu, detail_path), flush=True)
+        os.dup2(2, 1)
     if dp:
         dist.destroy_process_group()
 

@@ -253,6 +253,8 @@ def test_one_rank_rccl_rehearsal_of_the_bench_line():
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '2', '--batch', '4', '--no-cpu-baseline', '--secondary', '0']
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    line = json.loads(out.stdout.strip().splitlines()[-1])
+    lines = out.stdout.strip().splitlines()
+    assert len(lines) == 1, lines                # (RCCL's version banner goes to descriptor 1: bench.py keeps it off its stdout)
+    line = json.loads(lines[0])
     assert line['dist']['backend'] == 'nccl' and line['dist']['world_size'] == 1 and line['value'] > 0
     assert all(math.isfinite(v) for v in line['losses'].values()), line['losses']
