@@ -309,6 +309,7 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # (RCCL between processes needs dmabuf IPC on this driver; set before HIP starts)
     import torch
     import torch.distributed as dist
     import mocogan_chainer_amd.hiplib as hl

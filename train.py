@@ -84,6 +84,7 @@ def main(argv=None):
     from mocogan_chainer_amd import trainer as T
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # (RCCL between processes needs dmabuf IPC on this driver; before HIP starts)
     if not torch.cuda.is_available():
         raise SystemExit('train.py needs an MI355X: the HIP path has no CPU fallback (the reference\'s --gpu -1 CPU mode '
                          'is what oracle/ restates for tests)')
