@@ -208,11 +208,11 @@ def compact_line(out, secondary, cpu, detail_path):
     """The ONE stdout line: the contract fields, `config`, `roofline`, `cpu_baseline` and one short record per secondary workload --
     at most LINE_LIMIT bytes.  Per-layer tables, tile choices and the full secondary records live in DETAIL_FILE."""
     rl = out.get("roofline") or {}
-    line = {k: _round(out[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
-                                        "scaling", "vs_baseline", "dtype", "data") if k in out}
+    line = {k: _round(out[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_median",
+                                        "higher_is_better", "scaling", "vs_baseline", "dtype", "data") if k in out}
     cfg = out.get("config") or {}
-    line["config"] = {k: cfg[k] for k in ("workload", "variant", "per_gpu_batch", "global_batch", "parallelism", "side_streams", "sync_bn")
-                      if k in cfg}
+    line["config"] = {k: cfg[k] for k in ("workload", "variant", "per_gpu_batch", "global_batch", "parallelism", "side_streams", "sync_bn",
+                                          "input_ready_early") if k in cfg}
     line["roofline"] = {k: _round(rl[k]) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "kernel_ms_per_step", "traffic",
                                                    "algorithmic_bytes", "traffic_source", "algorithmic_gflop_per_step") if k in rl}
     if "by_pass" in rl:
@@ -233,8 +233,8 @@ def compact_line(out, secondary, cpu, detail_path):
         if "error" in s_:
             r["error"] = s_["error"][:160]
         else:
-            r.update(value=_round(s_["value"], 1), ms_per_step=_round(s_["ms_per_step"], 3), frac=_round(s_["roofline"]["frac"]),
-                     peak=_round(s_["roofline"]["peak"], 1))
+            r.update(value=_round(s_["value"], 1), ms_per_step=_round(s_["ms_per_step"], 3), ms_median=_round(s_.get("ms_per_step_median"), 3),
+                     frac=_round(s_["roofline"]["frac"]), peak=_round(s_["roofline"]["peak"], 1))
         sec.append(r)
     if sec:
         line["secondary"] = sec
@@ -244,19 +244,28 @@ def compact_line(out, secondary, cpu, detail_path):
     line["detail"] = os.path.basename(detail_path) if detail_path else None
     text = json.dumps(line)
     if len(text) > LINE_LIMIT:                       # never exceed the bound: drop the optional parts, longest first
-        for k in ("secondary", "losses", "dist"):
+        for k in sorted((k for k in ("secondary", "losses", "dist") if k in line), key=lambda k: -len(json.dumps(line[k]))):
             line.pop(k, None)
             text = json.dumps(line)
             if len(text) <= LINE_LIMIT:
                 break
-    assert len(text) <= LINE_LIMIT, len(text)
+    if len(text) > LINE_LIMIT:                       # still too long (a string grew): cut the long strings, keep every contract field
+        def clip(v):
+            return v[:120] if isinstance(v, str) else {k: clip(x) for k, x in v.items()} if isinstance(v, dict) else v
+        line = clip(line)
+        text = json.dumps(line)
+    if len(text) > LINE_LIMIT:                       # last resort: the contract fields and the pointer to the detail file -- a line is ALWAYS printed
+        line = {k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                     "vs_baseline", "dtype", "data", "detail") if k in line}
+        text = json.dumps(line)
     return text
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=50, help='timed iterations (BASELINE.md section 4: >= 50; `value` = all of them over the wall time, '
+                                                          'the median step time is reported beside it)')
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=32, help='clips per GPU (BASELINE config C2: 32)')
     ap.add_argument('--model', default='normal', choices=['normal', 'cgan', 'infogan'])
@@ -351,8 +360,12 @@ def main():
         if exchange is not None:                                                # ... and made identical by construction
             for net in (gen, di, dv):
                 exchange.broadcast_params([net.fp.p, net.fp.m, net.fp.v] + list(net.running.values()))
+        # input_ready_early: the batch is resident, so the next iteration's real chain may start under the end of this one -- the
+        # schedule model.updater.Updater runs too when its iterator stays a batch ahead (trainer.PrefetchIterator hands over the
+        # copy's event); MCG_INPUT_EARLY=0 switches it off.  It only matters where the two-chain schedule is on (>= 64 clips).
+        early = os.environ.get('MCG_INPUT_EARLY', '1') == '1'
         ts = mstep.TrainStep(model, gen, di, dv, exchange=exchange, seed=1234, rank=rank, precision=dtype, overlap=False,
-                              sync_bn=bool(args.sync_bn), input_ready_early=os.environ.get('MCG_INPUT_EARLY', '1') == '1')   # (the batch is resident)
+                              sync_bn=bool(args.sync_bn), input_ready_early=early)
         g = torch.Generator(device='cuda')
         g.manual_seed(rank)
         x_real = torch.rand((B, 3, 16, 64, 64), device='cuda', generator=g) * 2 - 1   # synthetic U(-1,1), resident in HBM
@@ -376,16 +389,24 @@ def main():
         # Pass 2 (headline): un-instrumented, EXACTLY `steps` iterations between barrier + synchronize, with the
         # side-stream placement unless --overlap 0.  Same kernels, same arithmetic, same results.
         ts.set_overlap(bool(overlap))
+        chains_before = mstep.chain_iterations
         # (untimed: the side streams' first iterations allocate -- blocks handed to another stream return to the caching allocator only
         #  after that stream's work, so the pools take ~10 iterations to settle; with 3 of them the batch-256 line scattered 9.9-12.1 k)
         for _ in range(max(warmup, 10) if overlap else 0):
             ts.run(x_real, t_real)
         barrier()
+        # (one event per iteration on the main stream, which joins the side streams at the end of every iteration: no host
+        #  synchronisation inside the timed region, the median step time comes from consecutive events afterwards)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         t0 = time.perf_counter()
-        for _ in range(steps):
+        marks[0].record()
+        for i in range(steps):
             ts.run(x_real, t_real)
+            marks[i + 1].record()
         barrier()
         dt_local = time.perf_counter() - t0
+        step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+        ms_median = step_ms[len(step_ms) // 2]
         tall = torch.tensor([dt_local], device='cuda', dtype=torch.float64)
         per_rank = [dt_local]
         if dp:
@@ -395,6 +416,7 @@ def main():
             dist.all_reduce(tall, op=dist.ReduceOp.MAX)
         dt_best = float(tall)
         losses = ts.losses()
+        early_used = bool(early and overlap and mstep.chain_iterations > chains_before)
         del ts, gen, di, dv, x_real
         torch.cuda.empty_cache()
         if rank != 0:
@@ -433,12 +455,13 @@ def main():
         per_rank_ms = sorted(t / steps * 1e3 for t in per_rank)
         return {
             "metric": "training clips/sec (16\u00d73\u00d764\u00d764)", "value": value, "unit": "clips/s", "n_gpus": world,
-            "steps": steps, "warmup": warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "steps": steps, "warmup": warmup, "ms_per_step": ms_per_step, "ms_per_step_median": ms_median,
+            "step_ms_min_max": [step_ms[0], step_ms[-1]], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic" + (" (single-device rehearsal)" if rehearsal else ""),
             "config": {"workload": "MUG-shape synthetic (B,3,16,64,64) U(-1,1), one update_core iteration per step "
                                    "(BASELINE.json %s)" % cfg_name, "variant": model,
                        "per_gpu_batch": B, "global_batch": B * world, "n_filters": 64, "dim_zl": 6,
-                       "parallelism": "dp%d" % world, "side_streams": bool(overlap),
+                       "parallelism": "dp%d" % world, "side_streams": bool(overlap), "input_ready_early": early_used,
                        "sync_bn": bool(args.sync_bn)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "dv_conv3d_mfma_util_pct": 100.0 * achieved / peak, "traffic": traffic,

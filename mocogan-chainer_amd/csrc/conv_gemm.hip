@@ -144,6 +144,12 @@ __device__ __forceinline__ constexpr int sw_cols(int row, int chunks_per_row) {
 #ifndef MCG_V2_M16
 #define MCG_V2_M16 1
 #endif
+#ifndef MCG_V2_EARLY             // (round 5 experiment, measured and NOT kept: 1 = the barrier of K-step s + 1 in the middle of step s and
+#define MCG_V2_EARLY 0           //  that step's first fragments read under the last MFMA group of step s; see the K loop)
+#endif
+#ifndef MCG_PROBE_HALFREADS      // (tools/probe_variant.py: the LDS-DMA GEMM with half its fragment reads -- what a body with half the
+#define MCG_PROBE_HALFREADS 0    //  LDS read bytes per FLOP could gain at most; results are garbage)
+#endif
 __device__ __forceinline__ constexpr int sw_cols16(int row, int chunks_per_row) {
     return sw_cols(row, chunks_per_row) | (MCG_V2_M16 ? ((row >> 3) & 1) << 1 : 0);
 }
@@ -1606,10 +1612,101 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
             k_nx[s] = k;
         }
     }
+    // EARLY (round 5 experiment, -DMCG_V2_EARLY=1; three-buffer rings, bf16 operands, not split): the barrier of K-step s + 1 sits in
+    // the MIDDLE of step s and the first fragments of step s + 1 are read during the last MFMA group of step s.  Idea: with the barrier
+    // at the top of a step every wave starts the step by issuing its first fragment reads and waiting for them with nothing to run
+    // meanwhile, and the other wave of the SIMD stands at the same place (the .s: barrier, eight reads, `lgkmcnt(2)`, first MFMA).
+    // MEASURED (MI355X, D_V dc2..dc4 at 512 clips, bf16-stored, 256x128 / 128x256 three-buffer tiles, alternating runs on one box,
+    // profiles/r05_early_ab.txt): forward -2 %, input gradient -1..-3 %, weight gradient +-1 % -- no gain; that latency is not what the
+    // K loop loses.  Correct (every LDS-DMA op and guard-band test passes with it) and kept as a switch.  Ring bookkeeping: the loads of step s + 2 go
+    // into the buffer of step s - 1, which every wave has finished reading when it passes the mid-step barrier of step s (its last
+    // reads of that buffer were waited for in step s - 1) -- so they are issued in the two MFMA groups BEHIND that barrier, and
+    // `vmcnt(0)` in front of the next mid-step barrier finds them a full step old.
+    constexpr bool EARLY = STAGES == 3 && !F32 && !SPLIT && MCG_V2_EARLY != 0;
+    constexpr bool TRA_ = !P::A_KC && !F32, TRB_ = !P::B_KC && !F32;   // operands read with the transposing read (inline asm)
+    // fragment registers live across K-steps (EARLY prefetches the next step's first fragments)
+    typedef typename std::conditional<F32, f32x4, bf16x8>::type frag_t;
+    bf16x8 fa16[2][M16 ? TM16 : 1], fb16[2][M16 ? HB : 1];
+    s16x4 blo16[2][M16 ? HB : 1], bhi16[2][M16 ? HB : 1];
+    frag_t fa[2][TM], fb[2][TN];
+    s16x4 alo[2][TM], ahi[2][TM], blo[2][TN], bhi[2][TN];
+    constexpr bool HR16 = MCG_PROBE_HALFREADS != 0;              // (timing ablation: half the fragment reads, results garbage)
+    constexpr int NRA16 = HR16 ? TM16 / 2 : TM16, NRB16 = (TRB_ ? 2 : 1) * HB;
+    auto reads16 = [&](auto ph_, u32 sb32) {                     // M16: the read set of phase ph = (group c, column half h)
+        constexpr int ph = decltype(ph_)::value, c = ph >> 1, h = ph & 1;
+        if constexpr (h == 0) {
+            static_for<0, TM16>([&](auto i_) {
+                constexpr int i = decltype(i_)::value;
+                if constexpr (!HR16 || (i & 1) == 0) ds128_issue<i * 2048>(fa16[c][i], sb32 + a_row16 + xk[c]);
+            });
+        }
+        if constexpr (!HR16 || h == 0)
+        static_for<0, HB>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            if constexpr (TRB_) tr16_issue<0, 4 * (BN * 2)>(blo16[h][j], bhi16[h][j], sb32 + tb16[h * HB + j] + rob[c]);
+            else ds128_issue<(h * HB + j) * 2048>(fb16[h][j], sb32 + b_row16 + xk[c]);
+        });
+    };
+    constexpr bool HR = MCG_PROBE_HALFREADS != 0 && !F32 && !SPLIT && TM >= 2 && TN >= 2;     // (timing ablation: half the fragment reads)
+    // bf16 tiles: EVERY fragment read is inline asm (see ds128_issue) and counted here; NRD = LDS reads per k chunk, in issue order
+    // A (TM rows x 1 or 2 reads) then B.  (fp32 tiles: plain loads, counted by the compiler.)
+    constexpr int NRD = F32 ? 0 : ((TRA_ ? 2 * TM : TM) + (TRB_ ? 2 * TN : TN)) / (HR ? 2 : 1);
+    auto frags = [&](auto kc_, const unsigned char* sbase, u32 sb32) {      // 32x32 MFMA: the fragments of k chunk kc
+        constexpr int kc = decltype(kc_)::value, slot = kc & 1;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            if (HR && (i & 1)) continue;
+            if constexpr (P::A_KC && F32) fa[slot][i] = *reinterpret_cast<const frag_t*>(sbase + a_row + xo[kc] + i * 4096);
+            else if constexpr (P::A_KC) {
+                if (i == 0) ds128_issue<0>(fa[slot][0], sb32 + a_row + xo[kc]);
+                else if (i == 1) ds128_issue<4096>(fa[slot][i], sb32 + a_row + xo[kc]);
+                else if (i == 2) ds128_issue<8192>(fa[slot][i], sb32 + a_row + xo[kc]);
+                else ds128_issue<12288>(fa[slot][i], sb32 + a_row + xo[kc]);
+            } else if constexpr (F32) {
+                const float* b = reinterpret_cast<const float*>(sbase) + (kc * 8 + 4 * lh) * BM + wm0 + i * 32 + li;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fa[slot][i][j] = b[j * BM];
+            } else tr16_issue<kc * 16 * (BM * 2), kc * 16 * (BM * 2) + 4 * (BM * 2)>(alo[slot][i], ahi[slot][i], sb32 + ta[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            if (HR && (i & 1)) continue;
+            if constexpr (P::B_KC && F32) fb[slot][i] = *reinterpret_cast<const frag_t*>(sbase + b_row + xo[kc] + i * 4096);
+            else if constexpr (P::B_KC) {
+                if (i == 0) ds128_issue<0>(fb[slot][0], sb32 + b_row + xo[kc]);
+                else if (i == 1) ds128_issue<4096>(fb[slot][i], sb32 + b_row + xo[kc]);
+                else if (i == 2) ds128_issue<8192>(fb[slot][i], sb32 + b_row + xo[kc]);
+                else ds128_issue<12288>(fb[slot][i], sb32 + b_row + xo[kc]);
+            } else if constexpr (F32) {
+                const float* b = reinterpret_cast<const float*>(sbase + A_BYTES) + (kc * 8 + 4 * lh) * BN + wn0 + i * 32 + li;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[slot][i][j] = b[j * BN];
+            } else tr16_issue<kc * 16 * (BN * 2), kc * 16 * (BN * 2) + 4 * (BN * 2)>(blo[slot][i], bhi[slot][i], sb32 + tb[i]);
+        }
+    };
+    // EARLY: the loads of the step two ahead in the two MFMA groups behind the mid-step barrier (half each); otherwise a quarter in
+    // front of each of the four groups
+    auto dma = [&](auto ph_, int nbuf) {
+        constexpr int ph = decltype(ph_)::value;
+        if constexpr (EARLY) {
+            if constexpr (ph == 2) { issue_part(nbuf, 0); issue_part(nbuf, 1); }
+            if constexpr (ph == 3) { issue_part(nbuf, 2); issue_part(nbuf, 3); }
+        } else issue_part(nbuf, ph);
+    };
     int buf = 0, nbuf = 0;
+    if constexpr (EARLY) {
+        if (k_cur < kend) {
+            wait_vmcnt<(STAGES - 2) * PIECES>();                 // this wave's pieces of the first step
+            __builtin_amdgcn_s_barrier();
+            if constexpr (M16) reads16(std::integral_constant<int, 0>{}, lds_addr(smem));
+            else frags(std::integral_constant<int, 0>{}, smem, lds_addr(smem));
+        }
+    }
     while (k_cur < kend) {
-        wait_vmcnt<(STAGES - 2) * PIECES>();                     // this wave's pieces of step k_cur have landed
-        __builtin_amdgcn_s_barrier();                            // ... and everyone's; everyone has finished reading the previous step
+        if constexpr (!EARLY) {
+            wait_vmcnt<(STAGES - 2) * PIECES>();                 // this wave's pieces of step k_cur have landed
+            __builtin_amdgcn_s_barrier();                        // ... and everyone's; everyone has finished reading the previous step
+        }
         {
             const int kl = k_nx[STAGES - 2];                     // the step STAGES - 1 ahead: into the buffer read one step ago
             int nb = buf + STAGES - 1; nb = nb >= STAGES ? nb - STAGES : nb;
@@ -1622,95 +1719,49 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
             k_nx[STAGES - 2] = kn;
         }
         const unsigned char* sbase = smem + buf * STAGE;
+        const int buf1 = buf + 1 == STAGES ? 0 : buf + 1;
+        const u32 sb32 = lds_addr(sbase), sb32n = lds_addr(smem + buf1 * STAGE);
         if constexpr (M16) {
             // four phases (group c, column half h): the reads of the next phase are in flight under the MFMAs of this one.  Read sets:
             // phase (c, 0) = the A blocks of group c + the B blocks of half 0, phase (c, 1) = the B blocks of half 1.  Every read is
             // inline asm (see ds128_issue) and counted here.
-            constexpr bool TRB = !P::B_KC;
-            constexpr int NRA = TM16, NRB = (TRB ? 2 : 1) * HB;
-            bf16x8 fa[2][TM16], fb[2][HB];
-            s16x4 blo[2][HB], bhi[2][HB];
-            const u32 sb32 = lds_addr(sbase);
-            auto reads = [&](auto ph_) {
-                constexpr int ph = decltype(ph_)::value, c = ph >> 1, h = ph & 1;
-                if constexpr (h == 0) {
-                    static_for<0, TM16>([&](auto i_) {
-                        constexpr int i = decltype(i_)::value;
-                        ds128_issue<i * 2048>(fa[c][i], sb32 + a_row16 + xk[c]);
-                    });
-                }
-                static_for<0, HB>([&](auto j_) {
-                    constexpr int j = decltype(j_)::value;
-                    if constexpr (TRB) tr16_issue<0, 4 * (BN * 2)>(blo[h][j], bhi[h][j], sb32 + tb16[h * HB + j] + rob[c]);
-                    else ds128_issue<(h * HB + j) * 2048>(fb[h][j], sb32 + b_row16 + xk[c]);
-                });
-            };
-            reads(std::integral_constant<int, 0>{});
+            if constexpr (!EARLY) reads16(std::integral_constant<int, 0>{}, sb32);
             static_for<0, 2 * NG>([&](auto ph_) {
                 constexpr int ph = decltype(ph_)::value, c = ph >> 1, h = ph & 1;
-                if constexpr (ph + 1 < 2 * NG) reads(std::integral_constant<int, ph + 1>{});
-                issue_part(nbuf, ph);
-                __builtin_amdgcn_sched_barrier(0);               // (keeps this quarter of the loads in front of this MFMA group)
-                constexpr int NEXT = ph + 1 < 2 * NG ? (h == 0 ? NRB : NRA + NRB) : 0;       // reads issued after the ones used now
+                if constexpr (ph + 1 < 2 * NG) reads16(std::integral_constant<int, ph + 1>{}, sb32);
+                else if constexpr (EARLY) reads16(std::integral_constant<int, 0>{}, sb32n);      // the next step's first fragments
+                dma(ph_, nbuf);
+                __builtin_amdgcn_sched_barrier(0);               // (keeps these loads in front of this MFMA group)
+                constexpr bool MORE = ph + 1 < 2 * NG || EARLY;  // reads issued after the ones used now: those of the following phase
+                constexpr int NEXT = !MORE ? 0 : (h == 0 ? (HR16 ? 0 : NRB16) : NRA16 + NRB16);
                 constexpr int YOUNGER = NEXT < 15 ? NEXT : 15;
                 if constexpr (h == 0) {
 #pragma unroll
-                    for (int i = 0; i < TM16; ++i) ds128_wait<YOUNGER>(fa[c][i]);
+                    for (int i = 0; i < TM16; i += HR16 ? 2 : 1) ds128_wait<YOUNGER>(fa16[c][i]);
                 }
+                if constexpr (!HR16 || h == 0) {
 #pragma unroll
                 for (int j = 0; j < HB; ++j) {
-                    if constexpr (TRB) fb[h][j] = tr16_wait<YOUNGER>(blo[h][j], bhi[h][j]);
-                    else ds128_wait<YOUNGER>(fb[h][j]);
+                    if constexpr (TRB_) fb16[h][j] = tr16_wait<YOUNGER>(blo16[h][j], bhi16[h][j]);
+                    else ds128_wait<YOUNGER>(fb16[h][j]);
+                }
                 }
 #pragma unroll
                 for (int i = 0; i < TM16; ++i)
 #pragma unroll
                     for (int j = 0; j < HB; ++j)
-                        acc4[i][h * HB + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[c][i], fb[h][j], acc4[i][h * HB + j], 0, 0, 0);
+                        acc4[i][h * HB + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa16[c][HR16 ? (i & ~1) : i], fb16[HR16 ? 0 : h][j], acc4[i][h * HB + j], 0, 0, 0);
+                if constexpr (EARLY && ph == 1) {
+                    __builtin_amdgcn_sched_barrier(0);           // (behind this group's MFMAs: hipcc hoisted the barrier in front of them)
+                    wait_vmcnt<0>();                             // this wave's pieces of the NEXT step (issued a step ago)
+                    __builtin_amdgcn_s_barrier();                // ... everyone's; and everyone has finished reading the previous step's buffer
+                }
             });
         } else {
         // operand fragments two deep: the reads of k chunk kc + 1 are in flight under the MFMAs of chunk kc
-        typedef typename std::conditional<F32, f32x4, bf16x8>::type frag_t;
-        constexpr bool TRA = !P::A_KC && !F32, TRB = !P::B_KC && !F32;          // operands read with the transposing read (inline asm)
-        // bf16 tiles: EVERY fragment read is inline asm (see ds128_issue) and counted here; NRD = LDS reads per k chunk, in issue order
-        // A (TM rows x 1 or 2 reads) then B.  (fp32 tiles: plain loads, counted by the compiler.)
-        constexpr int NRD = F32 ? 0 : (TRA ? 2 * TM : TM) + (TRB ? 2 * TN : TN);
-        frag_t fa[2][TM], fb[2][TN];
-        s16x4 alo[2][TM], ahi[2][TM], blo[2][TN], bhi[2][TN];
         frag_t sfa[SPLIT ? 3 : 1][TM], sfb[SPLIT ? 3 : 1][TN];
         s16x4 salo[SPLIT ? 3 : 1][TM], sahi[SPLIT ? 3 : 1][TM], sblo[SPLIT ? 3 : 1][TN], sbhi[SPLIT ? 3 : 1][TN];
-        const u32 sb32 = lds_addr(sbase);
-        auto frags = [&](auto kc_) {
-            constexpr int kc = decltype(kc_)::value, slot = kc & 1;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                if constexpr (P::A_KC && F32) fa[slot][i] = *reinterpret_cast<const frag_t*>(sbase + a_row + xo[kc] + i * 4096);
-                else if constexpr (P::A_KC) {
-                    if (i == 0) ds128_issue<0>(fa[slot][0], sb32 + a_row + xo[kc]);
-                    else if (i == 1) ds128_issue<4096>(fa[slot][i], sb32 + a_row + xo[kc]);
-                    else if (i == 2) ds128_issue<8192>(fa[slot][i], sb32 + a_row + xo[kc]);
-                    else ds128_issue<12288>(fa[slot][i], sb32 + a_row + xo[kc]);
-                } else if constexpr (F32) {
-                    const float* b = reinterpret_cast<const float*>(sbase) + (kc * 8 + 4 * lh) * BM + wm0 + i * 32 + li;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) fa[slot][i][j] = b[j * BM];
-                } else tr16_issue<kc * 16 * (BM * 2), kc * 16 * (BM * 2) + 4 * (BM * 2)>(alo[slot][i], ahi[slot][i], sb32 + ta[i]);
-            }
-#pragma unroll
-            for (int i = 0; i < TN; ++i) {
-                if constexpr (P::B_KC && F32) fb[slot][i] = *reinterpret_cast<const frag_t*>(sbase + b_row + xo[kc] + i * 4096);
-                else if constexpr (P::B_KC) {
-                    if (i == 0) ds128_issue<0>(fb[slot][0], sb32 + b_row + xo[kc]);
-                    else if (i == 1) ds128_issue<4096>(fb[slot][i], sb32 + b_row + xo[kc]);
-                    else if (i == 2) ds128_issue<8192>(fb[slot][i], sb32 + b_row + xo[kc]);
-                    else ds128_issue<12288>(fb[slot][i], sb32 + b_row + xo[kc]);
-                } else if constexpr (F32) {
-                    const float* b = reinterpret_cast<const float*>(sbase + A_BYTES) + (kc * 8 + 4 * lh) * BN + wn0 + i * 32 + li;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) fb[slot][i][j] = b[j * BN];
-                } else tr16_issue<kc * 16 * (BN * 2), kc * 16 * (BN * 2) + 4 * (BN * 2)>(blo[slot][i], bhi[slot][i], sb32 + tb[i]);
-            }
-        };
+        constexpr bool TRA = TRA_, TRB = TRB_;
         if constexpr (SPLIT) {
             static_assert(!F32, "split operands are bf16 planes");
             // all three planes of both operands, then the six products; the step's loads in front of the first four groups
@@ -1761,21 +1812,22 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sfa[pa][a], sfb[pb][b], acc[a][b], 0, 0, 0);
             });
         } else {
-        frags(std::integral_constant<int, 0>{});
+        if constexpr (!EARLY) frags(std::integral_constant<int, 0>{}, sbase, sb32);
         static_for<0, 4>([&](auto kc_) {
             constexpr int kc = decltype(kc_)::value;
-            if constexpr (kc + 1 < 4) frags(std::integral_constant<int, kc + 1>{});
-            issue_part(nbuf, kc);
-            __builtin_amdgcn_sched_barrier(0);                   // (keeps this quarter of the loads in front of this MFMA group)
-            constexpr int YOUNGER = kc + 1 < 4 ? (NRD < 15 ? NRD : 15) : 0;     // the reads of chunk kc + 1, issued after the ones used now
+            if constexpr (kc + 1 < 4) frags(std::integral_constant<int, kc + 1>{}, sbase, sb32);
+            else if constexpr (EARLY) frags(std::integral_constant<int, 0>{}, smem + buf1 * STAGE, sb32n);     // the next step's first chunk
+            dma(kc_, nbuf);
+            __builtin_amdgcn_sched_barrier(0);                   // (keeps these loads in front of this MFMA group)
+            constexpr int YOUNGER = (kc + 1 < 4 || EARLY) ? (NRD < 15 ? NRD : 15) : 0;     // the reads of the following chunk, issued after the ones used now
             if constexpr (!F32) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
+                for (int i = 0; i < TM; i += HR ? 2 : 1) {
                     if constexpr (TRA) fa[kc & 1][i] = tr16_wait<YOUNGER>(alo[kc & 1][i], ahi[kc & 1][i]);
                     else ds128_wait<YOUNGER>(fa[kc & 1][i]);
                 }
 #pragma unroll
-                for (int i = 0; i < TN; ++i) {
+                for (int i = 0; i < TN; i += HR ? 2 : 1) {
                     if constexpr (TRB) fb[kc & 1][i] = tr16_wait<YOUNGER>(blo[kc & 1][i], bhi[kc & 1][i]);
                     else ds128_wait<YOUNGER>(fb[kc & 1][i]);
                 }
@@ -1793,12 +1845,39 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
                     for (int b = 0; b < TN; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kc & 1][a], fb[kc & 1][b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kc & 1][HR ? (a & ~1) : a], fb[kc & 1][HR ? (b & ~1) : b], acc[a][b], 0, 0, 0);
+            }
+            if constexpr (EARLY && kc == 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                wait_vmcnt<0>();                                 // this wave's pieces of the NEXT step (issued a step ago)
+                __builtin_amdgcn_s_barrier();                    // ... everyone's; and everyone has finished reading the previous step's buffer
             }
         });
         }
         }
-        buf = buf + 1 == STAGES ? 0 : buf + 1;
+        buf = buf1;
+    }
+    if constexpr (EARLY) {           // the fragments read ahead for a step that does not exist: their registers stay reserved until they have landed
+        if constexpr (M16) {
+#pragma unroll
+            for (int i = 0; i < TM16; ++i) ds128_wait<0>(fa16[0][i]);
+#pragma unroll
+            for (int j = 0; j < HB; ++j) {
+                if constexpr (TRB_) fb16[0][j] = tr16_wait<0>(blo16[0][j], bhi16[0][j]);
+                else ds128_wait<0>(fb16[0][j]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if constexpr (TRA_) fa[0][i] = tr16_wait<0>(alo[0][i], ahi[0][i]);
+                else ds128_wait<0>(fa[0][i]);
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                if constexpr (TRB_) fb[0][i] = tr16_wait<0>(blo[0][i], bhi[0][i]);
+                else ds128_wait<0>(fb[0][i]);
+            }
+        }
     }
     wait_vmcnt<0>();                                             // the (dummy) loads still in flight write LDS: drain them before the
     __syncthreads();                                             // epilogue reuses the buffers

@@ -222,8 +222,19 @@ __global__ __launch_bounds__(NT) void fold_partials_kernel(int n_slots, long lon
     const int s0 = blockIdx.y * per;
     int s1 = s0 + per; if (s1 > n_slots) s1 = n_slots;
     double a = 0, b = 0;
-    if (c < C)
-        for (int sl = s0 + rl; sl < s1; sl += RL) { a += part[(long long)sl * stride + c]; b += part[(long long)sl * stride + C + c]; }
+    if (c < C) {
+        // eight slots in flight per thread (round 5): with one dependent load per trip this kernel, like the finalize kernels below,
+        // ran at memory LATENCY -- 5-8 us for a few hundred KB.  The additions keep their order (bit-identical sums).
+        int sl = s0 + rl;
+        for (; sl + 7 * RL < s1; sl += 8 * RL) {
+            float x[8], y[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { x[u] = part[(long long)(sl + u * RL) * stride + c]; y[u] = part[(long long)(sl + u * RL) * stride + C + c]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a += x[u]; b += y[u]; }
+        }
+        for (; sl < s1; sl += RL) { a += part[(long long)sl * stride + c]; b += part[(long long)sl * stride + C + c]; }
+    }
     red[0][threadIdx.x] = a; red[1][threadIdx.x] = b;
     __syncthreads();
     if (rl == 0 && c < C) {
@@ -246,8 +257,17 @@ __device__ __forceinline__ bool reduce_partials(int nblocks, int C, const float*
     const int cl = threadIdx.x % FIN_CH, sl = threadIdx.x / FIN_CH;
     c = blockIdx.x * FIN_CH + cl;
     double a = 0, b2 = 0;
-    if (c < C)
-        for (int b = sl; b < nblocks; b += FIN_SL) { a += part[(long long)b * stride + c]; b2 += part[(long long)b * stride + C + c]; }
+    if (c < C) {
+        int b = sl;
+        for (; b + 7 * FIN_SL < nblocks; b += 8 * FIN_SL) {          // eight partials in flight per thread, added in the old order
+            float x[8], y[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { x[u] = part[(long long)(b + u * FIN_SL) * stride + c]; y[u] = part[(long long)(b + u * FIN_SL) * stride + C + c]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a += x[u]; b2 += y[u]; }
+        }
+        for (; b < nblocks; b += FIN_SL) { a += part[(long long)b * stride + c]; b2 += part[(long long)b * stride + C + c]; }
+    }
     red[0][sl][cl] = a; red[1][sl][cl] = b2;
     __syncthreads();
     if (sl != 0 || c >= C) return false;

@@ -272,9 +272,13 @@ def set_autotune(on, use_pretuned=True):
     geometries at batch 32 per GPU (tuned_tiles_mi355x.json); anything else is still tuned on first use."""
     global _autotune
     _autotune = bool(on)
-    if on and use_pretuned and os.path.exists(_PRETUNED) and os.environ.get('MCG_NO_PRETUNED') != '1':
+    if use_pretuned and os.path.exists(_PRETUNED) and os.environ.get('MCG_NO_PRETUNED') != '1':
         for k, v in json.load(open(_PRETUNED)):
-            _tile_cache.setdefault(tuple(k), int(v))
+            # tuner off (train.py --autotune 0): the tile heuristic replaces the table's tile codes, but WHICH FORM a launch of an
+            # 'f32x3' network takes (split on the bf16 pipe / fp32 MFMA) has no heuristic -- those entries are loaded either way,
+            # otherwise such a network would silently run every GEMM on the fp32 kernels (round 4's advice)
+            if on or str(k[0]).startswith('split-'):
+                _tile_cache.setdefault(tuple(k), int(v))
 
 
 def reset_tuning():
@@ -344,6 +348,9 @@ def split_decided(kind, g):
     return _tile_cache.get(_geom_key('split-' + kind, g)) == 1
 
 
+_warned_undecided_split = False
+
+
 def split_pays(kind, g, run_plain, run_split):
     """Which of the two forms of a launch is faster for this geometry -- the fp32-MFMA kernels on fp32 operands (run_plain) or the
     split form on the bf16 pipe (run_split, INCLUDING whatever it takes to produce the split operands)?  Timed once per (pass,
@@ -355,8 +362,16 @@ def split_pays(kind, g, run_plain, run_split):
     key = _geom_key('split-' + kind, g)
     c = _tile_cache.get(key)
     if c is None and not _autotune:
-        return False                # tuner off (tests, train.py --autotune 0): nothing is timed -- the table's entries, else the fp32 form.
-                                    # (Under data parallelism per-rank timing could also leave the ranks on different forms.)
+        # tuner off (tests, train.py --autotune 0): nothing is timed -- the table's entries, else the fp32 form.
+        # (Under data parallelism per-rank timing could also leave the ranks on different forms.)
+        global _warned_undecided_split
+        if not _warned_undecided_split:
+            _warned_undecided_split = True
+            import warnings
+            warnings.warn("precision 'f32x3': the tile tuner is off and the table holds no decision for %s N=%d T=%d H=%d Ci=%d Co=%d -- "
+                          "this launch (and every other undecided one) runs the fp32-MFMA form; hiplib.set_autotune(True), "
+                          "MCG_SPLIT=always or a loaded tile table decide it" % (kind, g.N, g.Ti, g.Hi, g.Ci, g.Co))
+        return False
     if c is None:
         global _timing
         saved, _timing = _timing, None

@@ -188,9 +188,13 @@ class TrainStep:
         return (it * cls.MAX_RANKS + rank + 1) * cls.STREAMS_PER_RANK
 
     # ---- one iteration -------------------------------------------------------------------------
-    def run(self, x_real, t_real=None, inject=None):
+    def run(self, x_real, t_real=None, inject=None, input_event=None):
         """x_real: device tensor in the reference layout (N,C,T,H,W) (model/updater.py:89-90).
         t_real: int32 device tensor (N,) or None.
+        input_event: an event recorded (on whatever stream produced x_real -- a loader's copy stream) when x_real was complete; the
+        caller's current stream must be ordered behind it as well.  With it the two-chain schedule starts the VideoDiscriminator's
+        real chain as soon as that event and the previous iteration's Adam(D_V) have happened, beside the end of the previous
+        iteration (what `input_ready_early` promises for resident data, here per call and checked by the hardware).
         inject: parity mode -- dict with 't', 'noise_{i,v}_{real,fake}' (lists of 4 device tensors in
         device layout, pre-scaled) and 'gen' (latent draw dict); None = perf mode (Philox in-kernel,
         frame index from a seeded host generator shared by all ranks, quirk Q7)."""
@@ -240,8 +244,10 @@ class TrainStep:
         # (not for 'f32x3': measured 2-3 % SLOWER at 32 / 64 / 128 clips -- its launches are tuned, form by form, at the 2n batch)
         if CHAINS and self.side is not None and ex is None and dv.sync_bn is None and dv.precision != 'f32x3' and n >= CHAINS_MIN_N:
             cs = self._chain_stream
-            if self.input_ready_early and self._ev_dv_updated is not None and not cgan:
-                cs.wait_event(self._ev_dv_updated)                   # the previous iteration's Adam(D_V); x_real is ready by contract
+            if (self.input_ready_early or input_event is not None) and self._ev_dv_updated is not None and not cgan:
+                cs.wait_event(self._ev_dv_updated)                   # the previous iteration's Adam(D_V)
+                if input_event is not None:
+                    cs.wait_event(input_event)                       # x_real (otherwise ready by contract)
             else:
                 cs.wait_stream(main)                                 # x_real (and whatever produced it)
             with torch.cuda.stream(cs), self._dv_chains[0]:

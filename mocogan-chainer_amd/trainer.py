@@ -219,9 +219,11 @@ class PrefetchIterator(SerialIterator):
 
     __next__ = next
 
-    def next_device_batch(self, device):
+    def next_device_batch(self, device, with_event=False):
         """-> (x_real float32 (N,C,T,H,W) on `device`, labels list).  The H2D copy runs from pinned memory on a
-        side stream; the caller's stream waits for it."""
+        side stream; the caller's stream waits for it.  with_event: also returns the event recorded on the copy stream when the
+        batch was complete -- `TrainStep.run(input_event=...)` lets a stream that needs nothing but the batch (the
+        VideoDiscriminator's real chain) wait for exactly that instead of for everything queued on the caller's stream."""
         import torch
         videos, labels = self._pop()
         if self._copy_stream is None:
@@ -232,9 +234,12 @@ class PrefetchIterator(SerialIterator):
             dev = host.to(device, non_blocking=True)
             if self._raw:
                 dev = ((dev.float() - 128.) / 128.).permute(0, 4, 1, 2, 3).contiguous()     # (N,T,H,W,C) u8 -> (N,C,T,H,W)
+            ready = torch.cuda.Event() if with_event else None
+            if ready is not None:
+                ready.record(self._copy_stream)
         cur.wait_stream(self._copy_stream)
         dev.record_stream(cur)
-        return dev, labels
+        return (dev, labels, ready) if with_event else (dev, labels)
 
     def close(self):
         self._pool.shutdown(wait=False, cancel_futures=True)

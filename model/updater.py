@@ -122,8 +122,9 @@ class Updater:
     # ---- one iteration ---------------------------------------------------------------------------
     def update_core(self):
         it = self.get_iterator('main')
-        if hasattr(it, 'next_device_batch'):                                         # prefetching loader: uint8 from
-            x_real, labels = it.next_device_batch(self._step.device)                 # pinned memory, normalised on the GPU
+        ready = None
+        if hasattr(it, 'next_device_batch'):                                         # prefetching loader: uint8 from pinned memory on
+            x_real, labels, ready = it.next_device_batch(self._step.device, with_event=True)    # a copy stream, normalised on the GPU
         else:
             batch = it.next()
             labels = [b[1] for b in batch]
@@ -141,7 +142,8 @@ class Updater:
                 self._pin_evt = torch.cuda.Event()
                 self._pin_evt.record()
         t_real = None if labels[0] is None else torch.as_tensor(np.asarray(labels, dtype=np.int32)).to(self._step.device)
-        self._step.run(x_real, t_real)
+        # (the loader is a batch ahead: its copy's event lets the two-chain schedule start the next real chain under this iteration's tail)
+        self._step.run(x_real, t_real, input_event=ready)
         if self.is_new_epoch:
             l = self._step.losses()
             self.observation = dict(l)

@@ -23,8 +23,8 @@ def repo_root():
 # layers, the API surface), then the op-level oracle tests, then the guard-band runs, and the self-comparison / bit-identity tests
 # last -- a failure among the latter must not hide the oracle tests behind it (round 3's driver run: 137 tests unreached).
 _GPU_MODULE_ORDER = ["test_gpu_golden", "test_gpu_step", "test_gpu_fullwidth", "test_gpu_api", "test_gpu_cabi_host", "test_gpu_dp",
-                     "test_gpu_ops", "test_gpu_guardband", "test_gpu_properties"]
-_LAST = ("test_bf16_stored_operands_equal_rounding_in_the_kernel",)
+                     "test_gpu_ops", "test_gpu_guardband", "test_gpu_properties", "test_gpu_watch"]
+_LAST = ("test_bf16_stored_operands_equal_rounding_in_the_kernel", "test_round3_weight_gradient_pair_repeated_against_the_oracle")
 
 
 def pytest_collection_modifyitems(config, items):

@@ -28,9 +28,10 @@ class _Rendezvous(Exception):
     pass
 
 
-def emulate(nets, shards, model='normal', dim_zl=0):
+def emulate(nets, shards, model='normal', dim_zl=0, grads_out=None):
     """-> (gen, di, dv) parameter dicts after ONE data-parallel iteration over the shards, computed in one
-    process: update_core is re-run per phase with the averaged gradients of the earlier phases injected."""
+    process: update_core is re-run per phase with the averaged gradients of the earlier phases injected.
+    grads_out (a dict): receives the averaged gradients, {'image_dis' | 'video_dis' | 'image_gen': {parameter name: array}}."""
     gen, di, dv = nets
     world = len(shards)
     store, avg = {}, {}
@@ -58,4 +59,6 @@ def emulate(nets, shards, model='normal', dim_zl=0):
                 pass
         if phase is not None:
             avg[phase] = {k: sum(store[phase][r][k] for r in range(world)) / world for k in store[phase][0]}
+    if grads_out is not None:
+        grads_out.update(avg)
     return finals[0]

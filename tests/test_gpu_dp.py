@@ -82,21 +82,35 @@ def _run_ranks(sync_bn, port_base, precision='f32', nf=NF, backend='gloo', world
     return res
 
 
-def _update_errors(res, nets, ref):
+UPDATE_TOL = 1e-3       # measured 1.5e-4 .. 2e-4 (rounds 3-4); round 4's review: 1e-2 left 60x of slack
+
+
+def _update_errors(res, nets, ref, grads=None):
+    """Worst relative error of the parameter UPDATE (parameters move by ~alpha per step) of rank 0 against the oracle, every tensor
+    held to UPDATE_TOL.  grads: the oracle's (averaged) gradients {'image_gen' | 'image_dis' | 'video_dis': {name: array}}.  Adam's
+    first step with beta1 = 5e-5 is sign-like: an element whose gradient (incl. the WeightDecay term) is within the device / oracle
+    difference of zero may step the other way -- an O(alpha) difference no tolerance on the gradient excludes -- so, as in
+    test_gpu_step.check_params, elements with |g| below 1e-3 of the tensor's rms are left out of the norm."""
     worst = 0.0
+    gname = {'gen': 'image_gen', 'di': 'image_dis', 'dv': 'video_dis'}
     for name, refp in zip(('gen', 'di', 'dv'), ref):
         for k, v in refp.items():
             if 'avg_' in k or k.endswith('/N') or v.dtype.kind != 'f':
                 continue
             got = res[0][1][name][k].astype(np.float64)
-            base = nets[('gen', 'di', 'dv').index(name)][k]     # parameters move by ~alpha per step: compare the UPDATE
+            base = nets[('gen', 'di', 'dv').index(name)][k]
             du, dr = got - base, v - base
             if np.abs(dr).max() < 1e-12:
                 continue
+            if grads is not None and k in grads.get(gname[name], {}):
+                gt = np.asarray(grads[gname[name]][k], np.float64) + 1e-5 * base          # WeightDecay(1e-5) hook (train.py:96)
+                keep = np.abs(gt) > 1e-3 * np.sqrt(np.mean(gt * gt))
+                if keep.sum() == 0:
+                    continue
+                du, dr = du[keep], dr[keep]
             err = np.linalg.norm(du - dr) / max(np.linalg.norm(dr), 1e-30)
             worst = max(worst, err)
-            assert err < 1e-2, (name, k, err)             # measured ~2e-4; Adam's first step is sign-like, so a gradient
-                                                          # element within rounding of 0 may move by 2*alpha
+            assert err < UPDATE_TOL, (name, k, err)
     return worst
 
 
@@ -126,8 +140,9 @@ def test_two_rank_synchronised_batchnorm_matches_the_global_batch_oracle():
     for k in ('noise_i_real', 'noise_v_real', 'noise_i_fake', 'noise_v_fake'):
         rnd[k] = [np.concatenate((a, b)) for a, b in zip(r0[k], r1[k])]
     og, oi, ov = (oupd.new_adam_state(p) for p in (gen, di, dv))
-    oupd.update_core(MODEL, gen, di, dv, og, oi, ov, x, np.zeros(2 * N, dtype=np.int64), rnd, dim_zl=DIM_ZL, q1_rows=[0, N])
-    print('sync-BN worst relative update error', _update_errors(res, base, (gen, di, dv)))
+    o = oupd.update_core(MODEL, gen, di, dv, og, oi, ov, x, np.zeros(2 * N, dtype=np.int64), rnd, dim_zl=DIM_ZL, q1_rows=[0, N], keep=True)
+    grads = {'image_gen': o['grads_gen'], 'image_dis': o['grads_dis_i'], 'video_dis': o['grads_dis_v']}
+    print('sync-BN worst relative update error', _update_errors(res, base, (gen, di, dv), grads))
     for name, p in (('gen', gen), ('di', di), ('dv', dv)):
         for k, v in p.items():
             if 'avg_' in k:
@@ -157,10 +172,11 @@ def test_two_rank_hip_step_matches_the_sharded_oracle():
         return orig(model, gen, di, dv, og, oi, ov, x, np.zeros(N, dtype=np.int64), rnd, **kw)
     oupd.update_core = with_labels
     try:
-        ref = dp_common.emulate(nets, shards, model=MODEL, dim_zl=DIM_ZL)
+        avg = {}
+        ref = dp_common.emulate(nets, shards, model=MODEL, dim_zl=DIM_ZL, grads_out=avg)
     finally:
         oupd.update_core = orig
-    worst = _update_errors(res, nets, ref)
+    worst = _update_errors(res, nets, ref, avg)
     print('worst relative update error', worst)
 
 
@@ -218,10 +234,11 @@ def test_two_rank_rccl_matches_the_sharded_oracle():
     oupd.update_core = lambda model, gen, di, dv, og, oi, ov, x, t_real, rnd, **kw: orig(
         model, gen, di, dv, og, oi, ov, x, np.zeros(N, dtype=np.int64), rnd, **kw)
     try:
-        ref = dp_common.emulate(nets, shards, model=MODEL, dim_zl=DIM_ZL)
+        avg = {}
+        ref = dp_common.emulate(nets, shards, model=MODEL, dim_zl=DIM_ZL, grads_out=avg)
     finally:
         oupd.update_core = orig
-    print('RCCL: worst relative update error', _update_errors(res, nets, ref))
+    print('RCCL: worst relative update error', _update_errors(res, nets, ref, avg))
 
 
 def test_one_rank_rccl_matches_the_oracle():
@@ -237,10 +254,11 @@ def test_one_rank_rccl_matches_the_oracle():
     oupd.update_core = lambda model, gen, di, dv, og, oi, ov, x, t_real, rnd, **kw: orig(
         model, gen, di, dv, og, oi, ov, x, np.zeros(N, dtype=np.int64), rnd, **kw)
     try:
-        ref = dp_common.emulate(nets, shards, model=MODEL, dim_zl=DIM_ZL)
+        avg = {}
+        ref = dp_common.emulate(nets, shards, model=MODEL, dim_zl=DIM_ZL, grads_out=avg)
     finally:
         oupd.update_core = orig
-    print('RCCL, one rank: worst relative update error', _update_errors(res, nets, ref))
+    print('RCCL, one rank: worst relative update error', _update_errors(res, nets, ref, avg))
 
 
 def test_one_rank_rccl_rehearsal_of_the_bench_line():

@@ -1,0 +1,115 @@
+// Hardware probe (gfx950): what rate of LDS-DMA fills (buffer_load_dwordx4 ... lds, 1 KiB per wave-instruction) does a CU sustain
+// from an L2-resident source -- alone, beside ds_read_b128 traffic, beside bf16 MFMAs, and beside both -- with 4, 8 or 16 waves per CU?
+// The LDS-DMA GEMM kernels (gemm_bf16_v2_kernel) land at 8-10 TB/s of fills whatever their tile; this says whether that is the
+// fill path's own ceiling or what the fragment reads / the MFMA stream leave of it, i.e. what a body with half the LDS read bytes per
+// FLOP (4 waves x 128x128 outputs) could gain at most.  Per piece a wave issues R ds_read_b128 and M v_mfma_f32_32x32x16_bf16:
+//   256x256x64 tile, 8 waves: 64 pieces, 192 reads, 256 MFMAs per K-step  -> R = 3, M = 4
+//   256x128x64 tile, 8 waves: 48 pieces, 128 reads, 128 MFMAs             -> R = 2.67, M = 2.67
+//   256x256x64 tile, 4 waves of 128x128: 64 pieces, 128 reads, 256 MFMAs  -> R = 2, M = 4
+//   hipcc --offload-arch=gfx950 -O3 tools/lds_fill_probe.hip -o /tmp/lds_fill_probe && /tmp/lds_fill_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+typedef unsigned int u32;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define LDSP(p) ((__attribute__((address_space(3))) void*)(p))
+
+template <int WAVES, int R, int M, int INFLIGHT>
+__global__ __launch_bounds__(WAVES * 64) void fill(const unsigned char* src, u32 kib, int iters, float* sink, unsigned long long* clk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned char* mine = smem + wave * (8 * 1024);                       // 8 KiB per wave: a ring of eight 1-KiB pieces
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(src), 0, kib * 1024u, 0x00020000);
+    const u32 la = (u32)(size_t)(const __attribute__((address_space(3))) void*)mine + lane * 16;
+    bf16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.37f + 0.01f * ((lane * 7 + i) & 31)); b[i] = (__bf16)(-0.61f + 0.02f * ((lane * 3 + i) & 15)); }
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    bf16x8 d[4];
+    for (int i = 0; i < 4; ++i) d[i] = a;
+    u32 piece = (blockIdx.x * 977u + wave * 131u) % kib;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDSP(mine + (it & 7) * 1024), 16, piece * 1024u + lane * 16u, 0, 0, 0);
+        piece += 61u; piece = piece >= kib ? piece - kib : piece;
+        if constexpr (R > 0) {
+#pragma unroll
+            for (int q = 0; q < R; ++q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(d[q & 3]) : "v"(la), "n"((q & 7) * 1024));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < M; ++q) acc[q & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[q & 3], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (R > 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(INFLIGHT) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) s += acc[i][j];
+    for (int i = 0; i < 4; ++i) s += (float)d[i][0];
+    if (s == 12345.678f) sink[0] = s;                                     // (keeps everything alive)
+}
+
+template <int WAVES, int R, int M, int INFLIGHT = 6>
+void run(const unsigned char* src, u32 kib, float* sink, unsigned long long* clk, const char* what) {
+    const int iters = 4096, blocks = 256;
+    const size_t lds = 128 * 1024;                                         // > half the LDS: ONE workgroup per CU (16 waves use all of it)
+    auto k = fill<WAVES, R, M, INFLIGHT>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int rep = 0; rep < 5; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(WAVES * 64), lds, 0, src, kib, iters, sink, clk);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (rep > 0 && ms < best) best = ms;
+    }
+    std::vector<unsigned long long> h(2 * blocks);
+    hipMemcpy(h.data(), clk, h.size() * 8, hipMemcpyDeviceToHost);
+    std::vector<double> cyc, ghz;
+    for (int b = 0; b < blocks; ++b) { cyc.push_back((double)h[2 * b]); ghz.push_back((double)h[2 * b] / ((double)h[2 * b + 1] * 10.0)); }
+    std::sort(cyc.begin(), cyc.end()); std::sort(ghz.begin(), ghz.end());
+    const double bytes = (double)blocks * WAVES * iters * 1024.0;
+    const double per_cu_cyc = (double)WAVES * iters * 1024.0 / cyc[blocks / 2];
+    // matrix-pipe share by WALL time: MFMA cycles of one SIMD (WAVES / 4 waves x M x 32 cycles per piece) over the kernel's cycles at
+    // the clock the blocks report (the slowest block ends the launch)
+    const double mfma_frac = M ? ((double)(WAVES / 4) * iters * M * 32.0) / (best * 1e-3 * ghz[blocks / 2] * 1e9) : 0.0;
+    printf("%-44s waves %2d R %d M %d inflight %d: %7.3f ms  %6.2f TB/s  %5.1f B/clk/CU  clock %.2f GHz  cyc/piece/wave (median block) %6.1f  mfma pipe (wall) %.2f\n",
+           what, WAVES, R, M, INFLIGHT, best, bytes / best * 1e-9, per_cu_cyc, ghz[blocks / 2], cyc[blocks / 2] / iters, mfma_frac);
+}
+
+int main() {
+    const u32 kib = 2048;                                                 // 2 MiB source: resident in every XCD's 4 MiB L2
+    unsigned char* src; float* sink; unsigned long long* clk;
+    hipMalloc(&src, (size_t)kib * 1024); hipMalloc(&sink, 64); hipMalloc(&clk, 8 * 1024);
+    std::vector<unsigned short> h((size_t)kib * 512);
+    srand(1);
+    for (auto& v : h) v = (unsigned short)(0x3c00 + (rand() & 0x3ff) + ((rand() & 1) << 15));   // bf16 of magnitude ~1, random sign
+    hipMemcpy(src, h.data(), (size_t)kib * 1024, hipMemcpyHostToDevice);
+    run<8, 0, 0>(src, kib, sink, clk, "fills alone");
+    run<4, 0, 0>(src, kib, sink, clk, "fills alone");
+    run<16, 0, 0>(src, kib, sink, clk, "fills alone");
+    run<8, 0, 0, 2>(src, kib, sink, clk, "fills alone, 2 in flight per wave");
+    run<8, 3, 0>(src, kib, sink, clk, "fills + reads (256x256, 8 waves)");
+    run<8, 2, 0>(src, kib, sink, clk, "fills + reads");
+    run<4, 2, 0>(src, kib, sink, clk, "fills + reads (fat body)");
+    run<8, 0, 4>(src, kib, sink, clk, "fills + MFMAs (256x256, 8 waves)");
+    run<4, 0, 4>(src, kib, sink, clk, "fills + MFMAs (fat body)");
+    run<8, 3, 4>(src, kib, sink, clk, "fills + reads + MFMAs: 256x256, 8 waves");
+    run<8, 2, 4>(src, kib, sink, clk, "  ... with 2 reads per piece");
+    run<8, 1, 4>(src, kib, sink, clk, "  ... with 1 read per piece");
+    run<4, 2, 4>(src, kib, sink, clk, "fills + reads + MFMAs: fat body (4 x 128x128)");
+    run<4, 3, 4>(src, kib, sink, clk, "  ... with 3 reads per piece");
+    run<8, 3, 3>(src, kib, sink, clk, "256x128, 8 waves (R 2.67 M 2.67 rounded up)");
+    run<8, 3, 8>(src, kib, sink, clk, "twice the MFMAs per piece (a 512x512 tile)");
+    run<4, 2, 8>(src, kib, sink, clk, "twice the MFMAs per piece, 4 waves");
+    run<8, 0, 8>(src, kib, sink, clk, "MFMAs + fills, no reads, M 8");
+    return 0;
+}

@@ -62,7 +62,10 @@ def parse_args(argv=None):
     p.add_argument('--dp_shard', type=int, default=1,
                    help="data parallel: 1 (default) = rank r trains on items r, r + world, ... (an epoch of all ranks is one pass over "
                         "the data); 0 = every rank walks the whole dataset in its own order (an epoch is world passes)")
-    p.add_argument('--autotune', type=int, default=1, help="time the GEMM tile candidates once per layer geometry")
+    p.add_argument('--autotune', type=int, default=1,
+                   help="1: time the GEMM tile candidates once per layer geometry not in the shipped table; 0: the library's tile "
+                        "heuristic, and for --mfma f32x3 only the shipped table's split / fp32 decisions (geometries it does not "
+                        "hold run the fp32-MFMA form; a warning says so once)")
     p.add_argument('--sync_bn', type=int, default=0,
                    help="data parallel only: 1 = BatchNorm statistics over the global batch (all-reduced sums) instead of per rank")
     p.add_argument('--loader_workers', type=int, default=0,
