@@ -57,6 +57,31 @@ def worker_load(indices, raw, batch_no, chunk_no):
     return load_examples(_WORKER['dataset'], indices, raw)
 
 
+_SHM = {}
+
+
+def worker_load_shm(indices, batch_no, chunk_no, shm_name, first, clip_shape):
+    """As worker_load(raw=True), but the decoded uint8 frames go straight into clips [first, first + len(indices)) of the shared-memory
+    segment `shm_name` (one batch slot of trainer.PrefetchIterator) instead of back through the result pipe -- at 256 clips per batch
+    the pickled results (50 MB per batch) were what the loader spent its time on.  Returns the labels only."""
+    np.random.seed((int(_WORKER['seed']) * 1000003 + batch_no * 131 + chunk_no) % (2 ** 32))
+    shm = _SHM.get(shm_name)
+    if shm is None:
+        from multiprocessing import shared_memory
+        # (spawned workers share the parent's resource tracker: attaching re-registers the same name there, nothing is unlinked
+        #  when a worker exits; the parent unlinks in PrefetchIterator.close())
+        shm = shared_memory.SharedMemory(name=shm_name)
+        _SHM[shm_name] = shm
+    per = int(np.prod(clip_shape))
+    arr = np.ndarray((shm.size // per,) + tuple(clip_shape), dtype=np.uint8, buffer=shm.buf)
+    labels = []
+    for k, i in enumerate(indices):
+        v, l = _WORKER['dataset'].get_example_raw(int(i))
+        arr[first + k] = v
+        labels.append(l)
+    return labels
+
+
 class _FrameDirDataset:
     video_length = 16
     channels = 3            # 1: keep only the first colour plane (the grey-scale Moving-MNIST shape 16x1x64x64)

@@ -131,7 +131,7 @@ __device__ __forceinline__ f32x4 bload_s(__amdgpu_buffer_rsrc_t r, u32 lane_off,
 // through the load's scalar offset operand -- ~15 instead of ~35 vector instructions (several of them quarter-rate integer
 // multiplies) per K-step.  The bf16 kernels use it: their MFMA is 16x faster, and at 12 vector instructions per MFMA
 // (PMC, dc2's input gradient) the loaders, not the matrix pipe, set their pace.  The fp32 kernels do not: there the same
-// change made every launch 0.5-6 % faster on one stream and the side-stream iteration 2 % slower (section 3 of DESIGN.md).
+// change made every launch 0.5-6 % faster on one stream and the side-stream iteration 2 % slower (profiles/NOTES.md, section 3 of the old DESIGN.md).
 // (SW, tiles kept in global orientation [k][cols], read with ds_read_b64_tr_b16: the 16-byte column chunk a thread loads is
 // XOR-swizzled by its k row -- sw_cols -- so that the four k rows of a transposed-read block fall into different banks)
 __device__ __forceinline__ constexpr int sw_cols(int row, int chunks_per_row) {
@@ -1461,6 +1461,10 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
     const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+#ifdef MCG_STAMPS
+    unsigned long long tv_start = 0;
+    MCG_T(tv_start);
+#endif
     int bx, by, bz;
     {   // XCD-aware tile mapping, as in gemm_kernel
         const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
@@ -1694,6 +1698,10 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
         } else issue_part(nbuf, ph);
     };
     int buf = 0, nbuf = 0;
+#ifdef MCG_STAMPS                // (diagnostic build, tools/stamp_phases_v2.py: where a wave's cycles go; the shares are meaningful, the run time is not)
+    unsigned long long tv0 = 0, tv1 = 0, tv2 = 0, tv3 = 0, av_vm = 0, av_bar = 0, av_body = 0, av_steps = 0, tv_loop = 0;
+    MCG_T(tv_loop);
+#endif
     if constexpr (EARLY) {
         if (k_cur < kend) {
             wait_vmcnt<(STAGES - 2) * PIECES>();                 // this wave's pieces of the first step
@@ -1704,8 +1712,11 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
     }
     while (k_cur < kend) {
         if constexpr (!EARLY) {
+            MCG_T(tv0);
             wait_vmcnt<(STAGES - 2) * PIECES>();                 // this wave's pieces of step k_cur have landed
+            MCG_T(tv1);
             __builtin_amdgcn_s_barrier();                        // ... and everyone's; everyone has finished reading the previous step
+            MCG_T(tv2);
         }
         {
             const int kl = k_nx[STAGES - 2];                     // the step STAGES - 1 ahead: into the buffer read one step ago
@@ -1856,7 +1867,15 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
         }
         }
         buf = buf1;
+#ifdef MCG_STAMPS
+        MCG_T(tv3);
+        av_vm += tv1 - tv0; av_bar += tv2 - tv1; av_body += tv3 - tv2; av_steps += 1;
+#endif
     }
+#ifdef MCG_STAMPS
+    unsigned long long tv_end = 0;
+    MCG_T(tv_end);
+#endif
     if constexpr (EARLY) {           // the fragments read ahead for a step that does not exist: their registers stay reserved until they have landed
         if constexpr (M16) {
 #pragma unroll
@@ -1912,6 +1931,18 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
                     else p.store(m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, n0 + wn0 + b * 32 + li, acc[a][b][r]);
                 }
     }
+#ifdef MCG_STAMPS
+    {
+        unsigned long long tv_done = 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the stores have left: the epilogue's own time)
+        MCG_T(tv_done);
+        if (lane == 0) {
+            atomicAdd(&g_stamp[0], av_vm); atomicAdd(&g_stamp[1], av_bar); atomicAdd(&g_stamp[2], av_body);
+            atomicAdd(&g_stamp[3], tv_loop - tv_start); atomicAdd(&g_stamp[4], 1ull); atomicAdd(&g_stamp[5], tv_done - tv_end);
+            atomicAdd(&g_stamp[6], av_steps); atomicAdd(&g_stamp[7], tv_done - tv_start);
+        }
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------

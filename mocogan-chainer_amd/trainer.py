@@ -127,23 +127,43 @@ class PrefetchIterator(SerialIterator):
                                             initializer=_ds.worker_init, initargs=(seed, dataset))
         self._depth, self._chunk, self._queue, self._batch_no = prefetch, chunk, [], 0
         self._copy_stream = None
+        # raw (uint8) datasets: the workers write the decoded frames into shared-memory batch slots and return only the labels
+        # (MCG_LOADER_SHM=0: back through the result pipes, as before round 5)
+        self._slots, self._free_slots, self._clip_shape = [], [], None
+        if self._raw and os.environ.get('MCG_LOADER_SHM', '1') == '1':
+            from multiprocessing import shared_memory
+            st = np.random.get_state()                                # (a dataset may draw sub-sequence offsets: the order stays SerialIterator's)
+            self._clip_shape = tuple(np.asarray(dataset.get_example_raw(0)[0]).shape)
+            np.random.set_state(st)
+            nbytes = batch_size * int(np.prod(self._clip_shape))
+            for k in range(prefetch + 2):
+                shm = shared_memory.SharedMemory(create=True, size=nbytes, name='mcg_%d_%x_%d' % (os.getpid(), id(self) & 0xffffff, k))
+                self._slots.append((shm, np.ndarray((batch_size,) + self._clip_shape, dtype=np.uint8, buffer=shm.buf)))
+            self._free_slots = list(range(len(self._slots)))
         super().__init__(dataset, batch_size, repeat, shuffle)
+
+    def _drop_queue(self):
+        """forget the look-ahead: cancel what has not started, wait for what is running (it writes into a slot), free the slots"""
+        for _, futs, slot in getattr(self, '_queue', []):
+            for f in futs:
+                if not f.cancel():
+                    try:
+                        f.result()
+                    except Exception:
+                        pass
+            if slot is not None:
+                self._free_slots.append(slot)
+        self._queue = []
 
     def reset(self):
         super().reset()
-        for _, futs in getattr(self, '_queue', []):
-            for f in futs:
-                f.cancel()
-        self._queue = []
+        self._drop_queue()
         self._head = self._state()
 
     def load_state(self, epoch, current_position, order=None, is_new_epoch=None, previous_epoch_detail=None):
         """As SerialIterator.load_state; the look-ahead (batches already queued from the old position) is dropped
         and restarts from the restored position."""
-        for _, futs in self._queue:
-            for f in futs:
-                f.cancel()
-        self._queue = []
+        self._drop_queue()
         super().load_state(epoch, current_position, order, is_new_epoch, previous_epoch_detail)
         self._head = self._state()
 
@@ -192,22 +212,45 @@ class PrefetchIterator(SerialIterator):
             idx = self._advance()
             if idx is None:
                 break
-            futs = [self._pool.submit(_ds.worker_load, idx[c:c + self._chunk], self._raw, self._batch_no, c)
-                    for c in range(0, len(idx), self._chunk)]
+            slot = None
+            if self._slots and len(idx) <= self.batch_size:
+                slot = self._free_slots.pop()
+                futs = [self._pool.submit(_ds.worker_load_shm, idx[c:c + self._chunk], self._batch_no, c, self._slots[slot][0].name, c,
+                                          self._clip_shape) for c in range(0, len(idx), self._chunk)]
+            else:
+                futs = [self._pool.submit(_ds.worker_load, idx[c:c + self._chunk], self._raw, self._batch_no, c)
+                        for c in range(0, len(idx), self._chunk)]
             self._batch_no += 1
-            self._queue.append((self._state(), futs))
+            self._queue.append((self._state(), futs, slot))
         self._head = self._state()
         self._set_state(user)
 
-    def _pop(self):
+    def _pop(self, out=None):
+        """out: a callable (shape, dtype) -> NumPy array the batch is assembled IN (a pinned staging buffer), or None"""
         self._fill()
         if not self._queue:
             raise StopIteration
-        st, futs = self._queue.pop(0)
+        st, futs, slot = self._queue.pop(0)
         parts = [f.result() for f in futs]
         self._set_state(st)                                           # what SerialIterator shows after this batch
+        if slot is not None:                                          # the frames are in the batch slot; the workers returned the labels
+            labels = [l for p in parts for l in p]
+            view = self._slots[slot][1][:len(labels)]
+            if out is not None:
+                videos = out(view.shape, view.dtype)
+                np.copyto(videos, view)
+            else:
+                videos = view.copy()
+            self._free_slots.append(slot)
+            self._fill()
+            return videos, labels
         self._fill()
-        videos = np.concatenate([p[0] for p in parts])
+        arrs = [p[0] for p in parts]
+        if out is not None:
+            shape = (sum(a.shape[0] for a in arrs),) + arrs[0].shape[1:]
+            videos = np.concatenate(arrs, out=out(shape, arrs[0].dtype))
+        else:
+            videos = np.concatenate(arrs)
         labels = [l for p in parts for l in p[1]]
         return videos, labels
 
@@ -225,13 +268,30 @@ class PrefetchIterator(SerialIterator):
         batch was complete -- `TrainStep.run(input_event=...)` lets a stream that needs nothing but the batch (the
         VideoDiscriminator's real chain) wait for exactly that instead of for everything queued on the caller's stream."""
         import torch
-        videos, labels = self._pop()
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream(device=device)
-        host = torch.from_numpy(videos).pin_memory()
+            self._pin, self._pin_free, self._pin_i = [None] * 3, [None] * 3, 0
+        # A ring of three PINNED staging buffers, allocated once: the batch is assembled in one of them and copied from there.
+        # (Round 5, found by timing the product path -- tools/bench_train.py: `torch.from_numpy(videos).pin_memory()` allocated and
+        # freed pinned memory every iteration, and freeing pinned memory waits for the device -- 35-40 ms per batch whatever its
+        # size, the loader SLOWER than the serial loop: 900 against 1900 clips/s at batch 32.)
+        i = self._pin_i = (self._pin_i + 1) % 3
+
+        def staging(shape, dtype):
+            t = self._pin[i]
+            tdt = torch.from_numpy(np.empty(0, dtype)).dtype
+            if t is None or tuple(t.shape) != tuple(shape) or t.dtype != tdt:
+                t = self._pin[i] = torch.empty(shape, dtype=tdt, pin_memory=True)
+            elif self._pin_free[i] is not None:
+                self._pin_free[i].synchronize()                       # the copy that last read this buffer (three batches ago)
+            return t.numpy()
+        videos, labels = self._pop(out=staging)
+        host = self._pin[i]
         cur = torch.cuda.current_stream()
         with torch.cuda.stream(self._copy_stream):
             dev = host.to(device, non_blocking=True)
+            self._pin_free[i] = torch.cuda.Event()
+            self._pin_free[i].record(self._copy_stream)
             if self._raw:
                 dev = ((dev.float() - 128.) / 128.).permute(0, 4, 1, 2, 3).contiguous()     # (N,T,H,W,C) u8 -> (N,C,T,H,W)
             ready = torch.cuda.Event() if with_event else None
@@ -242,7 +302,15 @@ class PrefetchIterator(SerialIterator):
         return (dev, labels, ready) if with_event else (dev, labels)
 
     def close(self):
-        self._pool.shutdown(wait=False, cancel_futures=True)
+        self._pool.shutdown(wait=bool(getattr(self, '_slots', None)), cancel_futures=True)      # (workers may still be writing into a slot)
+        slots, self._slots = getattr(self, '_slots', []), []
+        while slots:
+            shm = slots.pop()[0]                                      # (the NumPy view of the slot goes first: a mapped buffer cannot be closed)
+            try:
+                shm.close()
+                shm.unlink()
+            except Exception:
+                pass
 
     def __del__(self):
         try:

@@ -17,7 +17,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define LDSP(p) ((__attribute__((address_space(3))) void*)(p))
 
-template <int WAVES, int R, int M, int INFLIGHT>
+// PAT: what a piece's 64 lanes read.  0: 1 KiB contiguous.  1: the im2col gather -- eight rows of 128 bytes, 4 KiB apart (a lane group of
+// eight = one row).  2: the same with the 16-byte chunks of a row in the XOR-swizzled order the GEMM kernels use (chunk (l & 7) ^ key(row)).
+// 3: rows 128 bytes long but only 64 bytes apart in units of... (unused).
+template <int WAVES, int R, int M, int INFLIGHT, int PAT = 0>
 __global__ __launch_bounds__(WAVES * 64) void fill(const unsigned char* src, u32 kib, int iters, float* sink, unsigned long long* clk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -30,12 +33,17 @@ __global__ __launch_bounds__(WAVES * 64) void fill(const unsigned char* src, u32
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
     bf16x8 d[4];
     for (int i = 0; i < 4; ++i) d[i] = a;
-    u32 piece = (blockIdx.x * 977u + wave * 131u) % kib;
+    u32 lane_off = lane * 16u;
+    if constexpr (PAT == 1) lane_off = (u32)(lane >> 3) * 4096u + (u32)(lane & 7) * 16u;
+    if constexpr (PAT == 2) lane_off = (u32)(lane >> 3) * 4096u + (u32)(((lane & 7) ^ ((lane >> 4) * 2 + ((lane >> 3) & 1) * 5)) & 7) * 16u;
+    const u32 span = PAT ? 7u * 4096u + 128u : 1024u;                      // bytes a piece reaches beyond its base
+    const u32 lim = (kib * 1024u - span) / 128u;                           // piece bases in units of 128 bytes
+    u32 piece = ((blockIdx.x * 977u + wave * 131u) * 8u) % lim;
     __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDSP(mine + (it & 7) * 1024), 16, piece * 1024u + lane * 16u, 0, 0, 0);
-        piece += 61u; piece = piece >= kib ? piece - kib : piece;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDSP(mine + (it & 7) * 1024), 16, piece * 128u + lane_off, 0, 0, 0);
+        piece += 61u * 8u; piece = piece >= lim ? piece - lim : piece;
         if constexpr (R > 0) {
 #pragma unroll
             for (int q = 0; q < R; ++q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(d[q & 3]) : "v"(la), "n"((q & 7) * 1024));
@@ -56,11 +64,11 @@ __global__ __launch_bounds__(WAVES * 64) void fill(const unsigned char* src, u32
     if (s == 12345.678f) sink[0] = s;                                     // (keeps everything alive)
 }
 
-template <int WAVES, int R, int M, int INFLIGHT = 6>
+template <int WAVES, int R, int M, int INFLIGHT = 6, int PAT = 0>
 void run(const unsigned char* src, u32 kib, float* sink, unsigned long long* clk, const char* what) {
     const int iters = 4096, blocks = 256;
     const size_t lds = 128 * 1024;                                         // > half the LDS: ONE workgroup per CU (16 waves use all of it)
-    auto k = fill<WAVES, R, M, INFLIGHT>;
+    auto k = fill<WAVES, R, M, INFLIGHT, PAT>;
     hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e30f;
@@ -81,8 +89,8 @@ void run(const unsigned char* src, u32 kib, float* sink, unsigned long long* clk
     // matrix-pipe share by WALL time: MFMA cycles of one SIMD (WAVES / 4 waves x M x 32 cycles per piece) over the kernel's cycles at
     // the clock the blocks report (the slowest block ends the launch)
     const double mfma_frac = M ? ((double)(WAVES / 4) * iters * M * 32.0) / (best * 1e-3 * ghz[blocks / 2] * 1e9) : 0.0;
-    printf("%-44s waves %2d R %d M %d inflight %d: %7.3f ms  %6.2f TB/s  %5.1f B/clk/CU  clock %.2f GHz  cyc/piece/wave (median block) %6.1f  mfma pipe (wall) %.2f\n",
-           what, WAVES, R, M, INFLIGHT, best, bytes / best * 1e-9, per_cu_cyc, ghz[blocks / 2], cyc[blocks / 2] / iters, mfma_frac);
+    printf("%-44s pat %d waves %2d R %d M %d inflight %d: %7.3f ms  %6.2f TB/s  %5.1f B/clk/CU  clock %.2f GHz  cyc/piece/wave (median block) %6.1f  mfma pipe (wall) %.2f\n",
+           what, PAT, WAVES, R, M, INFLIGHT, best, bytes / best * 1e-9, per_cu_cyc, ghz[blocks / 2], cyc[blocks / 2] / iters, mfma_frac);
 }
 
 int main() {
@@ -93,6 +101,11 @@ int main() {
     srand(1);
     for (auto& v : h) v = (unsigned short)(0x3c00 + (rand() & 0x3ff) + ((rand() & 1) << 15));   // bf16 of magnitude ~1, random sign
     hipMemcpy(src, h.data(), (size_t)kib * 1024, hipMemcpyHostToDevice);
+    run<8, 0, 0, 6, 1>(src, kib, sink, clk, "fills alone, gathered rows");
+    run<8, 0, 0, 6, 2>(src, kib, sink, clk, "fills alone, gathered + swizzled chunks");
+    run<8, 3, 4, 6, 1>(src, kib, sink, clk, "256x256 mix, gathered rows");
+    run<8, 3, 4, 6, 2>(src, kib, sink, clk, "256x256 mix, gathered + swizzled");
+    run<8, 3, 3, 6, 2>(src, kib, sink, clk, "256x128 mix, gathered + swizzled");
     run<8, 0, 0>(src, kib, sink, clk, "fills alone");
     run<4, 0, 0>(src, kib, sink, clk, "fills alone");
     run<16, 0, 0>(src, kib, sink, clk, "fills alone");
