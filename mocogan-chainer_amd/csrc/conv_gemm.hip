@@ -147,6 +147,9 @@ __device__ __forceinline__ constexpr int sw_cols(int row, int chunks_per_row) {
 #ifndef MCG_V2_EARLY             // (round 5 experiment, measured and NOT kept: 1 = the barrier of K-step s + 1 in the middle of step s and
 #define MCG_V2_EARLY 0           //  that step's first fragments read under the last MFMA group of step s; see the K loop)
 #endif
+#ifndef MCG_V2_SKEW              // (round 5 experiment, measured and NOT kept: 1 = the two waves of a SIMD issue their LDS-DMA pieces at
+#define MCG_V2_SKEW 0            //  opposite ends of a K-step; see the K loop)
+#endif
 #ifndef MCG_PROBE_HALFREADS      // (tools/probe_variant.py: the LDS-DMA GEMM with half its fragment reads -- what a body with half the
 #define MCG_PROBE_HALFREADS 0    //  LDS read bytes per FLOP could gain at most; results are garbage)
 #endif
@@ -1091,15 +1094,22 @@ template <int OFF>
 __device__ __forceinline__ void ds128_issue(bf16x8& d, u32 addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(d) : "v"(addr), "n"(OFF));
 }
+// (MCG_PROBE_NOFRAGWAIT, timing ablation of tools/ab_variant.sh: no fragment read is ever waited for -- what the LDS latency costs;
+//  results are garbage)
+#ifdef MCG_PROBE_NOFRAGWAIT
+#define MCG_FRAGWAIT(N) 15
+#else
+#define MCG_FRAGWAIT(N) (N)
+#endif
 template <int N>
 __device__ __forceinline__ void ds128_wait(bf16x8& d) {
     static_assert(N >= 0 && N < 16, "lgkmcnt is a 4-bit field");
-    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(d) : "n"(N));
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(d) : "n"(MCG_FRAGWAIT(N)));
 }
 template <int N>
 __device__ __forceinline__ bf16x8 tr16_wait(s16x4& lo, s16x4& hi) {
     static_assert(N >= 0 && N < 16, "lgkmcnt is a 4-bit field");
-    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(lo), "+v"(hi) : "n"(N));
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(lo), "+v"(hi) : "n"(MCG_FRAGWAIT(N)));
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
@@ -1630,14 +1640,18 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
     constexpr bool TRA_ = !P::A_KC && !F32, TRB_ = !P::B_KC && !F32;   // operands read with the transposing read (inline asm)
     // fragment registers live across K-steps (EARLY prefetches the next step's first fragments)
     typedef typename std::conditional<F32, f32x4, bf16x8>::type frag_t;
-    bf16x8 fa16[2][M16 ? TM16 : 1], fb16[2][M16 ? HB : 1];
-    s16x4 blo16[2][M16 ? HB : 1], bhi16[2][M16 ? HB : 1];
+    // DIST2 (-DMCG_V2_EARLY=2, M16 launches): the fragments of phase ph + 2 are read under the MFMAs of phase ph (two phases of
+    // look-ahead instead of one; the B fragments then live in four buffers, one per phase)
+    constexpr bool DIST2 = EARLY && M16 && MCG_V2_EARLY == 2 && MCG_PROBE_HALFREADS == 0;
+    constexpr int NBB = DIST2 ? 4 : 2;
+    bf16x8 fa16[2][M16 ? TM16 : 1], fb16[NBB][M16 ? HB : 1];
+    s16x4 blo16[NBB][M16 ? HB : 1], bhi16[NBB][M16 ? HB : 1];
     frag_t fa[2][TM], fb[2][TN];
     s16x4 alo[2][TM], ahi[2][TM], blo[2][TN], bhi[2][TN];
     constexpr bool HR16 = MCG_PROBE_HALFREADS != 0;              // (timing ablation: half the fragment reads, results garbage)
     constexpr int NRA16 = HR16 ? TM16 / 2 : TM16, NRB16 = (TRB_ ? 2 : 1) * HB;
     auto reads16 = [&](auto ph_, u32 sb32) {                     // M16: the read set of phase ph = (group c, column half h)
-        constexpr int ph = decltype(ph_)::value, c = ph >> 1, h = ph & 1;
+        constexpr int ph = decltype(ph_)::value, c = ph >> 1, h = ph & 1, bb = DIST2 ? ph : h;
         if constexpr (h == 0) {
             static_for<0, TM16>([&](auto i_) {
                 constexpr int i = decltype(i_)::value;
@@ -1647,8 +1661,8 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
         if constexpr (!HR16 || h == 0)
         static_for<0, HB>([&](auto j_) {
             constexpr int j = decltype(j_)::value;
-            if constexpr (TRB_) tr16_issue<0, 4 * (BN * 2)>(blo16[h][j], bhi16[h][j], sb32 + tb16[h * HB + j] + rob[c]);
-            else ds128_issue<(h * HB + j) * 2048>(fb16[h][j], sb32 + b_row16 + xk[c]);
+            if constexpr (TRB_) tr16_issue<0, 4 * (BN * 2)>(blo16[bb][j], bhi16[bb][j], sb32 + tb16[h * HB + j] + rob[c]);
+            else ds128_issue<(h * HB + j) * 2048>(fb16[bb][j], sb32 + b_row16 + xk[c]);
         });
     };
     constexpr bool HR = MCG_PROBE_HALFREADS != 0 && !F32 && !SPLIT && TM >= 2 && TN >= 2;     // (timing ablation: half the fragment reads)
@@ -1690,12 +1704,30 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
     };
     // EARLY: the loads of the step two ahead in the two MFMA groups behind the mid-step barrier (half each); otherwise a quarter in
     // front of each of the four groups
+    // SKEW (round 5): the two waves that share a SIMD (waves w and w + 4: a workgroup's waves go to the SIMDs cyclically) do the SAME
+    // work per K-step in a different ORDER -- waves 4..7 issue all of the step's LDS-DMA pieces in a burst right behind the barrier,
+    // while waves 0..3 run their MFMA groups; waves 0..3 issue theirs behind their last MFMA group, while waves 4..7 run theirs.
+    // The in-kernel stamps (profiles/r05_stamps_v2_*.txt) showed why: behind the barrier all eight waves run in lockstep, every
+    // LDS-DMA issue holds its wave for 60-180 cycles, and the two waves of a SIMD ended up one after the other (a K-step took the SUM
+    // of their bodies: body 1646 + barrier wait 523 cycles per wave for 512 cycles of MFMAs each).
+    constexpr bool SKEW = MCG_V2_SKEW != 0 && !EARLY && !F32;
+    const bool late_dma = wave < 4;                               // (scalar: `wave` is uniform)
     auto dma = [&](auto ph_, int nbuf) {
         constexpr int ph = decltype(ph_)::value;
-        if constexpr (EARLY) {
+        if constexpr (SKEW) {
+            if constexpr (ph == 0) {
+                if (!late_dma) { issue_part(nbuf, 0); issue_part(nbuf, 1); issue_part(nbuf, 2); issue_part(nbuf, 3); }
+            }
+        } else if constexpr (EARLY) {
             if constexpr (ph == 2) { issue_part(nbuf, 0); issue_part(nbuf, 1); }
             if constexpr (ph == 3) { issue_part(nbuf, 2); issue_part(nbuf, 3); }
         } else issue_part(nbuf, ph);
+    };
+    auto dma_tail = [&](int nbuf) {                               // behind the step's last MFMA group
+        if constexpr (SKEW) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (late_dma) { issue_part(nbuf, 0); issue_part(nbuf, 1); issue_part(nbuf, 2); issue_part(nbuf, 3); }
+        }
     };
     int buf = 0, nbuf = 0;
 #ifdef MCG_STAMPS                // (diagnostic build, tools/stamp_phases_v2.py: where a wave's cycles go; the shares are meaningful, the run time is not)
@@ -1706,8 +1738,10 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
         if (k_cur < kend) {
             wait_vmcnt<(STAGES - 2) * PIECES>();                 // this wave's pieces of the first step
             __builtin_amdgcn_s_barrier();
-            if constexpr (M16) reads16(std::integral_constant<int, 0>{}, lds_addr(smem));
-            else frags(std::integral_constant<int, 0>{}, smem, lds_addr(smem));
+            if constexpr (M16) {
+                reads16(std::integral_constant<int, 0>{}, lds_addr(smem));
+                if constexpr (DIST2) reads16(std::integral_constant<int, 1>{}, lds_addr(smem));
+            } else frags(std::integral_constant<int, 0>{}, smem, lds_addr(smem));
         }
     }
     while (k_cur < kend) {
@@ -1715,7 +1749,9 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
             MCG_T(tv0);
             wait_vmcnt<(STAGES - 2) * PIECES>();                 // this wave's pieces of step k_cur have landed
             MCG_T(tv1);
+#ifndef MCG_PROBE_NOBAR          // (timing ablation: the K loop without its barrier; results are garbage)
             __builtin_amdgcn_s_barrier();                        // ... and everyone's; everyone has finished reading the previous step
+#endif
             MCG_T(tv2);
         }
         {
@@ -1739,13 +1775,18 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
             if constexpr (!EARLY) reads16(std::integral_constant<int, 0>{}, sb32);
             static_for<0, 2 * NG>([&](auto ph_) {
                 constexpr int ph = decltype(ph_)::value, c = ph >> 1, h = ph & 1;
-                if constexpr (ph + 1 < 2 * NG) reads16(std::integral_constant<int, ph + 1>{}, sb32);
+                if constexpr (DIST2) {
+                    if constexpr (ph + 2 < 2 * NG) reads16(std::integral_constant<int, ph + 2>{}, sb32);
+                    else reads16(std::integral_constant<int, ph + 2 - 2 * NG>{}, sb32n);          // the next step's first two phases
+                } else if constexpr (ph + 1 < 2 * NG) reads16(std::integral_constant<int, ph + 1>{}, sb32);
                 else if constexpr (EARLY) reads16(std::integral_constant<int, 0>{}, sb32n);      // the next step's first fragments
                 dma(ph_, nbuf);
                 __builtin_amdgcn_sched_barrier(0);               // (keeps these loads in front of this MFMA group)
-                constexpr bool MORE = ph + 1 < 2 * NG || EARLY;  // reads issued after the ones used now: those of the following phase
-                constexpr int NEXT = !MORE ? 0 : (h == 0 ? (HR16 ? 0 : NRB16) : NRA16 + NRB16);
+                constexpr bool MORE = ph + 1 < 2 * NG || EARLY;  // reads issued after the ones used now: those of the following phase(s)
+                // (DIST2: the read sets of the two following phases -- one with the A blocks, one without, whatever ph is)
+                constexpr int NEXT = !MORE ? 0 : DIST2 ? NRA16 + 2 * NRB16 : (h == 0 ? (HR16 ? 0 : NRB16) : NRA16 + NRB16);
                 constexpr int YOUNGER = NEXT < 15 ? NEXT : 15;
+                constexpr int bb = DIST2 ? ph : h;
                 if constexpr (h == 0) {
 #pragma unroll
                     for (int i = 0; i < TM16; i += HR16 ? 2 : 1) ds128_wait<YOUNGER>(fa16[c][i]);
@@ -1753,21 +1794,26 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
                 if constexpr (!HR16 || h == 0) {
 #pragma unroll
                 for (int j = 0; j < HB; ++j) {
-                    if constexpr (TRB_) fb16[h][j] = tr16_wait<YOUNGER>(blo16[h][j], bhi16[h][j]);
-                    else ds128_wait<YOUNGER>(fb16[h][j]);
+                    if constexpr (TRB_) fb16[bb][j] = tr16_wait<YOUNGER>(blo16[bb][j], bhi16[bb][j]);
+                    else ds128_wait<YOUNGER>(fb16[bb][j]);
                 }
                 }
 #pragma unroll
                 for (int i = 0; i < TM16; ++i)
 #pragma unroll
                     for (int j = 0; j < HB; ++j)
-                        acc4[i][h * HB + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa16[c][HR16 ? (i & ~1) : i], fb16[HR16 ? 0 : h][j], acc4[i][h * HB + j], 0, 0, 0);
+#ifdef MCG_PROBE_NOMFMA          // (timing ablation: loads, fragment reads, waits and the barrier without the MFMAs; results are garbage)
+                        asm volatile("" :: "v"(fa16[c][HR16 ? (i & ~1) : i]), "v"(fb16[HR16 ? 0 : bb][j]));
+#else
+                        acc4[i][h * HB + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa16[c][HR16 ? (i & ~1) : i], fb16[HR16 ? 0 : bb][j], acc4[i][h * HB + j], 0, 0, 0);
+#endif
                 if constexpr (EARLY && ph == 1) {
                     __builtin_amdgcn_sched_barrier(0);           // (behind this group's MFMAs: hipcc hoisted the barrier in front of them)
                     wait_vmcnt<0>();                             // this wave's pieces of the NEXT step (issued a step ago)
                     __builtin_amdgcn_s_barrier();                // ... everyone's; and everyone has finished reading the previous step's buffer
                 }
             });
+            dma_tail(nbuf);
         } else {
         // operand fragments two deep: the reads of k chunk kc + 1 are in flight under the MFMAs of chunk kc
         frag_t sfa[SPLIT ? 3 : 1][TM], sfb[SPLIT ? 3 : 1][TN];
@@ -1815,13 +1861,19 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
                 constexpr int c = decltype(c_)::value;
                 constexpr int pa = (c == 0 || c == 1 || c == 3) ? 0 : (c == 2 || c == 4) ? 1 : 2;
                 constexpr int pb = (c == 0 || c == 2 || c == 5) ? 0 : (c == 1 || c == 4) ? 1 : 2;
-                if constexpr (c < 4) { issue_part(nbuf, c); __builtin_amdgcn_sched_barrier(0); }
+                if constexpr (SKEW) {
+                    if constexpr (c == 0) {
+                        if (!late_dma) { issue_part(nbuf, 0); issue_part(nbuf, 1); issue_part(nbuf, 2); issue_part(nbuf, 3); }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else if constexpr (c < 4) { issue_part(nbuf, c); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
                     for (int b = 0; b < TN; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sfa[pa][a], sfb[pb][b], acc[a][b], 0, 0, 0);
             });
+            dma_tail(nbuf);
         } else {
         if constexpr (!EARLY) frags(std::integral_constant<int, 0>{}, sbase, sb32);
         static_for<0, 4>([&](auto kc_) {
@@ -1856,7 +1908,11 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
                     for (int b = 0; b < TN; ++b)
+#ifdef MCG_PROBE_NOMFMA
+                        asm volatile("" :: "v"(fa[kc & 1][HR ? (a & ~1) : a]), "v"(fb[kc & 1][HR ? (b & ~1) : b]));
+#else
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kc & 1][HR ? (a & ~1) : a], fb[kc & 1][HR ? (b & ~1) : b], acc[a][b], 0, 0, 0);
+#endif
             }
             if constexpr (EARLY && kc == 1) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -1864,6 +1920,7 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
                 __builtin_amdgcn_s_barrier();                    // ... everyone's; and everyone has finished reading the previous step's buffer
             }
         });
+        dma_tail(nbuf);
         }
         }
         buf = buf1;
@@ -1884,6 +1941,10 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
             for (int j = 0; j < HB; ++j) {
                 if constexpr (TRB_) fb16[0][j] = tr16_wait<0>(blo16[0][j], bhi16[0][j]);
                 else ds128_wait<0>(fb16[0][j]);
+                if constexpr (DIST2) {
+                    if constexpr (TRB_) fb16[1][j] = tr16_wait<0>(blo16[1][j], bhi16[1][j]);
+                    else ds128_wait<0>(fb16[1][j]);
+                }
             }
         } else {
 #pragma unroll
@@ -2085,14 +2146,27 @@ __global__ __launch_bounds__(NT2) void dgrad_patch_kernel(DgPatchPol p) {
             if (q < 6 && s + 1 < S) issue_patch(s + 1, q, q + 1);
             issue_b(Gn);
 #endif
+            // PSKEW (round 5, as SKEW in gemm_bf16_v2_kernel): the two waves of a SIMD (set cg = 0 / 1) issue the stage's three pieces
+            // at opposite ends of the stage -- set 1 in a burst behind the barrier while set 0 multiplies, set 0 behind its last MFMA
+            // group while set 1 multiplies -- instead of both spreading them between the same MFMA groups in lockstep
+            constexpr bool PSKEW = MCG_V2_SKEW != 0;
+            auto burst = [&]() {
+                if (q < 6 && s + 1 < S) issue_patch(s + 1, q, q + 1);
+                issue_b1(Gn, 0);
+                issue_b1(Gn, 1);
+            };
             auto spread = [&](int part) {
 #ifndef MCG_PATCH_BURST
+                if constexpr (PSKEW) return;
                 if (part == 0) { if (q < 6 && s + 1 < S) issue_patch(s + 1, q, q + 1); }
                 else if (part == 1) issue_b1(Gn, 0);
                 else if (part == 2) issue_b1(Gn, 1);
                 __builtin_amdgcn_sched_barrier(0);
 #endif
             };
+#ifndef MCG_PATCH_BURST
+            if constexpr (PSKEW) { if (cg == 1) burst(); __builtin_amdgcn_sched_barrier(0); }
+#endif
             const unsigned char* bb = bst + (G & 3) * BSTG + cg * 8192;       // this set's slice (ph = cg)
             int p0 = prow[0], p1 = prow[1];
             asm volatile("" : "+v"(p0), "+v"(p1));               // (keeps the operand addresses of a super-step from being hoisted out of
@@ -2132,6 +2206,9 @@ __global__ __launch_bounds__(NT2) void dgrad_patch_kernel(DgPatchPol p) {
                             acc[pw][a][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[pa][a], sb[pb_][i], acc[pw][a][i], 0, 0, 0);
                     if constexpr (c < 3) spread(c);
                 });
+#ifndef MCG_PATCH_BURST
+                if constexpr (PSKEW) { __builtin_amdgcn_sched_barrier(0); if (cg == 0) burst(); }
+#endif
                 return;
             }
             // Fragments two chunks deep, EVERY read in asm and counted here (see ds128_issue): chunk kc + 1's six reads (2 A, 4 B) are
@@ -2162,6 +2239,9 @@ __global__ __launch_bounds__(NT2) void dgrad_patch_kernel(DgPatchPol p) {
                         acc[pw][a][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kc & 1][a], fb[i], acc[pw][a][i], 0, 0, 0);
                 if constexpr (kc < 3) spread(kc);
             });
+#ifndef MCG_PATCH_BURST
+            if constexpr (PSKEW) { __builtin_amdgcn_sched_barrier(0); if (cg == 0) burst(); }
+#endif
         });
     }
     wait_vmcnt<0>();

@@ -264,13 +264,14 @@ class PrefetchIterator(SerialIterator):
 
     def next_device_batch(self, device, with_event=False):
         """-> (x_real float32 (N,C,T,H,W) on `device`, labels list).  The H2D copy runs from pinned memory on a
-        side stream; the caller's stream waits for it.  with_event: also returns the event recorded on the copy stream when the
-        batch was complete -- `TrainStep.run(input_event=...)` lets a stream that needs nothing but the batch (the
-        VideoDiscriminator's real chain) wait for exactly that instead of for everything queued on the caller's stream."""
+        side stream; the caller's stream waits for it.  with_event: -> (x_real, labels, event, labels_dev) -- the event recorded on
+        the copy stream when the batch was complete (`TrainStep.run(input_event=...)` lets a stream that needs nothing but the batch,
+        the VideoDiscriminator's real chain, wait for exactly that instead of for everything queued on the caller's stream) and the
+        labels as an int32 device tensor copied on that stream too (None for an unlabelled dataset)."""
         import torch
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream(device=device)
-            self._pin, self._pin_free, self._pin_i = [None] * 3, [None] * 3, 0
+            self._pin, self._pin_free, self._pin_i, self._pin_lab = [None] * 3, [None] * 3, 0, [None] * 3
         # A ring of three PINNED staging buffers, allocated once: the batch is assembled in one of them and copied from there.
         # (Round 5, found by timing the product path -- tools/bench_train.py: `torch.from_numpy(videos).pin_memory()` allocated and
         # freed pinned memory every iteration, and freeing pinned memory waits for the device -- 35-40 ms per batch whatever its
@@ -290,16 +291,26 @@ class PrefetchIterator(SerialIterator):
         cur = torch.cuda.current_stream()
         with torch.cuda.stream(self._copy_stream):
             dev = host.to(device, non_blocking=True)
-            self._pin_free[i] = torch.cuda.Event()
-            self._pin_free[i].record(self._copy_stream)
             if self._raw:
                 dev = ((dev.float() - 128.) / 128.).permute(0, 4, 1, 2, 3).contiguous()     # (N,T,H,W,C) u8 -> (N,C,T,H,W)
+            lab_dev = None
+            if with_event and labels and labels[0] is not None:
+                # the labels travel the same way (pinned, copy stream): `torch.as_tensor(labels).to(device)` from pageable memory is a
+                # BLOCKING copy ordered behind everything queued on the caller's stream -- the host then cannot run ahead of the GPU
+                if self._pin_lab[i] is None or self._pin_lab[i].numel() < len(labels):
+                    self._pin_lab[i] = torch.empty(max(len(labels), self.batch_size), dtype=torch.int32, pin_memory=True)
+                self._pin_lab[i][:len(labels)] = torch.from_numpy(np.asarray(labels, dtype=np.int32))
+                lab_dev = self._pin_lab[i][:len(labels)].to(device, non_blocking=True)
+            self._pin_free[i] = torch.cuda.Event()                    # both staging buffers of slot i have been read
+            self._pin_free[i].record(self._copy_stream)
             ready = torch.cuda.Event() if with_event else None
             if ready is not None:
                 ready.record(self._copy_stream)
         cur.wait_stream(self._copy_stream)
         dev.record_stream(cur)
-        return (dev, labels, ready) if with_event else (dev, labels)
+        if lab_dev is not None:
+            lab_dev.record_stream(cur)
+        return (dev, labels, ready, lab_dev) if with_event else (dev, labels)
 
     def close(self):
         self._pool.shutdown(wait=bool(getattr(self, '_slots', None)), cancel_futures=True)      # (workers may still be writing into a slot)

@@ -122,9 +122,9 @@ class Updater:
     # ---- one iteration ---------------------------------------------------------------------------
     def update_core(self):
         it = self.get_iterator('main')
-        ready = None
+        ready = t_real = None
         if hasattr(it, 'next_device_batch'):                                         # prefetching loader: uint8 from pinned memory on
-            x_real, labels, ready = it.next_device_batch(self._step.device, with_event=True)    # a copy stream, normalised on the GPU
+            x_real, labels, ready, t_real = it.next_device_batch(self._step.device, with_event=True)   # a copy stream, normalised on the GPU
         else:
             batch = it.next()
             labels = [b[1] for b in batch]
@@ -141,7 +141,19 @@ class Updater:
             if x_real.is_cuda:
                 self._pin_evt = torch.cuda.Event()
                 self._pin_evt.record()
-        t_real = None if labels[0] is None else torch.as_tensor(np.asarray(labels, dtype=np.int32)).to(self._step.device)
+        if t_real is None and labels[0] is not None:
+            # (pinned + non-blocking: a copy from pageable memory blocks the host until everything queued before it has run)
+            lab = getattr(self, '_pin_lab', None)
+            if lab is None or lab.numel() < len(labels):
+                lab = self._pin_lab = torch.empty(len(labels), dtype=torch.int32, pin_memory=torch.cuda.is_available())
+            evt = getattr(self, '_pin_lab_evt', None)
+            if evt is not None:
+                evt.synchronize()
+            lab[:len(labels)] = torch.from_numpy(np.asarray(labels, dtype=np.int32))
+            t_real = lab[:len(labels)].to(self._step.device, non_blocking=True)
+            if t_real.is_cuda:
+                self._pin_lab_evt = torch.cuda.Event()
+                self._pin_lab_evt.record()
         # (the loader is a batch ahead: its copy's event lets the two-chain schedule start the next real chain under this iteration's tail)
         self._step.run(x_real, t_real, input_event=ready)
         if self.is_new_epoch:

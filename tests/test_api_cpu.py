@@ -119,6 +119,48 @@ def test_prefetch_iterator_keeps_serial_order_and_epoch_bookkeeping(tmp_path):
         p.close()
 
 
+def test_prefetch_iterator_shared_memory_slots_equal_the_result_pipes(tmp_path, monkeypatch):
+    """Round 5: raw (uint8) datasets reach the training process through shared-memory batch slots the workers write into; the
+    batches must be those of the pickled-result transport (MCG_LOADER_SHM=0) and of SerialIterator, sample for sample, across a
+    wrap-around and a reset; the staging callback of next_device_batch (`_pop(out=...)`) receives the same frames; close() leaves
+    no segment behind."""
+    import os
+    from mocogan_chainer_amd.trainer import SerialIterator, PrefetchIterator
+    from datasets import MugDataset
+    _fake_frame_tree(tmp_path / "mug")
+    mug = MugDataset(tmp_path / "mug")
+
+    def run(make, staged=False):
+        np.random.seed(11)
+        it = make()
+        out = []
+        try:
+            for k in range(5):
+                if staged:
+                    v, l = it._pop(out=lambda shape, dt: np.empty(shape, dt))
+                    b = [(((v[i].astype(np.float32) - 128.) / 128.).transpose(3, 0, 1, 2), l[i]) for i in range(len(l))]
+                else:
+                    b = it.next()
+                out.append(([x[1] for x in b], [x[0].copy() for x in b], it.epoch, it.is_new_epoch, it.epoch_detail))
+                if k == 2 and getattr(it, '_slots', None):
+                    assert len(it._free_slots) + len(it._queue) == len(it._slots)          # no slot is lost
+        finally:
+            if hasattr(it, 'close'):
+                it.close()
+        return out
+    ref = run(lambda: SerialIterator(mug, 3, shuffle=False))
+    shm = run(lambda: PrefetchIterator(mug, 3, n_workers=2, prefetch=2, chunk=2, shuffle=False))
+    staged = run(lambda: PrefetchIterator(mug, 3, n_workers=2, prefetch=2, chunk=2, shuffle=False), staged=True)
+    monkeypatch.setenv('MCG_LOADER_SHM', '0')
+    pipes = run(lambda: PrefetchIterator(mug, 3, n_workers=2, prefetch=2, chunk=2, shuffle=False))
+    for got in (shm, staged, pipes):
+        for a, b in zip(ref, got):
+            assert a[0] == b[0] and a[2:] == b[2:]                  # labels, epoch bookkeeping: SerialIterator's
+        for a, b in zip(shm, got):                                  # frames: the workers' sub-sequence offsets are seeded per (seed, batch, chunk)
+            assert all(np.array_equal(x, y) for x, y in zip(a[1], b[1]))
+    assert not [f for f in os.listdir('/dev/shm') if f.startswith('mcg_%d_' % os.getpid())]
+
+
 def test_grid_and_sequence_helpers():
     from util import to_grid, to_sequence
     v = np.arange(2 * 3 * 1 * 2 * 2, dtype=np.uint8).reshape(2, 3, 1, 2, 2)
@@ -413,3 +455,10 @@ def test_bench_stdout_line_stays_small():
     text = bench.compact_line(out, big, cpu, None)
     assert len(text) <= bench.LINE_LIMIT and json.loads(text)["value"] == round(2142.123456, 4)
     assert bench.PEAK_F32X3_TFLOPS == pytest.approx(2516.8 / 6)
+    # round 4's advice: a string that grows must shrink the line, never cost it (an assert there meant NO stdout line at all)
+    grown = rec("f32", "configs[1]" + "w" * 3000, 2142.0)
+    grown["roofline"]["kernel"] = "k" * 3000
+    text = bench.compact_line(grown, secondary, dict(cpu, sample="s" * 5000), "/somewhere/bench_detail.json")
+    line = json.loads(text)
+    assert len(text) <= bench.LINE_LIMIT and line["value"] == 2142.0 and line["metric"] and line["unit"] == "clips/s" and line["n_gpus"] == 1
+

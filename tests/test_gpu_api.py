@@ -179,7 +179,12 @@ def test_prefetching_loader_feeds_the_updater(tmp_path, monkeypatch):
         for _ in range(3):
             b = ser.next()
             x_ref = np.stack([e[0] for e in b])
-            x_dev, labels = pre.next_device_batch(torch.device('cuda'))
+            if _ == 1:                                               # the Updater's form: + the copy's event and the labels on the device
+                x_dev, labels, ready, lab_dev = pre.next_device_batch(torch.device('cuda'), with_event=True)
+                ready.synchronize()
+                assert lab_dev.dtype == torch.int32 and lab_dev.cpu().tolist() == labels
+            else:
+                x_dev, labels = pre.next_device_batch(torch.device('cuda'))
             torch.cuda.synchronize()
             assert x_dev.shape == (4, 3, 16, 64, 64) and x_dev.dtype == torch.float32 and x_dev.is_contiguous()
             assert np.array_equal(x_dev.cpu().numpy(), x_ref) and labels == [e[1] for e in b]

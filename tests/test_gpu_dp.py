@@ -268,7 +268,7 @@ def test_one_rank_rccl_rehearsal_of_the_bench_line():
     import math
     import subprocess
     env = dict(os.environ, MCG_DP_REHEARSE_NCCL='1', MASTER_PORT='37711', MCG_BENCH_DETAIL=os.devnull)
-    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '2', '--batch', '4', '--no-cpu-baseline', '--secondary', '0']
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '2', '--batch', '4', '--dtype', 'f32', '--no-cpu-baseline', '--secondary', '0']
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = out.stdout.strip().splitlines()

@@ -64,6 +64,12 @@ __global__ __launch_bounds__(WAVES * 64) void fill(const unsigned char* src, u32
     if (s == 12345.678f) sink[0] = s;                                     // (keeps everything alive)
 }
 
+// Which waves of a workgroup share a SIMD?  Every wave reports HW_REG_HW_ID (gfx9 layout: wave [3:0], SIMD [5:4], CU [11:8], SE [15:13]).
+__global__ void whereami(u32* out) {
+    const u32 id = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    if ((threadIdx.x & 63) == 0) out[blockIdx.x * 16 + (threadIdx.x >> 6)] = id;
+}
+
 template <int WAVES, int R, int M, int INFLIGHT = 6, int PAT = 0>
 void run(const unsigned char* src, u32 kib, float* sink, unsigned long long* clk, const char* what) {
     const int iters = 4096, blocks = 256;
@@ -101,6 +107,19 @@ int main() {
     srand(1);
     for (auto& v : h) v = (unsigned short)(0x3c00 + (rand() & 0x3ff) + ((rand() & 1) << 15));   // bf16 of magnitude ~1, random sign
     hipMemcpy(src, h.data(), (size_t)kib * 1024, hipMemcpyHostToDevice);
+    {
+        u32* w; hipMalloc(&w, 4 * 16 * 4);
+        for (int nw : {8, 4, 16}) {
+            hipMemset(w, 0, 4 * 16 * 4);
+            hipLaunchKernelGGL(whereami, dim3(4), dim3(nw * 64), 0, 0, w);
+            u32 h[64]; hipMemcpy(h, w, sizeof(h), hipMemcpyDeviceToHost);
+            for (int b = 0; b < 2; ++b) {
+                printf("workgroup %d of %2d waves: SIMD of wave 0..%d:", b, nw, nw - 1);
+                for (int i = 0; i < nw; ++i) printf(" %u", (h[b * 16 + i] >> 4) & 3);
+                printf("   (CU %u SE %u)\n", (h[b * 16] >> 8) & 15, (h[b * 16] >> 13) & 7);
+            }
+        }
+    }
     run<8, 0, 0, 6, 1>(src, kib, sink, clk, "fills alone, gathered rows");
     run<8, 0, 0, 6, 2>(src, kib, sink, clk, "fills alone, gathered + swizzled chunks");
     run<8, 3, 4, 6, 1>(src, kib, sink, clk, "256x256 mix, gathered rows");

@@ -13,7 +13,7 @@ timeout -k 10 200 python tools/bench_train.py --mfma f32 --batchsize 32 --data s
 R=$(pwd)
 export MCG_DP_REHEARSE_NCCL=1 MASTER_PORT=37741 TMPDIR=/tmp
 cd /tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $O/dp_trace -o dp -- python3 $R/bench.py --batch 32 --steps 6 --warmup 3 --no-cpu-baseline --secondary 0 > $O/dp_bench.json 2> $O/dp_trace.err
+timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $O/dp_trace -o dp -- python3 $R/bench.py --dtype f32 --batch 32 --steps 6 --warmup 3 --no-cpu-baseline --secondary 0 > $O/dp_bench.json 2> $O/dp_trace.err
 cd $R
 unset MCG_DP_REHEARSE_NCCL
 T=$(find $O/dp_trace -name '*kernel_trace.csv' | head -1)

@@ -29,7 +29,11 @@ def main():
     adam = [i for i, r in enumerate(rows) if 'adam_wd' in r['Kernel_Name']]
     ends = [rows[adam[i]]['e'] for i in range(2, len(adam), 3)]
     spans = list(zip(ends[:-1], ends[1:]))[-iters:]
-    is_rccl = lambda n: 'ccl' in n.lower() or 'AllReduce' in n or 'Broadcast' in n
+    is_rccl = lambda n: any(k in n for k in ('nccl', 'Nccl', 'rccl', 'Rccl', 'AllReduce', 'ncclDevKernel'))
+    names = sorted({short(r['Kernel_Name']) for r in rows if is_rccl(r['Kernel_Name'])})
+    print('RCCL kernels in the trace: %s' % (names or 'NONE (a world of one: the collective is a no-op on the device, no ring kernel is launched)'))
+    copies = [r for r in rows if 'copyBuffer' in r['Kernel_Name'] or 'fillBuffer' in r['Kernel_Name']]
+    print('runtime copy / fill kernels: %d' % len(copies))
     for a, b in spans:
         ks = [r for r in rows if r['s'] >= a and r['e'] <= b]
         print('iteration of %.3f ms, %d kernels, %d of them RCCL' % ((b - a) / 1e6, len(ks), sum(is_rccl(r['Kernel_Name']) for r in ks)))
