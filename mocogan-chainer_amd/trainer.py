@@ -118,13 +118,15 @@ class PrefetchIterator(SerialIterator):
       transposes on the GPU;
     * ``next()`` still returns the reference's list of ``(video float32 (C,T,H,W), label)``."""
 
-    def __init__(self, dataset, batch_size, repeat=True, shuffle=True, n_workers=8, prefetch=4, chunk=4, seed=0):
+    def __init__(self, dataset, batch_size, repeat=True, shuffle=True, n_workers=8, prefetch=4, chunk=None, seed=0):
         import concurrent.futures as cf
         import multiprocessing as mp
         self._raw = hasattr(dataset, 'get_example_raw')
         import datasets as _ds                                        # torch-free module: all a worker imports
         self._pool = cf.ProcessPoolExecutor(max_workers=n_workers, mp_context=mp.get_context('spawn'),
                                             initializer=_ds.worker_init, initargs=(seed, dataset))
+        if chunk is None:                                             # clips per worker task: two tasks per worker and batch, at least 4 clips
+            chunk = max(4, -(-batch_size // (2 * max(n_workers, 1))))  # (64 tasks per 256-clip batch cost the training thread 3-6 ms in submit / result)
         self._depth, self._chunk, self._queue, self._batch_no = prefetch, chunk, [], 0
         self._copy_stream = None
         # raw (uint8) datasets: the workers write the decoded frames into shared-memory batch slots and return only the labels
@@ -141,6 +143,14 @@ class PrefetchIterator(SerialIterator):
                 self._slots.append((shm, np.ndarray((batch_size,) + self._clip_shape, dtype=np.uint8, buffer=shm.buf)))
             self._free_slots = list(range(len(self._slots)))
         super().__init__(dataset, batch_size, repeat, shuffle)
+
+    def _reclaim(self, block=False):
+        """page-locked slots whose device copy has completed go back to the free list (block: wait for the oldest if none is free)"""
+        busy = getattr(self, '_busy', [])
+        while busy and (busy[0][1].query() or (block and not self._free_slots)):
+            slot, ev = busy.pop(0)
+            ev.synchronize()
+            self._free_slots.append(slot)
 
     def _drop_queue(self):
         """forget the look-ahead: cancel what has not started, wait for what is running (it writes into a slot), free the slots"""
@@ -214,6 +224,8 @@ class PrefetchIterator(SerialIterator):
                 break
             slot = None
             if self._slots and len(idx) <= self.batch_size:
+                if not self._free_slots:
+                    self._reclaim(block=True)
                 slot = self._free_slots.pop()
                 futs = [self._pool.submit(_ds.worker_load_shm, idx[c:c + self._chunk], self._batch_no, c, self._slots[slot][0].name, c,
                                           self._clip_shape) for c in range(0, len(idx), self._chunk)]
@@ -225,8 +237,10 @@ class PrefetchIterator(SerialIterator):
         self._head = self._state()
         self._set_state(user)
 
-    def _pop(self, out=None):
-        """out: a callable (shape, dtype) -> NumPy array the batch is assembled IN (a pinned staging buffer), or None"""
+    def _pop(self, out=None, keep_slot=False):
+        """out: a callable (shape, dtype) -> NumPy array the batch is assembled IN (a pinned staging buffer), or None.
+        keep_slot (page-locked slots): no copy at all -- returns (view of the batch slot, labels, slot); the caller releases the slot
+        (`_busy`) once its device copy has read it."""
         self._fill()
         if not self._queue:
             raise StopIteration
@@ -236,6 +250,8 @@ class PrefetchIterator(SerialIterator):
         if slot is not None:                                          # the frames are in the batch slot; the workers returned the labels
             labels = [l for p in parts for l in p]
             view = self._slots[slot][1][:len(labels)]
+            if keep_slot:
+                return view, labels, slot
             if out is not None:
                 videos = out(view.shape, view.dtype)
                 np.copyto(videos, view)
@@ -272,7 +288,46 @@ class PrefetchIterator(SerialIterator):
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream(device=device)
             self._pin, self._pin_free, self._pin_i, self._pin_lab = [None] * 3, [None] * 3, 0, [None] * 3
-        # A ring of three PINNED staging buffers, allocated once: the batch is assembled in one of them and copied from there.
+            # The batch slots themselves are page-locked when that is possible (hipHostRegister of the shared-memory segments): the
+            # workers then decode straight into pinned memory and the H2D copy reads the slot -- no host copy at all (50 MB per batch
+            # at 256 clips: 8-10 ms of the training thread, which at bf16 batch 256 made the HOST the bound: 22.7 against 20.2 ms)
+            self._busy, self._slots_pinned = [], False
+            if self._slots and os.environ.get('MCG_LOADER_PIN_SLOTS', '1') == '1':
+                try:
+                    from torch.cuda._pin_memory_utils import pin_memory as _pin
+                    for shm, arr in self._slots:
+                        _pin(arr.ctypes.data, arr.nbytes)
+                    self._slots_pinned = torch.from_numpy(self._slots[0][1]).is_pinned()
+                except Exception as exc:                              # (fall back to the staging ring)
+                    sys.stderr.write('PrefetchIterator: batch slots not page-locked (%r): staging through pinned buffers\n' % (exc,))
+        if getattr(self, '_slots_pinned', False):
+            self._reclaim()
+            view, labels, slot = self._pop(keep_slot=True)
+            host = torch.from_numpy(view)
+            i = self._pin_i = (self._pin_i + 1) % 3
+            cur = torch.cuda.current_stream()
+            with torch.cuda.stream(self._copy_stream):
+                dev = host.to(device, non_blocking=True)
+                if self._raw:
+                    dev = ((dev.float() - 128.) / 128.).permute(0, 4, 1, 2, 3).contiguous()
+                lab_dev = None
+                if with_event and labels and labels[0] is not None:
+                    if self._pin_lab[i] is None or self._pin_lab[i].numel() < len(labels):
+                        self._pin_lab[i] = torch.empty(max(len(labels), self.batch_size), dtype=torch.int32, pin_memory=True)
+                    elif self._pin_free[i] is not None:
+                        self._pin_free[i].synchronize()
+                    self._pin_lab[i][:len(labels)] = torch.from_numpy(np.asarray(labels, dtype=np.int32))
+                    lab_dev = self._pin_lab[i][:len(labels)].to(device, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(self._copy_stream)
+                self._pin_free[i] = done
+                self._busy.append((slot, done))
+            cur.wait_event(done)
+            dev.record_stream(cur)
+            if lab_dev is not None:
+                lab_dev.record_stream(cur)
+            return (dev, labels, done, lab_dev) if with_event else (dev, labels)
+        # Otherwise: a ring of three PINNED staging buffers, allocated once; the batch is assembled in one of them and copied from there.
         # (Round 5, found by timing the product path -- tools/bench_train.py: `torch.from_numpy(videos).pin_memory()` allocated and
         # freed pinned memory every iteration, and freeing pinned memory waits for the device -- 35-40 ms per batch whatever its
         # size, the loader SLOWER than the serial loop: 900 against 1900 clips/s at batch 32.)
@@ -315,6 +370,16 @@ class PrefetchIterator(SerialIterator):
     def close(self):
         self._pool.shutdown(wait=bool(getattr(self, '_slots', None)), cancel_futures=True)      # (workers may still be writing into a slot)
         slots, self._slots = getattr(self, '_slots', []), []
+        if getattr(self, '_slots_pinned', False):
+            try:
+                import torch
+                torch.cuda.synchronize()
+                from torch.cuda._pin_memory_utils import unpin_memory
+                for _, arr in slots:
+                    unpin_memory(arr.ctypes.data)
+            except Exception:
+                pass
+            self._slots_pinned = False
         while slots:
             shm = slots.pop()[0]                                      # (the NumPy view of the slot goes first: a mapped buffer cannot be closed)
             try:

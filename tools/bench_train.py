@@ -52,7 +52,8 @@ def main():
     ap.add_argument('--batchsize', type=int, default=32)
     ap.add_argument('--model', default='normal', choices=['normal', 'cgan', 'infogan'])
     ap.add_argument('--data', default='cached', choices=['cached', 'synthetic', 'jpeg'])
-    ap.add_argument('--size', type=int, default=1024, help='clips in the dataset')
+    ap.add_argument('--size', type=int, default=0, help='clips in the dataset (default: max(1024, 16 batches) -- the per-epoch report reads the '
+                                                        'losses back, a host synchronisation, so a 4-iteration epoch measures that instead)')
     ap.add_argument('--loader_workers', type=int, default=8)
     ap.add_argument('--iters', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=15)
@@ -70,6 +71,8 @@ def main():
         raise SystemExit('bench_train.py needs an MI355X')
     hl.set_autotune(True)
     np.random.seed(0)
+    if args.size <= 0:
+        args.size = max(1024, 16 * args.batchsize)
     num_labels, channel, T_ = 6, 3, 16
     if args.data == 'cached':
         ds = CachedClips(args.size, num_labels, channel, T_)
@@ -118,7 +121,7 @@ def main():
            "loader_workers": args.loader_workers, "dtype": args.mfma, "model": args.model, "batch": args.batchsize, "iters": args.iters,
            "side_streams": bool(args.overlap), "two_chain_iterations": mstep.chain_iterations - chains0,
            "clips_per_s": round(args.batchsize * args.iters / dt, 1), "ms_per_iteration": round(dt / args.iters * 1e3, 3),
-           "epochs_seen": updater.epoch}
+           "epochs_seen": updater.epoch, "dataset_clips": args.size}
     print(json.dumps(rec), flush=True)
     try:
         prev = json.load(open(args.out))

@@ -1,5 +1,5 @@
 set -e
-TAG=${1:-r04_g}
+TAG=${1:-r05_j}
 R=$(pwd); O=$R/gpurun_out/$TAG; mkdir -p $O
 export TMPDIR=/tmp
 # tile tables first (so that the profiled pass has no tuning launches)
