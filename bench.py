@@ -453,6 +453,7 @@ def main():
             "configs[1]" if (dtype == 'f32' and B == 32 and model == 'normal') else \
             "configs[1], fp32 products on the bf16 pipe" if (dtype == 'f32x3' and B == 32 and model == 'normal') else \
             "configs[3]" if (dtype == 'f32' and B == 32 and model == 'infogan') else \
+            "configs[3], fp32 products on the bf16 pipe" if (dtype == 'f32x3' and B == 32 and model == 'infogan') else \
             "configs[4]" if (B == 128 and world == 8 and model == 'normal') else "off-list variant of configs[1]"
         per_rank_ms = sorted(t / steps * 1e3 for t in per_rank)
         return {
@@ -549,7 +550,7 @@ def main():
         if world == 1:
             also('normal', other, 32)          # configs[1] again in the other form of its fp32 arithmetic (fp32 MFMA / bf16 pipe): first
             also('normal', 'bf16', 256)
-            also('infogan', 'f32', 32)
+            also('infogan', HEADLINE_DTYPE, 32)
         elif world == 8 or os.environ.get('MCG_BENCH_SECONDARY_DP') == '1':
             also('normal', HEADLINE_DTYPE, 128)
             also('normal', other, 128)
