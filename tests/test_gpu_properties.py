@@ -35,11 +35,13 @@ def _step_layers(batch):
     return out
 
 
-@pytest.mark.parametrize("precision,tol,batch", [("f32", 2e-5, 32), ("bf16", 2e-2, 32), ("bf16", 2e-2, 256)],
-                         ids=["f32-b32", "bf16-b32", "bf16-b256-configs2"])
+@pytest.mark.parametrize("precision,tol,batch", [("f32", 2e-5, 32), ("bf16", 2e-2, 32), ("bf16", 2e-2, 256), ("f32x3", 2e-5, 32), ("f32x3", 2e-5, 128)],
+                         ids=["f32-b32", "bf16-b32", "bf16-b256-configs2", "f32x3-b32-headline", "f32x3-b128-configs4-share"])
 def test_conv_passes_are_adjoint_and_linear_at_full_size(precision, tol, batch):
-    """batch 32 = BASELINE configs[1]; bf16 at batch 256 = configs[2] (the shipped tile table holds its geometries:
-    D at 512 and 256 clips, G at 4096 frames)."""
+    """batch 32 = BASELINE configs[1] (fp32 MFMA, and the headline's arithmetic: the same fp32 products formed on the bf16 pipe from
+    three-term operands, held to the fp32 tolerance); bf16 at batch 256 = configs[2] (the shipped tile table holds its geometries:
+    D at 512 and 256 clips, G at 4096 frames); batch 128 = one GPU's share of configs[4] (global batch 1024 on 8 GPUs: D at 256 and
+    128 clips, G at 2048 frames -- the only part of that configuration a one-GPU box can run)."""
     import mocogan_chainer_amd.hiplib as hl
     hl.load()
     hl.set_autotune(True)
@@ -47,7 +49,10 @@ def test_conv_passes_are_adjoint_and_linear_at_full_size(precision, tol, batch):
     gen.manual_seed(5)
     try:
         for name, N, T, H, Ci, Co, kt, ci_real in _step_layers(batch):
-            g = hl.make_geom(N, T, H, H, Ci, Co, kt, precision=precision)
+            split = precision == "f32x3" and Ci % 16 == 0 and Co % 16 == 0     # (the 4-channel layers of an f32x3 network run the fp32 kernels)
+            g = hl.make_geom(N, T, H, H, Ci, Co, kt, precision=precision if split else "f32" if precision == "f32x3" else precision)
+            if split and not (hl.split_covers('fprop', g) and hl.split_covers('dgrad', g) and hl.split_covers('wgrad', g)):
+                continue
             x = torch.randn((N, T, H, H, Ci), device='cuda', generator=gen)
             if Ci == 4:
                 x[..., 3] = 0                                       # padded channel
@@ -56,11 +61,13 @@ def test_conv_passes_are_adjoint_and_linear_at_full_size(precision, tol, batch):
                 w[..., 3] = 0
             gy = torch.randn((N, g.To, g.Ho, g.Wo, Co), device='cuda', generator=gen)
             y = torch.empty_like(gy)
-            hl.conv_fprop(g, x, w, None, y)
+            sp = (lambda t, **kw: hl.split_planes(t, **kw)) if split else (lambda t, **kw: t)
+            wd = sp(w, run=16 * kt * 16 * Ci) if split else w              # the filter as the input gradient reads it
+            hl.conv_fprop(g, sp(x), sp(w), None, y)
             gx = torch.empty_like(x)
-            hl.conv_dgrad(g, gy, w, None, gx)
+            hl.conv_dgrad(g, sp(gy), wd, None, gx)
             gw = torch.zeros_like(w)
-            hl.conv_wgrad(g, x, gy, gw)
+            hl.conv_wgrad(g, sp(x), sp(gy), gw)
             a, b, c = _dot(y, gy), _dot(x, gx), _dot(w, gw)
             scale = float(torch.linalg.vector_norm(y.double()) * torch.linalg.vector_norm(gy.double()))
             assert abs(a - b) < tol * scale and abs(a - c) < tol * scale, (name, precision, a, b, c, scale)
@@ -69,10 +76,10 @@ def test_conv_passes_are_adjoint_and_linear_at_full_size(precision, tol, batch):
             if Ci == 4:
                 x2[..., 3] = 0
             y2, y3 = torch.empty_like(y), torch.empty_like(y)
-            hl.conv_fprop(g, x2, w, None, y2)
-            hl.conv_fprop(g, 2 * x - 3 * x2, w, None, y3)
+            hl.conv_fprop(g, sp(x2), sp(w), None, y2)
+            hl.conv_fprop(g, sp(2 * x - 3 * x2), sp(w), None, y3)
             err = float(torch.linalg.vector_norm((y3 - (2 * y - 3 * y2)).double()) / torch.linalg.vector_norm(y3.double()))
-            assert err < (5e-6 if precision == "f32" else 2e-2), (name, err)
+            assert err < (5e-6 if precision in ("f32", "f32x3") else 2e-2), (name, err)
             del x, x2, y, y2, y3, gy, gx, gw, w
     finally:
         hl.set_autotune(False)
