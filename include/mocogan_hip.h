@@ -120,7 +120,7 @@ typedef struct mcg_conv_geom {
 
 /* ABI revision of this header: a host built against another revision must not call in (argument lists differ).
  * 3 = round 3 (mcg_randint, bf16 tensors in the synchronised-BatchNorm backward; round 2 changed mcg_bn_act_fwd / mcg_bn_act_bwd / mcg_adam_wd / mcg_conv_geom). */
-#define MCG_ABI_VERSION 5
+#define MCG_ABI_VERSION 6
 int mcg_version(void);
 
 /* ---- implicit-GEMM convolution on the fp32 MFMA (v_mfma_f32_32x32x2_f32) ------------------- */
@@ -354,6 +354,12 @@ int mcg_randn_rowquad(int64_t M, int C, float sigma, uint64_t seed, uint64_t str
  *                              x / y, and of w = [Co][taps][Ci] as fprop reads it);
  *   run = 16 * taps * Ci     : w as dgrad reads it -> [Co/16][4][16][taps][Ci] (the planes of 16 filters, filter by filter). */
 int mcg_split_planes(int64_t n, int64_t run, const float* src, void* dst, void* stream);
+/* Several mcg_split_planes in ONE launch (ABI 6): segment s splits segs[s].n values at segs[s].src into segs[s].dst with run
+ * segs[s].run -- bit for bit what the single call writes.  For the filters of an 'f32x3' network: every (filter, form) pair the
+ * network's launches read is refreshed in one launch right after the Adam update instead of one launch per pair on first use
+ * (train.py:93-101 is where the reference's optimizer rewrites the parameters).  `segs` is a HOST array of nseg <= 32 entries. */
+typedef struct mcg_split_seg { const float* src; void* dst; int64_t n; int64_t run; } mcg_split_seg;
+int mcg_split_planes_multi(int nseg, const mcg_split_seg* segs, void* stream);
 
 /* out[i] = word (i & 3) of Philox counter (i >> 2) of the stream, modulo `modulus`: the generator's label draw
  * xp.random.randint(dim_zl, size=batchsize) (model/net.py:91-92) from the same keyed generator as the normals. */

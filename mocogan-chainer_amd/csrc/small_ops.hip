@@ -1194,6 +1194,23 @@ __global__ __launch_bounds__(NT) void split_planes_kernel(long long n8, long lon
         store_split8(dst, i * 8, run, load8(src, i * 8, 0));
 }
 
+// mcg_split_planes_multi: up to 32 (source, run, destination) segments in one launch.  A BLOCK belongs to one segment (found in the
+// prefix sums of the segments' block counts: a uniform scan, scalar loads of the kernel arguments -- a per-thread segment index would
+// put the argument arrays into scratch); its threads write the three planes exactly as split_planes_kernel does.
+constexpr int MAX_SPLIT_SEGS = 32;
+struct SplitSegs { const float* src[MAX_SPLIT_SEGS]; __bf16* dst[MAX_SPLIT_SEGS]; long long run[MAX_SPLIT_SEGS]; long long n8[MAX_SPLIT_SEGS];
+                   int blk_end[MAX_SPLIT_SEGS]; int nseg; };
+__global__ __launch_bounds__(NT) void split_planes_multi_kernel(SplitSegs sg) {
+    int s = 0;
+    while (s + 1 < sg.nseg && (int)blockIdx.x >= sg.blk_end[s]) ++s;                    // (block-uniform)
+    const int b0 = s ? sg.blk_end[s - 1] : 0, nb = sg.blk_end[s] - b0;
+    const float* __restrict__ src = sg.src[s];
+    __bf16* __restrict__ dst = sg.dst[s];
+    const long long run = sg.run[s], n8 = sg.n8[s];
+    for (long long i = (long long)((int)blockIdx.x - b0) * NT + threadIdx.x; i < n8; i += (long long)nb * NT)
+        store_split8(dst, i * 8, run, load8(src, i * 8, 0));
+}
+
 }  // namespace
 
 extern "C" int mcg_version(void) { return MCG_ABI_VERSION; }
@@ -1537,6 +1554,23 @@ extern "C" int mcg_adam_wd(int64_t n, float* p, const float* g, float* m, float*
 extern "C" int mcg_split_planes(int64_t n, int64_t run, const float* src, void* dst, void* stream) {
     if (!src || !dst || n <= 0 || run < 16 || (run & 15) || n % run) return MCG_ERR_BAD_ARG;
     hipLaunchKernelGGL(split_planes_kernel, dim3(ew_grid(n / 8)), dim3(NT), 0, (hipStream_t)stream, (long long)(n / 8), (long long)run, src, (__bf16*)dst);
+    return launch_status();
+}
+
+extern "C" int mcg_split_planes_multi(int nseg, const mcg_split_seg* segs, void* stream) {
+    if (!segs || nseg <= 0 || nseg > MAX_SPLIT_SEGS) return MCG_ERR_BAD_ARG;
+    SplitSegs sg;
+    int blocks = 0;
+    for (int s = 0; s < nseg; ++s) {
+        const mcg_split_seg& q = segs[s];
+        if (!q.src || !q.dst || q.n <= 0 || q.run < 16 || (q.run & 15) || q.n % q.run) return MCG_ERR_BAD_ARG;
+        long long nb = (q.n / 8 + NT - 1) / NT;
+        if (nb > 512) nb = 512;                                     // (a few MB per filter: 512 blocks of a segment keep every CU busy)
+        blocks += (int)nb;
+        sg.src[s] = q.src; sg.dst[s] = (__bf16*)q.dst; sg.run[s] = q.run; sg.n8[s] = q.n / 8; sg.blk_end[s] = blocks;
+    }
+    sg.nseg = nseg;
+    hipLaunchKernelGGL(split_planes_multi_kernel, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, sg);
     return launch_status();
 }
 

@@ -85,9 +85,10 @@ SIGNATURES = {
     "mcg_randn": (_I, [_I64, _F, _U64, _U64, _P, _P]),
     "mcg_randint": (_I, [_I64, _I, _U64, _U64, _P, _P]),
     "mcg_split_planes": (_I, [_I64, _I64, _P, _P, _P]),
+    "mcg_split_planes_multi": (_I, [_I, _P, _P]),
 }
 
-ABI_VERSION = 5          # MCG_ABI_VERSION of include/mocogan_hip.h these prototypes were written against
+ABI_VERSION = 6          # MCG_ABI_VERSION of include/mocogan_hip.h these prototypes were written against
 
 _lib = None
 
@@ -803,6 +804,28 @@ def adam_wd(p, g, m, v, lr_t, beta1, beta2, eps, wd, grad_scale=1.0, p16=None):
 def randint(out, modulus, seed, stream_id):
     """out (int32)[i] = Philox word i of the stream, modulo `modulus` (oracle.philox.randint states the same draw)"""
     _check(load().mcg_randint(out.numel(), int(modulus), seed, stream_id, _p(_dense(out), torch.int32), _stream()), "mcg_randint")
+
+
+class SplitSeg(C.Structure):                                       # mcg_split_seg
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("n", C.c_int64), ("run", C.c_int64)]
+
+
+def split_planes_multi(items):
+    """items: [(fp32 source tensor, run, bf16 destination tensor of 4x the elements), ...] -- mcg_split_planes of every item in ONE
+    launch (an 'f32x3' network's filters right after its Adam update).  The split operands count as GEMM time in bench.py's
+    roofline leg, as split_planes' do."""
+    segs = (SplitSeg * len(items))()
+    for q, (src, run, dst) in zip(segs, items):
+        assert src.is_contiguous() and dst.is_contiguous() and dst.dtype == torch.bfloat16 and dst.numel() == 4 * src.numel()
+        q.src, q.dst, q.n, q.run = src.data_ptr(), dst.data_ptr(), src.numel(), int(run)
+    e0 = None
+    if _timing is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _check(load().mcg_split_planes_multi(len(items), C.cast(segs, C.c_void_p), _stream()), "mcg_split_planes_multi")
+    if e0 is not None:
+        e1.record()
+        _timing.setdefault(_tag + ".split", []).append((e0, e1))
 
 
 def split_planes(src, run=16, out=None):

@@ -144,6 +144,26 @@ class _Net:
             cache[(name, form)] = ent = (self.fp.version, out)
         return ent[1]
 
+    def refresh_wsplits(self):
+        """Right after this network's Adam update ('f32x3' networks): every (filter, form) pair its launches have used so far is
+        re-split in ONE launch (mcg_split_planes_multi) instead of one launch per pair on first use -- 15 launches per iteration
+        became 2-3.  Pairs not yet in the cache (the first iteration) are still split on first use by _wsplit."""
+        cache = self.__dict__.get('_wsplits')
+        if not cache or self.precision != 'f32x3' or os.environ.get('MCG_WSPLIT_MULTI', '1') != '1':
+            return
+        items = []
+        for (name, form), (ver, out) in cache.items():
+            if ver != self.fp.version:
+                w = self.fp.param(name)
+                items.append((w, 16 if form == 'f' else 16 * (w.numel() // w.shape[0]), out))
+        if not items:
+            return
+        hl.set_tag(getattr(self, 'tag', 'G'))
+        for i in range(0, len(items), 32):
+            hl.split_planes_multi(items[i:i + 32])
+        for key in cache:
+            cache[key] = (self.fp.version, cache[key][1])
+
     def _cfprop(self, g, x, wname, w, b, y, ep=None, must_fuse=False, xs=None, force=False):
         """hl.conv_fprop of this network (w = the filter operand the caller would pass; xs: callable returning the split form of x).
         force: x exists in its split form ONLY (its producer relied on _split_only): the split launch is the only correct one."""

@@ -59,6 +59,7 @@ def adam_update(net, hyper, grad_scale=1.0):
     hl.adam_wd(fp.p, fp.g, fp.m, fp.v, hyper.lr(net.t), hyper.beta1, hyper.beta2, hyper.eps, hyper.weight_decay, grad_scale,
                p16=fp.p16 if net.precision == 'bf16' else None)
     fp.touch()
+    net.refresh_wsplits()                                         # ('f32x3': the split forms of the filters follow in one launch)
 
 
 class GradExchange:

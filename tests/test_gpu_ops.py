@@ -1060,6 +1060,26 @@ def test_split_planes_are_an_exact_expansion(hl):
         assert torch.equal((hi.double() + mid.double() + lo.double())[big], src.double()[big])
 
 
+def test_split_planes_multi_equals_the_single_launches(hl):
+    """mcg_split_planes_multi (ABI 6): several (source, run) segments in one launch -- the filters of an 'f32x3' network after its
+    Adam update -- write bit for bit what one mcg_split_planes per segment writes, into destinations of different sizes (incl. a
+    segment smaller than a block and one larger than the per-segment block cap), and leave the padding planes alone; bad segments
+    are refused."""
+    torch.manual_seed(9)
+    srcs = [(torch.randn((64, 4 * 16 * 64), device="cuda"), 16), (torch.randn((64, 4 * 16 * 64), device="cuda"), 16 * 4 * 16 * 64),
+            (torch.randn((16, 32), device="cuda"), 16), (torch.randn((512, 64 * 128), device="cuda") * 1e-3, 16),
+            (torch.randn((512, 64 * 128), device="cuda"), 16 * 64 * 128)]
+    want = [hl.split_planes(t, run=r, out=torch.full((t.shape[0], 4 * t.shape[1]), 7.0, device="cuda", dtype=torch.bfloat16)) for t, r in srcs]
+    got = [torch.full((t.shape[0], 4 * t.shape[1]), 7.0, device="cuda", dtype=torch.bfloat16) for t, _ in srcs]
+    hl.split_planes_multi([(t, r, o) for (t, r), o in zip(srcs, got)])
+    for w, g in zip(want, got):
+        assert torch.equal(w.view(torch.int16), g.view(torch.int16))
+    with pytest.raises(hl.McgError):
+        hl.split_planes_multi([(srcs[2][0], 24, got[2])])             # run not a multiple of 16
+    with pytest.raises(hl.McgError):
+        hl.split_planes_multi([(srcs[2][0], 16, got[2])] * 33)        # more segments than one launch takes
+
+
 @pytest.mark.parametrize("case", SPLIT_CASES)
 @pytest.mark.parametrize("tile", [0, 8, 10, 2007])           # (10: 128x128, two blocks per CU; 2007: the K range of a tile over four blocks)
 def test_split_fp32_products_match_the_oracle(hl, case, tile):

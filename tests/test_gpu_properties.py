@@ -47,10 +47,14 @@ def test_conv_passes_are_adjoint_and_linear_at_full_size(precision, tol, batch):
     hl.set_autotune(True)
     gen = torch.Generator(device='cuda')
     gen.manual_seed(5)
+    checked = refused = 0
     try:
         for name, N, T, H, Ci, Co, kt, ci_real in _step_layers(batch):
             split = precision == "f32x3" and Ci % 16 == 0 and Co % 16 == 0     # (the 4-channel layers of an f32x3 network run the fp32 kernels)
-            g = hl.make_geom(N, T, H, H, Ci, Co, kt, precision=precision if split else "f32" if precision == "f32x3" else precision)
+            # (ci_valid as the networks pass it: the shipped table's choices for the 4-channel layers -- e.g. the patch-in-LDS weight
+            #  gradient at 256 clips -- were made, and are only valid, for the clip's three data channels)
+            g = hl.make_geom(N, T, H, H, Ci, Co, kt, precision=precision if split else "f32" if precision == "f32x3" else precision,
+                             ci_valid=ci_real)
             if split and not (hl.split_covers('fprop', g) and hl.split_covers('dgrad', g) and hl.split_covers('wgrad', g)):
                 continue
             x = torch.randn((N, T, H, H, Ci), device='cuda', generator=gen)
@@ -63,11 +67,19 @@ def test_conv_passes_are_adjoint_and_linear_at_full_size(precision, tol, batch):
             y = torch.empty_like(gy)
             sp = (lambda t, **kw: hl.split_planes(t, **kw)) if split else (lambda t, **kw: t)
             wd = sp(w, run=16 * kt * 16 * Ci) if split else w              # the filter as the input gradient reads it
-            hl.conv_fprop(g, sp(x), sp(w), None, y)
             gx = torch.empty_like(x)
-            hl.conv_dgrad(g, sp(gy), wd, None, gx)
             gw = torch.zeros_like(w)
-            hl.conv_wgrad(g, sp(x), sp(gy), gw)
+            try:
+                hl.conv_fprop(g, sp(x), sp(w), None, y)
+                hl.conv_dgrad(g, sp(gy), wd, None, gx)
+                hl.conv_wgrad(g, sp(x), sp(gy), gw)
+            except hl.McgError:
+                # a geometry whose split form the library refuses in one of the passes (the network then runs that pass on the fp32
+                # kernels, nets._c*): nothing to check in the split form -- but most layers must have one
+                assert split, (name, precision)
+                refused += 1
+                continue
+            checked += 1
             a, b, c = _dot(y, gy), _dot(x, gx), _dot(w, gw)
             scale = float(torch.linalg.vector_norm(y.double()) * torch.linalg.vector_norm(gy.double()))
             assert abs(a - b) < tol * scale and abs(a - c) < tol * scale, (name, precision, a, b, c, scale)
@@ -81,6 +93,7 @@ def test_conv_passes_are_adjoint_and_linear_at_full_size(precision, tol, batch):
             err = float(torch.linalg.vector_norm((y3 - (2 * y - 3 * y2)).double()) / torch.linalg.vector_norm(y3.double()))
             assert err < (5e-6 if precision in ("f32", "f32x3") else 2e-2), (name, err)
             del x, x2, y, y2, y3, gy, gx, gw, w
+        assert checked >= 8 and refused <= checked // 3, (checked, refused)
     finally:
         hl.set_autotune(False)
 
