@@ -65,7 +65,6 @@ __device__ __forceinline__ void store_split8(__bf16* dst, long long e, long long
     *reinterpret_cast<bf16x8_t*>(d + 2 * run) = lo;        // (the fourth plane only pads a group to 128 bytes: no kernel fetches it)
 }
 __device__ __forceinline__ void store8(float* out, long long e, f32x8 v, int out16) {       // out16: MCG_IO_OUT_BF16 / MCG_IO_OUT_SPLIT / 0
-    if (out16 & MCG_IO_OUT_SPLIT) { store_split8(reinterpret_cast<__bf16*>(out), e, 16, v); return; }
     if (out16 & MCG_IO_OUT_SPLIT) { store_split8(reinterpret_cast<__bf16*>(out), e, 16, v); return; }     // (out16: MCG_IO_OUT_BF16 / _SPLIT / 0)
     if (out16) { *reinterpret_cast<bf16x8_t*>(reinterpret_cast<__bf16*>(out) + e) = __builtin_convertvector(v, bf16x8_t); return; }
     *reinterpret_cast<f32x4*>(out + e) = __builtin_shufflevector(v, v, 0, 1, 2, 3);

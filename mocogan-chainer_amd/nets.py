@@ -9,14 +9,13 @@ the dict returned by forward, which is what lets the step reproduce Chainer's "b
 already-updated weights" ordering (quirk Q5) exactly.
 """
 import math
+import os
 
 import numpy as np
 import torch
 
 from . import hiplib as hl
 from . import layout as lay
-
-import os
 
 NOISE_SIGMA_Z = 0.33          # make_hidden: np.random.normal(0, 0.33), model/net.py:55-56
 IMG = 64                      # output size hard-coded in the reference, model/net.py:115
