@@ -810,10 +810,15 @@ class SplitSeg(C.Structure):                                       # mcg_split_s
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("n", C.c_int64), ("run", C.c_int64)]
 
 
+split_multi_launches = 0                                       # (tests assert that the one-launch refresh really ran)
+
+
 def split_planes_multi(items):
     """items: [(fp32 source tensor, run, bf16 destination tensor of 4x the elements), ...] -- mcg_split_planes of every item in ONE
     launch (an 'f32x3' network's filters right after its Adam update).  The split operands count as GEMM time in bench.py's
     roofline leg, as split_planes' do."""
+    global split_multi_launches
+    split_multi_launches += 1
     segs = (SplitSeg * len(items))()
     for q, (src, run, dst) in zip(segs, items):
         assert src.is_contiguous() and dst.is_contiguous() and dst.dtype == torch.bfloat16 and dst.numel() == 4 * src.numel()
