@@ -147,6 +147,9 @@ __device__ __forceinline__ constexpr int sw_cols(int row, int chunks_per_row) {
 #ifndef MCG_V2_EARLY             // (round 5 experiment, measured and NOT kept: 1 = the barrier of K-step s + 1 in the middle of step s and
 #define MCG_V2_EARLY 0           //  that step's first fragments read under the last MFMA group of step s; see the K loop)
 #endif
+#ifndef MCG_PATCH_MERGE          // (1 = dgrad_patch_kernel with one barrier per two stages; see its pipeline comment)
+#define MCG_PATCH_MERGE 0
+#endif
 #ifndef MCG_V2_SKEW              // (round 5 experiment, measured and NOT kept: 1 = the two waves of a SIMD issue their LDS-DMA pieces at
 #define MCG_V2_SKEW 0            //  opposite ends of a K-step; see the K loop)
 #endif
@@ -2121,27 +2124,34 @@ __global__ __launch_bounds__(NT2) void dgrad_patch_kernel(DgPatchPol p) {
     // Pipeline: a stage = one (pw, bh, bw) of a super-step = one filter slice per wave set, 16 MFMAs per wave.  The filter stages run
     // THREE ahead in a ring of four (counted vmcnt: a wave issues 2 filter pieces per stage, plus one of the next patch's six pieces
     // in stages 0..5 -- waiting until at most 4 loads are outstanding retires everything but the two youngest stages' filter pieces).
+    // MERGE (round 5, -DMCG_PATCH_MERGE=1): ONE barrier per pair of stages (bw = 0, 1) -- the ring as two 32-KB halves, the pair two
+    // ahead loaded while a pair is multiplied (G + 2 instead of G + 3), `vmcnt(0)` in front of the barrier: a stage is 16 MFMAs per
+    // wave, half a GEMM K-step, and the barrier costs ~180 cycles of it (tools/mini_gemm_probe.hip)
+    constexpr bool MERGE = MCG_PATCH_MERGE != 0;
     issue_patch(0, 0, 6);
     const int total = 8 * S;
     issue_b(0);
     if (1 < total) issue_b(1); else { issue_b(0); }               // (the count of outstanding loads must not depend on S)
-    if (2 < total) issue_b(2); else { issue_b(0); }
+    if constexpr (!MERGE) { if (2 < total) issue_b(2); else { issue_b(0); } }
     for (int s = 0; s < S; ++s) {
         const unsigned char* pb = patch + (s & 1) * PATCH;
         static_for<0, 8>([&](auto q_) {
             constexpr int q = decltype(q_)::value, pw = q >> 2, bh = (q >> 1) & 1, bw = q & 1;
             const int G = 8 * s + q;
+            if constexpr (!MERGE || bw == 0) {
 #ifndef MCG_PP_NOVMWAIT          // (ablation: loads issued but never waited for -- what a longer look-ahead could gain at most)
-            wait_vmcnt<4>();
+                if constexpr (MERGE) wait_vmcnt<0>(); else wait_vmcnt<4>();
 #endif
 #ifndef MCG_PP_NOBAR
-            __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_barrier();
 #endif
+            }
             // This stage's loads -- one piece of the next patch (stages 0..5), the two filter pieces of stage G + 3 -- are NOT issued
             // here in a burst: every LDS-DMA instruction holds its wave's issue for 60-180 cycles, and behind the barrier all eight
             // waves would sit in that burst together with the matrix pipes idle.  They go between the MFMA groups below (same order
             // of issue, so the vmcnt arithmetic is unchanged): the MFMAs of a group run while the wave issues the next load.
-            const int Gn = G + 3 < total ? G + 3 : G;             // (past the end: a harmless reload into the slot read one stage ago)
+            const int Gn = MERGE ? (G + 2 < total ? G + 2 : G)    // (past the end: the stage's own slices again -- the same bytes)
+                                 : (G + 3 < total ? G + 3 : G);   // (past the end: a harmless reload into the slot read one stage ago)
 #ifdef MCG_PATCH_BURST       // (timing A/B: round 3's placement)
             if (q < 6 && s + 1 < S) issue_patch(s + 1, q, q + 1);
             issue_b(Gn);

@@ -102,6 +102,28 @@ class SerialIterator:
         return self
 
 
+def _remove_stale_slots(root='/dev/shm'):
+    """batch slots ('mcg_<pid>_...') of training processes that no longer exist -- a run that was killed could not unlink its own, and
+    /dev/shm is memory"""
+    try:
+        names = os.listdir(root)
+    except OSError:
+        return
+    for name in names:
+        parts = name.split('_')
+        if len(parts) == 4 and parts[0] == 'mcg' and parts[1].isdigit():
+            pid = int(parts[1])
+            try:
+                os.kill(pid, 0)                                       # (signal 0: existence check only)
+            except ProcessLookupError:
+                try:
+                    os.unlink(os.path.join(root, name))
+                except OSError:
+                    pass
+            except OSError:
+                pass                                                  # (exists, not ours to judge)
+
+
 class PrefetchIterator(SerialIterator):
     """SerialIterator's order and epoch bookkeeping, with the samples of the next `prefetch` batches being
     decoded by `n_workers` worker processes while the GPU trains (the reference's
@@ -134,6 +156,7 @@ class PrefetchIterator(SerialIterator):
         self._slots, self._free_slots, self._clip_shape = [], [], None
         if self._raw and os.environ.get('MCG_LOADER_SHM', '1') == '1':
             from multiprocessing import shared_memory
+            _remove_stale_slots()
             st = np.random.get_state()                                # (a dataset may draw sub-sequence offsets: the order stays SerialIterator's)
             self._clip_shape = tuple(np.asarray(dataset.get_example_raw(0)[0]).shape)
             np.random.set_state(st)
