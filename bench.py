@@ -526,7 +526,11 @@ def main():
     out = measure(args.model, args.dtype, args.batch, args.steps, args.warmup, args.overlap)
     # The other single-GPU workloads BASELINE.json names ride on the same line (a few steps each): configs[2] (bf16
     # networks, batch 256) and configs[3] (--model infogan, batch 32); on 8 GPUs configs[4] (global batch 1024).
-    headline_cfg = args.model == 'normal' and args.dtype == HEADLINE_DTYPE and args.batch == 32
+    # MCG_BENCH_REHEARSAL_BATCH (single-device rehearsals only, tests/test_gpu_dp.py): the per-rank batch that stands in for the
+    # headline's 32 and the 8-GPU secondaries' 128, so that a one-GPU box can walk the `world == 8` branch below in seconds
+    reh_b = int(os.environ.get('MCG_BENCH_REHEARSAL_BATCH', '0')) if rehearsal else 0
+    headline_cfg = args.model == 'normal' and args.dtype == HEADLINE_DTYPE and args.batch == (reh_b or 32)
+    sec_b = reh_b or 128
     secondary = []
 
     def also(model, dtype, B):
@@ -552,8 +556,8 @@ def main():
             also('normal', 'bf16', 256)
             also('infogan', HEADLINE_DTYPE, 32)
         elif world == 8 or os.environ.get('MCG_BENCH_SECONDARY_DP') == '1':
-            also('normal', HEADLINE_DTYPE, 128)
-            also('normal', other, 128)
+            also('normal', HEADLINE_DTYPE, sec_b)
+            also('normal', other, sec_b)
     if rank == 0 and args.save_tiles:
         hl.save_tile_choices(args.save_tiles)
     if rank == 0:

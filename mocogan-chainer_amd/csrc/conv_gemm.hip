@@ -433,6 +433,10 @@ struct DgradP {
         return k0;
     }
     __device__ int rotated(int k0) const { int k = k0 + krot; return k >= K ? k - K : k; }     // K-steps never straddle the wrap
+    // A split-K block whose K chunk holds no live temporal tap (rows near the temporal boundary: up to 3 of 4 chunks) has nothing
+    // to add to the cleared / accumulated x -- it leaves before its first load instead of adding a tile of zeros with float atomics
+    // (round 6: 12 of 28 blocks of D_V dc4's four-way split, each 16384 atomics).  Block-uniform: tmin, tmax and z are.
+    __device__ bool idle(int k_first, int kend) const { return kchunk < K && k_first >= kend && !(bias && zsplit == 0); }
     __device__ void load_a(int k0, f32x4 (&r)[NA]) const {
         if constexpr (ST) {
             if (g.lgCo >= 0 && (g.Co & (BK - 1)) == 0) {          // one sub-filter tap per K-step: scalar decode (as FpropP::load_a)
@@ -859,6 +863,10 @@ __device__ __forceinline__ void fused_epilogue(const P& p, f32x16 (&acc)[TM][TN]
     }
 }
 
+// p.idle(first live K-step, end of the block's K range) where the policy has one (DgradP), else false
+template <class P> __device__ __forceinline__ auto block_idle(const P& p, int k, int kend, int) -> decltype(p.idle(k, kend)) { return p.idle(k, kend); }
+template <class P> __device__ __forceinline__ bool block_idle(const P&, int, int, long) { return false; }
+
 // ------------------------------------------------------------------------------------------
 // The GEMM core
 // ------------------------------------------------------------------------------------------
@@ -936,6 +944,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(P p) {
     f32x4 ra[NA], rb[NB];
     const int kend = p.k_end(z);
     int k0 = p.next_valid(p.k_begin(z));
+    if (block_idle(p, k0, kend, 0)) return;
 #ifdef MCG_PROBE_NOLOOP        // (tools/probe_variant.py: what a block costs WITHOUT its K loop -- row decode, tap masks, store)
     k0 = kend;
 #endif
@@ -1182,6 +1191,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(P p) {
     f32x4 ra[NA], rb[NB];
     const int kend = p.k_end(z);
     int k0 = p.next_valid(p.k_begin(z));
+    if (block_idle(p, k0, kend, 0)) return;
     if (k0 < kend) { p.load_a(k0, ra); p.load_b(k0, rb); }
 
     constexpr int EA = P::EA, EB = P::EB;                 // 4: fp32 operand, rounded to bf16 here; 8: bf16 operand, stored as loaded
@@ -1619,6 +1629,7 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
     }
 
     int k_cur = p.next_valid(p.k_begin(z));
+    if (block_idle(p, k_cur, kend, 0)) return;                   // (before the first LDS-DMA load is in flight)
     int k_nx[STAGES - 1];                                        // the K-steps whose loads are (to be) in flight
     {
         int k = k_cur;

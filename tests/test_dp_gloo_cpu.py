@@ -141,7 +141,7 @@ def _epoch_worker(rank, world, port, q, n_items, batch, max_epoch):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_items,world,batch,max_epoch", [(11, 2, 2, 3), (7, 2, 4, 5)])
+@pytest.mark.parametrize("n_items,world,batch,max_epoch", [(11, 2, 2, 3), (7, 2, 4, 5), (19, 8, 2, 2)])      # (19 % 8 = 3: eight ranks, ragged shards)
 def test_ranks_reach_max_epoch_together_when_world_does_not_divide_the_dataset(n_items, world, batch, max_epoch):
     """train.py --dp_shard stops on (max_epoch, 'epoch') of each rank's OWN iterator (reference train.py:128-132); with shards of
     unequal length the short ranks would leave first and the long one would wait in the gradient all-reduce forever (advisor,
@@ -160,3 +160,60 @@ def test_ranks_reach_max_epoch_together_when_world_does_not_divide_the_dataset(n
     shard = -(-n_items // world)
     want_iters = -(-shard * max_epoch // batch)                   # SerialIterator: epoch e is complete after ceil(e * len / batch) batches
     assert [r[1] for r in res] == [want_iters] * world and [r[2] for r in res] == [max_epoch] * world
+
+
+def _exchange8_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import mocogan_chainer_amd.step as step
+        ex = step.GradExchange()
+        assert ex.active and ex.world == world and ex.grad_scale == 1.0 / world
+        res = {}
+        # three flat gradients in the order the iteration produces them (D_I, D_V, G: SURVEY 8e), D_V's and G's in two buckets with
+        # the LATE bucket started first (step.TrainStep.run starts it from the weight-gradient stream), every handle finished later
+        for name, n, cut in (('di', 1003, None), ('dv', 4099, 977), ('gen', 1301, 211)):
+            g = torch.Generator().manual_seed(1000 * rank + len(name))
+            flat = torch.randn(n, generator=g, dtype=torch.float32)
+            if cut is None:
+                handles = [ex.start(flat)]
+            else:
+                handles = [ex.start(flat[cut:]), ex.start(flat[:cut])]
+            for h in handles:
+                ex.finish(h)
+            res[name] = (flat * ex.grad_scale).numpy()
+        # the tile table / parameters travel from rank 0
+        t = torch.full((5,), float(rank))
+        ex.broadcast_params([t], src=0)
+        q.put((rank, res, t.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_rank_bucketed_exchange_averages_the_flat_gradients():
+    """configs[4]'s world size on CPU: GradExchange with EIGHT gloo ranks -- buckets of the three flat gradients started in the
+    iteration's order and finished later -- leaves every rank with the mean of the eight gradients (SUM, then grad_scale = 1/8 as
+    mcg_adam_wd applies it), bit-identical on all ranks, and rank 0's parameters everywhere."""
+    world = 8
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_exchange8_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    try:
+        res = sorted((q.get(timeout=300) for _ in procs), key=lambda r: r[0])
+    finally:
+        [p.join(60) for p in procs]
+        [p.kill() for p in procs if p.is_alive()]
+    assert all(p.exitcode == 0 for p in procs)
+    for name, n in (('di', 1003), ('dv', 4099), ('gen', 1301)):
+        want = np.zeros(n, np.float64)
+        for r in range(world):
+            g = torch.Generator().manual_seed(1000 * r + len(name))
+            want += torch.randn(n, generator=g, dtype=torch.float32).double().numpy()
+        want /= world
+        for r in range(world):
+            assert np.array_equal(res[r][1][name], res[0][1][name]), (name, r)          # replicas stay identical
+        assert np.allclose(res[0][1][name], want, rtol=1e-5, atol=1e-6), name
+    assert all(np.array_equal(r[2], np.zeros(5, np.float32)) for r in res)

@@ -276,3 +276,42 @@ def test_one_rank_rccl_rehearsal_of_the_bench_line():
     line = json.loads(lines[0])
     assert line['dist']['backend'] == 'nccl' and line['dist']['world_size'] == 1 and line['value'] > 0
     assert all(math.isfinite(v) for v in line['losses'].values()), line['losses']
+
+
+def test_four_rank_single_device_rehearsal_of_the_eight_gpu_branch():
+    """bench.py's `world == 8` branch -- every rank's preflight of a secondary workload, pretune_and_share_tiles, the configs[4]-shaped
+    secondaries in both fp32 forms, Philox rank offsets, the MAX-over-ranks timing, ONE stdout line from rank 0 -- walked on a one-GPU
+    box: the driver's own launch line (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`) with FOUR ranks on
+    cuda:0 over gloo (MCG_SINGLE_DEVICE / MCG_DIST_BACKEND), MCG_BENCH_SECONDARY_DP=1 taking the branch that `world == 8` takes, and
+    MCG_BENCH_REHEARSAL_BATCH=2 standing in for 32 / 128 clips per rank.  Four, not eight: this pool's GPU boxes admit at most six
+    processes on a card (the harness's process guard), so the eight-rank case itself cannot run before an 8-GPU node does; what
+    differs at eight is the value of `world` in the same code.  (reference train.py:87-91: the single-device assumption replaced.)"""
+    import json
+    import math
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        detail = os.path.join(tmp, 'detail.json')
+        env = dict(os.environ, MCG_SINGLE_DEVICE='1', MCG_DIST_BACKEND='gloo', MCG_BENCH_SECONDARY_DP='1', MCG_BENCH_REHEARSAL_BATCH='2',
+                   MCG_BENCH_DETAIL=detail, HSA_ENABLE_IPC_MODE_LEGACY='0')
+        for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+            env.pop(k, None)
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '4', '--master-addr', '127.0.0.1',
+               '--master-port', '37733', os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--steps', '2', '--warmup', '1', '--batch', '2',
+               '--secondary-steps', '2']
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = [l for l in out.stdout.strip().splitlines() if l.startswith('{')]
+        assert len(lines) == 1, out.stdout[-2000:]
+        line = json.loads(lines[0])
+        assert line['n_gpus'] == 4 and line['dist'] == {'backend': 'gloo', 'world_size': 4} and line['value'] > 0
+        assert line['config']['per_gpu_batch'] == 2 and line['config']['global_batch'] == 8 and line['config']['parallelism'] == 'dp4'
+        assert 'rehearsal' in line['data'] and 'cpu_baseline' not in line           # (a rehearsal is never a reported number)
+        assert all(math.isfinite(v) for v in line['losses'].values()), line['losses']
+        sec = line['secondary']
+        assert [s['dtype'] for s in sec] == ['f32x3', 'f32'] and all('error' not in s and s['value'] > 0 for s in sec), sec
+        full = json.load(open(detail))
+        assert [s['config']['global_batch'] for s in full['secondary']] == [8, 8]
+        assert all(s['dist']['world_size'] == 4 for s in full['secondary'])
+        ranks_ms = full['dist']['per_rank_ms_per_step']
+        assert ranks_ms['min'] > 0 and ranks_ms['max'] >= ranks_ms['median'] >= ranks_ms['min']
