@@ -52,9 +52,21 @@ def worker_init(seed, dataset):
     _WORKER['seed'], _WORKER['dataset'] = seed, dataset
 
 
-def worker_load(indices, raw, batch_no, chunk_no):
-    np.random.seed((int(_WORKER['seed']) * 1000003 + batch_no * 131 + chunk_no) % (2 ** 32))
-    return load_examples(_WORKER['dataset'], indices, raw)
+def _seed_sample(batch_no, pos):
+    """the worker's NumPy generator for ONE sample: (loader seed, batch number, position in the batch) -- the sampled sub-sequence
+    offsets then do not depend on how a batch is cut into worker tasks (--loader_workers, the chunk size), so a resumed run with
+    another worker count sees the same data stream (round 5's advice)"""
+    np.random.seed((int(_WORKER['seed']) * 1000003 + batch_no * 4099 + pos) % (2 ** 32))
+
+
+def worker_load(indices, raw, batch_no, first):
+    """`first`: position in the batch of indices[0]"""
+    ds = _WORKER['dataset']
+    out = []
+    for k, i in enumerate(indices):
+        _seed_sample(batch_no, first + k)
+        out.append(ds.get_example_raw(int(i)) if raw else ds.get_example(int(i)))
+    return np.stack([o[0] for o in out]), [o[1] for o in out]
 
 
 _SHM = {}
@@ -64,7 +76,6 @@ def worker_load_shm(indices, batch_no, chunk_no, shm_name, first, clip_shape):
     """As worker_load(raw=True), but the decoded uint8 frames go straight into clips [first, first + len(indices)) of the shared-memory
     segment `shm_name` (one batch slot of trainer.PrefetchIterator) instead of back through the result pipe -- at 256 clips per batch
     the pickled results (50 MB per batch) were what the loader spent its time on.  Returns the labels only."""
-    np.random.seed((int(_WORKER['seed']) * 1000003 + batch_no * 131 + chunk_no) % (2 ** 32))
     shm = _SHM.get(shm_name)
     if shm is None:
         from multiprocessing import shared_memory
@@ -76,6 +87,7 @@ def worker_load_shm(indices, batch_no, chunk_no, shm_name, first, clip_shape):
     arr = np.ndarray((shm.size // per,) + tuple(clip_shape), dtype=np.uint8, buffer=shm.buf)
     labels = []
     for k, i in enumerate(indices):
+        _seed_sample(batch_no, first + k)
         v, l = _WORKER['dataset'].get_example_raw(int(i))
         arr[first + k] = v
         labels.append(l)

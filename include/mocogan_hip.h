@@ -119,8 +119,9 @@ typedef struct mcg_conv_geom {
 } mcg_conv_geom;
 
 /* ABI revision of this header: a host built against another revision must not call in (argument lists differ).
- * 3 = round 3 (mcg_randint, bf16 tensors in the synchronised-BatchNorm backward; round 2 changed mcg_bn_act_fwd / mcg_bn_act_bwd / mcg_adam_wd / mcg_conv_geom). */
-#define MCG_ABI_VERSION 6
+ * 3 = round 3 (mcg_randint, bf16 tensors in the synchronised-BatchNorm backward; round 2 changed mcg_bn_act_fwd / mcg_bn_act_bwd / mcg_adam_wd / mcg_conv_geom);
+ * 6 = round 5 (mcg_split_planes_multi); 7 = round 6 (mcg_pack_clip_u8; nothing else changed). */
+#define MCG_ABI_VERSION 7
 int mcg_version(void);
 
 /* ---- implicit-GEMM convolution on the fp32 MFMA (v_mfma_f32_32x32x2_f32) ------------------- */
@@ -180,7 +181,11 @@ typedef struct mcg_conv_epilogue {
                                  * network read.  With the plain store or any epilogue (MCG_SUMS_BN_BWD: LDS-DMA kernels only); never with a
                                  * split-K tile code, an accumulating dgrad or the Ci = 4 layers (MCG_ERR_UNSUPPORTED).  The
                                  * sums of an epilogue are those of the STORED (rounded) values: BatchNorm then normalises the
-                                 * tensor it reads with that tensor's own mean and variance */
+                                 * tensor it reads with that tensor's own mean and variance.
+                                 * MCG_IO_OUT_SPLIT (ABI 7; mcg_conv_fprop_ex with act, Co a multiple of 16): y is written in the
+                                 * MCG_PREC_SPLIT layout [pixel][Co/16][4 planes][16] (uint16_t bf16 terms hi, mid, lo; the
+                                 * fourth plane is padding and is not written) -- bit for bit what mcg_split_planes(run 16)
+                                 * makes of the fp32 result, for a next layer whose GEMMs all read the split form */
     /* dgrad only: v *= (mask bit ? 1 : 0.2) -- leaky_relu's backward from the bits the forward pass stored */
     const uint32_t* mask_in;
     /* out (host side, valid after the call): */
@@ -294,6 +299,12 @@ int mcg_colsum_acc(int64_t M, int C, const float* g, float* db, void* workspace,
 int mcg_pack_clip(int N, int C, int Cp, int T, int HW, const float* x, int64_t x_stride_n,
                   int64_t x_stride_c, const float* addend,
                   float sigma, uint64_t seed, uint64_t stream_id, float* out, void* stream);
+/* The same from the loader's uint8 clips (reference datasets.py:95,108 decodes frames to (T,H,W,C) uint8 and normalises
+ * (v - 128) / 128 on the host; model/updater.py:87-92 stacks and transposes): out[N][T][HW][Cp] = (x[N][T][HW][C] - 128) / 128
+ * (+ noise as mcg_pack_clip, same counters), padded channels = 0.  Byte (n,t,hw,c) of x is at
+ * x + n*x_stride_n + t*x_stride_t + hw*C + c, so frame t of every clip is T = 1 with x + t*HW*C and the clip's x_stride_n. */
+int mcg_pack_clip_u8(int N, int C, int Cp, int T, int HW, const uint8_t* x, int64_t x_stride_n, int64_t x_stride_t,
+                     const float* addend, float sigma, uint64_t seed, uint64_t stream_id, float* out, void* stream);
 /* cgan (model/updater.py:65-76, concat_label_video): out[n][p][0..Cq) = x[n][p][0..C), then dl label planes -- +1 at channel
  * C + labels[n], -1 at the others -- then zeros; x is [N][P][Cp], out [N][P][Cq], Cq % 4 == 0, labels int32 [N] in [0, dl).
  * dl == 0 (labels may be NULL): a channel slice into another row width -- the way back, where label planes carry no gradient. */

@@ -79,7 +79,7 @@ struct Epi {
     int bn_y16;                 // bn_y is bf16 (LDS-DMA kernels' row-wise epilogue only)
     const float* addend[2]; float sigma; u64 seed; u64 stream[2];
     u32* mask_out; const u32* mask_in; int mask_cb;
-    int out16;                  // the output tensor is bf16 (bf16 networks: what the element-wise passes and the next GEMMs read;
+    int out16;                  // 2: MCG_IO_OUT_SPLIT (fused_epilogue's class-3 store only); 1: the output tensor is bf16 (bf16 networks: what the element-wise passes and the next GEMMs read;
                                 // plain store and epilogue classes 1 / 3; never with split-K, whose partial tiles are added in fp32)
 };
 struct RowInfo { long long base; long long pix; int grp; bool ok; };   // base: element offset of the row's column 0 in the output
@@ -152,6 +152,9 @@ __device__ __forceinline__ constexpr int sw_cols(int row, int chunks_per_row) {
 #endif
 #ifndef MCG_V2_SKEW              // (round 5 experiment, measured and NOT kept: 1 = the two waves of a SIMD issue their LDS-DMA pieces at
 #define MCG_V2_SKEW 0            //  opposite ends of a K-step; see the K loop)
+#endif
+#ifndef MCG_C4_AB                // (round 6 experiment, measured and NOT kept: 1 = D_V's first layer forward as fprop_c4_ab_kernel -- its two
+#define MCG_C4_AB 0              //  wave groups half a frame step apart, filters in registers; see that kernel)
 #endif
 #ifndef MCG_PROBE_HALFREADS      // (tools/probe_variant.py: the LDS-DMA GEMM with half its fragment reads -- what a body with half the
 #define MCG_PROBE_HALFREADS 0    //  LDS read bytes per FLOP could gain at most; results are garbage)
@@ -820,7 +823,16 @@ __device__ __forceinline__ void fused_epilogue(const P& p, f32x16 (&acc)[TM][TN]
                     }
                     if constexpr (!STORE) acc[a][b][4 * q + i] = v;
                     else if (ok) {
-                        if (e.out16) reinterpret_cast<__bf16*>(out)[o] = (__bf16)v;
+                        if (EPI == 3 && e.out16 == 2) {              // (class 3 only: the other instantiations keep their code)
+                            // MCG_IO_OUT_SPLIT (round 6, D's first layer of an 'f32x3' network): the value leaves as the three bf16
+                            // terms the next layer's split GEMMs read -- [pixel][C / 16][4 planes][16], exactly what
+                            // mcg_split_planes would make of the fp32 tensor, which is then never written (nor read back and split)
+                            __bf16* d = reinterpret_cast<__bf16*>(out) + ri.pix * (4ll * C) + (col >> 4) * 64 + (col & 15);
+                            const __bf16 hi = (__bf16)v;
+                            const float r1 = v - (float)hi;
+                            const __bf16 mid = (__bf16)r1;
+                            d[0] = hi; d[16] = mid; d[32] = (__bf16)(r1 - (float)mid);
+                        } else if (e.out16) reinterpret_cast<__bf16*>(out)[o] = (__bf16)v;
                         else out[o] = v;
                     }
                     if (mode & EPI_SUMS) {
@@ -2413,6 +2425,150 @@ __global__ __launch_bounds__(512) void fprop_c4_kernel(C4FpropP p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// fprop_c4_kernel with its two halves of a frame step OVERLAPPED (round 6; 3-D layers with <= 3 data channels: D_V's dc1).
+// In fprop_c4_kernel the eight waves of a block multiply together, then run their epilogues together (row decode, leaky_relu, the
+// in-kernel Philox noise, 32 stores per lane), then meet at two barriers: while the epilogues run the matrix pipe idles -- measured
+// at 64 clips: 0.225 ms for the plain store, 0.27-0.29 ms with the first layer's activation + noise epilogue, against 0.133 ms of
+// MFMA work.  Here the two waves that share a SIMD (waves w and w + 4: a workgroup's waves go to the SIMDs cyclically) run HALF A
+// STEP APART: in every half-step one of them multiplies (192 MFMAs, the matrix pipe to itself) and the other runs the epilogue of
+// the step it multiplied in the previous half.  What makes room for it:
+//   * the filters live in REGISTERS (a lane's B operands: 4 x 4 x 2 taps x 3 channels = 96 values of its output channel), so LDS
+//     holds only the patch ring -- 98 KB -- and the K loop reads LDS for the A operand alone;
+//   * the ring has kt + 1 slabs: frame k + kt is loaded (global -> registers) in the first half of step k, stored in the second
+//     half into the slot of frame k - 1, whose last reader (group 1, second half of step k - 1) is a barrier behind; its first
+//     reader (group 0, first half of step k + 1) a barrier ahead.  One barrier per half-step.
+//   * A fragments are read one (frame, kh, tap pair) group ahead of the MFMAs that use them: with ONE multiplying wave per SIMD
+//     nobody else hides the LDS latency.
+// Same arithmetic, same order of additions as fprop_c4_kernel<KT, WO, EPI, 3>: bit-identical results
+// (tests/test_gpu_ops.py::test_overlapped_first_layer_forward_equals_the_weight_stationary_kernel passes with -DMCG_C4_AB=1).
+// MEASURED (MI355X, D_V dc1 at 64 clips, plain store, alternating launches on one box, profiles/r06_c4_overlap_ab.txt): 0.247-0.249 ms
+// against 0.222-0.228 ms for fprop_c4_kernel -- SLOWER.  194 VGPRs, no spills, 192 MFMAs per half-step in groups of six behind
+// one-group-ahead LDS reads: the schedule is the intended one.  What it shows: on the fp32 MFMA the epilogue's VALU instructions do
+// not run beside another wave's MFMAs -- the v_mfma_f32_32x32x2_f32 stream and the VALU share the SIMD's issue (what the fp32 GEMM
+// core's loaders showed in round 1) -- so a step costs MFMA cycles + epilogue VALU cycles however the waves are phased, and the
+// single multiplying wave per SIMD additionally exposes LDS latency that two interleaved waves hide.  Off (MCG_C4_AB = 0).
+// ------------------------------------------------------------------------------------------
+#if MCG_C4_AB
+template <int WO, int EPI>
+__global__ __launch_bounds__(512) void fprop_c4_ab_kernel(C4FpropP p) {
+    constexpr int KT = 4, RING = KT + 1, BM = 256, BN = 64, K = KT * 64;
+    constexpr int R = BM / WO, PR = 2 * R + 2, WI = 2 * WO;
+    constexpr int PLANE = (WO + 2) * 16, ROW = 2 * PLANE, SLAB = PR * ROW;             // bytes (layout of fprop_c4_kernel)
+    constexpr int ENT = 2 * (WO + 2), NLD = (PR * ENT + 511) / 512;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* pl = smem;                                  // RING * SLAB
+    const Geom& g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int grp = wave >> 2;                                 // 0: multiplies in the even half-steps, 1: in the odd ones
+    const int hblocks = g.Ho / R;
+    const int n = blockIdx.x / hblocks, ho0 = (blockIdx.x - n * hblocks) * R;
+    const __amdgpu_buffer_rsrc_t xr = make_srd(p.x, g.x_bytes);
+
+    // ---- this lane's B operands (output channel wn * 32 + li; lane half lh takes the taps kw = 2 j2 + lh) -> registers
+    const int wm = wave >> 1, wn = wave & 1;                   // (the wave grid fused_epilogue<.., 4, 2, ..> assumes)
+    float wr[KT][4][2][3];
+    {
+        const float* wp = p.w + (long long)(wn * 32 + li) * K + lh * 4;
+#pragma unroll
+        for (int a = 0; a < KT; ++a)
+#pragma unroll
+            for (int kh = 0; kh < 4; ++kh)
+#pragma unroll
+                for (int j2 = 0; j2 < 2; ++j2) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(wp + ((a * 4 + kh) * 4 + 2 * j2) * 4);
+                    wr[a][kh][j2][0] = v[0]; wr[a][kh][j2][1] = v[1]; wr[a][kh][j2][2] = v[2];
+                }
+    }
+    // ---- patch slabs, as fprop_c4_kernel: entry e of patch row pr is input pixel (hi, wi) = (2 ho0 - 1 + pr, e - 1)
+    u32 goff[NLD]; int loff[NLD];
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int idx = tid + 512 * j, pr = idx / ENT, en = idx - pr * ENT;
+        const int hi = 2 * ho0 - 1 + pr, wi = en - 1;
+        const bool ok = pr < PR && (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)WI;
+        goff[j] = ok ? (u32)(((long long)n * g.Ti * g.Hi + hi) * WI + wi) * 16u : OOB;
+        loff[j] = pr < PR ? pr * ROW + (en & 1) * PLANE + (en >> 1) * 16 : -1;
+    }
+    const u32 fbytes = (u32)g.Hi * WI * 16u;
+    f32x4 stage[NLD];
+    auto slab_load = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) stage[j] = bload(xr, goff[j] == OOB ? OOB : goff[j] + (u32)t * fbytes);
+    };
+    auto slab_store = [&](int slot) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j)
+            if (loff[j] >= 0) *reinterpret_cast<f32x4*>(pl + slot * SLAB + loff[j]) = stage[j];
+    };
+#pragma unroll
+    for (int t = 0; t < KT; ++t) { slab_load(t); slab_store(t); }
+    __syncthreads();
+
+    int abase[2];
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx) {
+        const int r = wm * 64 + sidx * 32 + li, hol = r / WO, wo = r - hol * WO;
+        abase[sidx] = (2 * hol) * ROW + lh * PLANE + wo * 16;
+    }
+
+    f32x16 acc[2][1];
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[sidx][0][r] = 0.f;
+    const int To = g.To;
+    // half-step h: step k = h >> 1.  Group 0 multiplies step k in h = 2 k and stores it in h = 2 k + 1; group 1 multiplies step k in
+    // h = 2 k + 1 and stores it in h = 2 k + 2 (the last half-step, h = 2 To, only drains group 1).
+    for (int h = 0; h <= 2 * To; ++h) {
+        const int k = h >> 1;
+        const bool even = (h & 1) == 0;
+        const bool more = k + KT < g.Ti;                       // (k + KT < Ti implies k < To)
+        if (even && more) slab_load(k + KT);                   // lands under this half-step's work ...
+        if (!even && more) { int sl = k + KT; sl -= (sl / RING) * RING; slab_store(sl); }      // ... and goes into frame k - 1's slot a barrier later
+        if (((h + grp) & 1) == 0) {
+            const int km = (h - grp) >> 1;                     // the step this wave multiplies now
+            if (km < To) {
+#pragma unroll
+                for (int sidx = 0; sidx < 2; ++sidx)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[sidx][0][r] = 0.f;
+                const int s0 = km - (km / RING) * RING;
+                int sb[KT];
+#pragma unroll
+                for (int a = 0; a < KT; ++a) { int sl = s0 + a; sl = sl >= RING ? sl - RING : sl; sb[a] = sl * SLAB; }
+                f32x4 av[2][2];                                // [buffer][sidx]: group gi + 1 is read under the MFMAs of group gi
+#pragma unroll
+                for (int sidx = 0; sidx < 2; ++sidx) av[0][sidx] = *reinterpret_cast<const f32x4*>(pl + sb[0] + abase[sidx]);
+#pragma unroll
+                for (int gi = 0; gi < KT * 8; ++gi) {          // gi = (a * 4 + kh) * 2 + j2
+                    const int a = gi >> 3, kh = (gi >> 1) & 3, j2 = gi & 1;
+                    if (gi + 1 < KT * 8) {
+                        const int a1 = (gi + 1) >> 3, kh1 = ((gi + 1) >> 1) & 3, j21 = (gi + 1) & 1;
+#pragma unroll
+                        for (int sidx = 0; sidx < 2; ++sidx)
+                            av[(gi + 1) & 1][sidx] = *reinterpret_cast<const f32x4*>(pl + sb[a1] + abase[sidx] + kh1 * ROW + j21 * 16);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+#pragma unroll
+                        for (int sidx = 0; sidx < 2; ++sidx)
+                            acc[sidx][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[gi & 1][sidx][c], wr[a][kh][j2][c], acc[sidx][0], 0, 0, 0);
+                }
+            }
+        } else {
+            const int ke = (h - grp - 1) >> 1;                 // the step this wave multiplied in the previous half-step
+            if (ke >= 0 && ke < To) {
+                const int m0 = ((n * To + ke) * g.Ho + ho0) * WO;
+                fused_epilogue<C4FpropP, BM, BN, 4, 2, 2, 1, EPI>(p, acc, m0, 0, m0 / BM, 0, tid, reinterpret_cast<float*>(smem));
+            }
+        }
+        __syncthreads();
+    }
+}
+#endif  // MCG_C4_AB
+
 // The same kernel on the bf16 MFMA (v_mfma_f32_32x32x16_bf16) for networks in bf16 mode: x and w (fp32 in memory: the
 // first layer's tensors stay fp32) are rounded to bf16 on their way into LDS.  One MFMA covers the 4 kw x 4 channels
 // of a (frame, kh) filter row: lane half h reads the two adjacent pixels kw = 2h, 2h + 1 of its output pixel as one
@@ -2834,6 +2990,36 @@ int launch_fprop_c4(const Geom& g, const float* x, const float* w, const float* 
 #undef MCG_C4_LAUNCH
     return MCG_OK;
 }
+
+#if MCG_C4_AB
+// fprop_c4_ab_kernel (the overlapped form): 3-D layers of the padded RGB clip on the fp32 MFMA, plain store or the first layer's epilogue
+// (neither has per-channel sums: fused_epilogue then runs without a block barrier, which the two wave groups could not share)
+bool c4_fprop_ab_ok(const Geom& g, const Epi& e) {
+    return c4_fprop_ok(g, e) && g.kt == 4 && g.cv <= 3 && g.prec == MCG_PREC_F32 && (e.mode == 0 || e.mode == EPI_ACT) && !e.out16;
+}
+
+template <int WO>
+int launch_fprop_c4_ab(const Geom& g, const float* x, const float* w, const float* bias, float* y, const Epi& e, hipStream_t s) {
+    C4FpropP p;
+    p.g = g; p.e = e; p.x = x; p.w = w; p.bias = bias; p.y = y;
+    p.M = g.N * g.To * g.Ho * g.Wo;
+    constexpr int R = 256 / WO;
+    const size_t lds = (size_t)5 * (2 * R + 2) * 2 * (WO + 2) * 16;
+    static std::once_flag once[2];
+    hipError_t attr = hipSuccess;
+    const dim3 grid(g.N * (g.Ho / R));
+    if (e.mode & EPI_ACT) {
+        std::call_once(once[0], [&] { attr = hipFuncSetAttribute((const void*)fprop_c4_ab_kernel<WO, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+        if (attr != hipSuccess) return MCG_ERR_LAUNCH;
+        hipLaunchKernelGGL((fprop_c4_ab_kernel<WO, 3>), grid, dim3(512), lds, s, p);
+    } else {
+        std::call_once(once[1], [&] { attr = hipFuncSetAttribute((const void*)fprop_c4_ab_kernel<WO, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+        if (attr != hipSuccess) return MCG_ERR_LAUNCH;
+        hipLaunchKernelGGL((fprop_c4_ab_kernel<WO, 1>), grid, dim3(512), lds, s, p);
+    }
+    return MCG_OK;
+}
+#endif  // MCG_C4_AB
 
 // the MFMA col2im input-gradient kernel of the Ci = 4 layers: what it covers
 bool c4_dgrad_mfma_ok(const Geom& g, const Epi& e, const float* bias, int act, int accumulate) {
@@ -3461,7 +3647,10 @@ int make_epi(const mcg_conv_epilogue* ep, const Geom& g, int pass, Epi& e) {
         e.sigma = ep->sigma; e.seed = ep->seed; e.stream[0] = ep->stream_id[0]; e.stream[1] = ep->stream_id[1];
         e.mask_out = ep->mask_out;
     } else if (ep->mask_out) return MCG_ERR_BAD_ARG;
-    e.out16 = ep->out_bf16 ? 1 : 0;
+    e.out16 = (ep->out_bf16 & MCG_IO_OUT_SPLIT) ? 2 : ep->out_bf16 ? 1 : 0;
+    // the split output: forward, with the first layer's activation epilogue (the only class whose values leave through fused_epilogue's
+    // element-wise store), whole groups of 16 channels
+    if (e.out16 == 2 && (pass != 0 || !(e.mode & EPI_ACT) || (C & 15))) return MCG_ERR_UNSUPPORTED;
     if (ep->mask_in) {
         if (pass != 1) return MCG_ERR_UNSUPPORTED;
         e.mode |= EPI_MASKMUL; e.mask_in = ep->mask_in;
@@ -3502,6 +3691,10 @@ int conv_fprop_impl(const mcg_conv_geom* c, const float* x, const float* w, cons
         if (g.prec == MCG_PREC_BF16) {
             if (g.kt == 4) st = g.Wo == 32 ? launch_fprop_c4_bf16<4, 32>(g, x, w, bias, y, e, s) : launch_fprop_c4_bf16<4, 16>(g, x, w, bias, y, e, s);
             else st = g.Wo == 32 ? launch_fprop_c4_bf16<1, 32>(g, x, w, bias, y, e, s) : launch_fprop_c4_bf16<1, 16>(g, x, w, bias, y, e, s);
+#if MCG_C4_AB
+        } else if (t == 0 && c4_fprop_ab_ok(g, e)) {               // round 6 experiment: multiply and epilogue phases overlapped (tile code 6 keeps fprop_c4_kernel)
+            st = g.Wo == 32 ? launch_fprop_c4_ab<32>(g, x, w, bias, y, e, s) : launch_fprop_c4_ab<16>(g, x, w, bias, y, e, s);
+#endif
         } else {
             if (g.kt == 4) st = g.Wo == 32 ? launch_fprop_c4<4, 32>(g, x, w, bias, y, e, s) : launch_fprop_c4<4, 16>(g, x, w, bias, y, e, s);
             else st = g.Wo == 32 ? launch_fprop_c4<1, 32>(g, x, w, bias, y, e, s) : launch_fprop_c4<1, 16>(g, x, w, bias, y, e, s);
@@ -3730,8 +3923,9 @@ extern "C" int mcg_conv_wgrad(const mcg_conv_geom* c, const float* x, const floa
 }
 
 // ---- fully-connected layers on the GEMM core (called by mcg_fc_fprop / mcg_fc_wgrad in small_ops.hip when the
-// output width is large enough to fill MFMA tiles; not part of the public header) ----
-extern "C" int mcg_detail_fc_fprop_gemm(int M, int K, int N, const float* x, const float* w, const float* bias, float* y, void* stream) {
+// output width is large enough to fill MFMA tiles; not part of the public header: hidden visibility, the shared library does
+// not export them) ----
+extern "C" __attribute__((visibility("hidden"))) int mcg_detail_fc_fprop_gemm(int M, int K, int N, const float* x, const float* w, const float* bias, float* y, void* stream) {
     if ((K & 63) || (long long)M * K * 4 >= (1ll << 31) || (long long)N * K * 4 >= (1ll << 31)) return MCG_ERR_UNSUPPORTED;
     constexpr int BM = 64, BN = 64, BK = 64;
     FcFpropP<BM, BN, BK> p;
@@ -3750,7 +3944,7 @@ extern "C" int mcg_detail_fc_fprop_gemm(int M, int K, int N, const float* x, con
     return launch_status();
 }
 
-extern "C" int mcg_detail_fc_wgrad_gemm(int M, int K, int N, const float* x, const float* y, float* dw, void* stream) {
+extern "C" __attribute__((visibility("hidden"))) int mcg_detail_fc_wgrad_gemm(int M, int K, int N, const float* x, const float* y, float* dw, void* stream) {
     if ((K & 3) || (N & 3) || (long long)M * K * 4 >= (1ll << 31) || (long long)M * N * 4 >= (1ll << 31)) return MCG_ERR_UNSUPPORTED;
     constexpr int BM = 64, BN = 64, BK = 32;
     FcWgradP<BM, BN, BK> p;

@@ -566,6 +566,41 @@ __global__ __launch_bounds__(NT) void pack_clip_kernel(int N, int C, int Cp, int
     }
 }
 
+// The loader's clips as they arrive: uint8 [n][t][hw][C] (datasets.py:95 decodes to (T,H,W,C); the reference normalises and
+// transposes on the host, model/updater.py:87-92).  One pass does what five torch passes did on the product path (uint8 -> float,
+// - 128, / 128, permute to (N,C,T,H,W), and mcg_pack_clip back to channels-last): (v - 128) / 128 into the device layout
+// [n][t][hw][Cp], zero channel pad, + noise drawn exactly as pack_clip_kernel draws it (one Philox counter per 4-channel group).
+// sn / st: BYTE strides of the batch item and the frame in x (a single frame per item: T = 1, sn = T_clip * HW * C).
+__global__ __launch_bounds__(NT) void pack_clip_u8_kernel(int N, int C, int Cp, int T, int HW, const uint8_t* __restrict__ x,
+                                                          long long sn, long long st,
+                                                          const float* __restrict__ addend, float sigma, uint64_t seed,
+                                                          uint64_t stream_id, float* __restrict__ out) {
+    const long long npix = (long long)N * T * HW;
+    const int Cp4 = Cp >> 2;
+    for (long long p = (long long)blockIdx.x * NT + threadIdx.x; p < npix; p += (long long)gridDim.x * NT) {
+        int hw = (int)(p % HW);
+        long long q = p / HW;
+        int t = (int)(q % T), n = (int)(q / T);
+        const uint8_t* src = x + (long long)n * sn + (long long)t * st + (long long)hw * C;
+        for (int c4 = 0; c4 < Cp4; ++c4) {
+            f32x4 v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int c = c4 * 4 + k;
+                v[k] = c < C ? ((float)src[c] - 128.f) / 128.f : 0.f;
+            }
+            long long i4 = p * Cp4 + c4;
+            if (addend) v += *reinterpret_cast<const f32x4*>(addend + i4 * 4);
+            else if (sigma > 0.f) {
+                f32x4 z = randn4((uint64_t)i4, seed, stream_id);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (c4 * 4 + k < C) v[k] = fmaf(sigma, z[k], v[k]);
+            }
+            *reinterpret_cast<f32x4*>(out + i4 * 4) = v;
+        }
+    }
+}
+
 // cgan (model/updater.py:65-76): the first C channels of every pixel, then dl label planes (+1 on the item's label, -1 elsewhere),
 // then zero padding.  dl == 0: a plain channel slice into another row width (the way back: label planes carry no gradient).
 __global__ __launch_bounds__(NT) void concat_label_planes_kernel(long long npix, long long P, int C, int Cp, int dl, int Cq,
@@ -1429,6 +1464,15 @@ extern "C" int mcg_pack_clip(int N, int C, int Cp, int T, int HW, const float* x
     return launch_status();
 }
 
+extern "C" int mcg_pack_clip_u8(int N, int C, int Cp, int T, int HW, const uint8_t* x, int64_t x_stride_n, int64_t x_stride_t,
+                                const float* addend, float sigma, uint64_t seed, uint64_t stream_id, float* out, void* stream) {
+    if (!x || !out || N <= 0 || C <= 0 || Cp < C || (Cp & 3) || T <= 0 || HW <= 0 || x_stride_n < 0 || x_stride_t < 0) return MCG_ERR_BAD_ARG;
+    long long npix = (long long)N * T * HW;
+    hipLaunchKernelGGL(pack_clip_u8_kernel, dim3(ew_grid(npix)), dim3(NT), 0, (hipStream_t)stream, N, C, Cp, T, HW, x,
+                       (long long)x_stride_n, (long long)x_stride_t, addend, sigma, seed, stream_id, out);
+    return launch_status();
+}
+
 extern "C" int mcg_concat_label_planes(int N, int64_t P, int C, int Cp, int dl, int Cq, const float* x, const int32_t* labels, float* out,
                                        void* stream) {
     if (!x || !out || N <= 0 || P <= 0 || C <= 0 || Cp < C || dl < 0 || Cq < C + dl || (Cq & 3) || (dl && !labels)) return MCG_ERR_BAD_ARG;
@@ -1453,8 +1497,8 @@ extern "C" int mcg_tanh_bwd_to_frames(int N, int T, int64_t frame_elems, const f
 }
 
 // conv_gemm.hip: the fully-connected layers with a real output width run on the MFMA GEMM core
-extern "C" int mcg_detail_fc_fprop_gemm(int M, int K, int N, const float* x, const float* w, const float* bias, float* y, void* stream);
-extern "C" int mcg_detail_fc_wgrad_gemm(int M, int K, int N, const float* x, const float* y, float* dw, void* stream);
+extern "C" __attribute__((visibility("hidden"))) int mcg_detail_fc_fprop_gemm(int M, int K, int N, const float* x, const float* w, const float* bias, float* y, void* stream);
+extern "C" __attribute__((visibility("hidden"))) int mcg_detail_fc_wgrad_gemm(int M, int K, int N, const float* x, const float* y, float* dw, void* stream);
 
 extern "C" int mcg_fc_fprop(int M, int K, int Co, const float* x, const float* w, const float* bias, float* y, void* stream) {
     if (!x || !w || !y || M <= 0 || K <= 0 || (K & 3) || Co <= 0) return MCG_ERR_BAD_ARG;

@@ -75,6 +75,7 @@ SIGNATURES = {
     "mcg_colsum_acc": (_I, [_I64, _I, _P, _P, _P, _P]),
     "mcg_pack_clip": (_I, [_I, _I, _I, _I, _I, _P, _I64, _I64, _P, _F, _U64, _U64, _P, _P]),
     "mcg_unpack_clip": (_I, [_I, _I, _I, _I, _I, _P, _P, _P]),
+    "mcg_pack_clip_u8": (_I, [_I, _I, _I, _I, _I, _P, _I64, _I64, _P, _F, _U64, _U64, _P, _P]),
     "mcg_concat_label_planes": (_I, [_I, _I64, _I, _I, _I, _I, _P, _P, _P, _P]),
     "mcg_tanh_bwd_to_frames": (_I, [_I, _I, _I64, _P, _P, _P, _P]),
     "mcg_gru_seq_fwd": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -88,7 +89,7 @@ SIGNATURES = {
     "mcg_split_planes_multi": (_I, [_I, _P, _P]),
 }
 
-ABI_VERSION = 6          # MCG_ABI_VERSION of include/mocogan_hip.h these prototypes were written against
+ABI_VERSION = 7          # MCG_ABI_VERSION of include/mocogan_hip.h these prototypes were written against
 
 _lib = None
 
@@ -213,6 +214,10 @@ def set_tag(tag):
     """Label (network name) attached to the conv launches that follow."""
     global _tag
     _tag = tag
+
+
+def get_tag():
+    return _tag
 
 
 def timing_begin():
@@ -517,7 +522,7 @@ def _vp(t, dtype=torch.float32):
 
 
 def epilogue(sums=SUMS_NONE, groups=1, part=None, bn_y=None, bn_stats=(None, None), bn_act=ACT_NONE, act=ACT_NONE,
-             addend=(None, None), sigma=0.0, seed=0, stream_id=(0, 0), mask_out=None, mask_in=None, out_bf16=False):
+             addend=(None, None), sigma=0.0, seed=0, stream_id=(0, 0), mask_out=None, mask_in=None, out_bf16=False, out_split=False):
     """Builds a ConvEpilogue; the tensors must stay alive until the launch has been queued (they are the caller's)."""
     ep = ConvEpilogue()
     y16 = bn_y is not None and bn_y.dtype == torch.bfloat16
@@ -529,7 +534,7 @@ def epilogue(sums=SUMS_NONE, groups=1, part=None, bn_y=None, bn_stats=(None, Non
     ep.sigma, ep.seed = float(sigma), int(seed)
     ep.stream_id[0], ep.stream_id[1] = int(stream_id[0]), int(stream_id[1] if len(stream_id) > 1 else 0)
     ep.mask_out, ep.mask_in = _vp(_dense(mask_out), torch.int32), _vp(_dense(mask_in), torch.int32)
-    ep.out_bf16 = int(bool(out_bf16))
+    ep.out_bf16 = IO_OUT_SPLIT if out_split else int(bool(out_bf16))      # (out_split: the MCG_PREC_SPLIT layout, a bf16 tensor of 4 * Co columns)
     return ep
 
 
@@ -749,10 +754,23 @@ def colsum_acc(M, Cn, g, db, ws):
 
 def pack_clip(N, Cn, Cp, T, HW, x, out, addend=None, sigma=0.0, seed=0, stream_id=0, stride_n=None, stride_c=None):
     """x: reference-layout (N,C,T,H,W) tensor, or a frame view of one with explicit strides."""
+    if stride_n is None and stride_c is None:
+        _dense(x)                                          # (default strides are those of a dense tensor: a permuted view would be misread)
     stride_n = Cn * T * HW if stride_n is None else stride_n
     stride_c = T * HW if stride_c is None else stride_c
     _check(load().mcg_pack_clip(N, Cn, Cp, T, HW, _p(x), stride_n, stride_c, _p(_dense(addend)), sigma, seed, stream_id,
                                 _p(_dense(out)), _stream()), "mcg_pack_clip")
+
+
+def pack_clip_u8(N, Cn, Cp, T, HW, x, out, addend=None, sigma=0.0, seed=0, stream_id=0, stride_n=None, stride_t=None):
+    """x: the loader's uint8 clips (N,T,H,W,C), or frame x[:, t] of them (T = 1, the clip's stride_n): -> (x - 128) / 128 in the
+    device layout [N][T][HW][Cp] (+ noise as pack_clip)."""
+    if stride_n is None and stride_t is None:
+        _dense(x)
+    stride_t = HW * Cn if stride_t is None else stride_t
+    stride_n = T * stride_t if stride_n is None else stride_n
+    _check(load().mcg_pack_clip_u8(N, Cn, Cp, T, HW, _p(x, torch.uint8), stride_n, stride_t, _p(_dense(addend)), sigma, seed, stream_id,
+                                   _p(_dense(out)), _stream()), "mcg_pack_clip_u8")
 
 
 def concat_label_planes(x, c, dl, labels, out):

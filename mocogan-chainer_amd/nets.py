@@ -37,6 +37,7 @@ OUT16 = os.environ.get('MCG_OUT16', '1') == '1'        # bf16 networks: GEMM out
 Y16 = os.environ.get('MCG_Y16', '1') == '1'            # bf16 networks: the 64-channel neighbours of the clip (dc1's output gradient in D, the last
                                                        # layer's input and its gradient in G) stored in bf16, 'bf16y' launches read them (A/B switch)
 FUSE = set(filter(None, os.environ.get('MCG_FUSE', 'stats,dc1').split(',')))
+DC1_SPLIT_OUT = os.environ.get('MCG_DC1_SPLIT_OUT', '1') == '1'   # 'f32x3': D's first-layer epilogue writes the split form layer 2 reads (A/B switch)
 WGRAD_AFTER = os.environ.get('MCG_WGRAD_AFTER', '0') == '1'    # side-stream weight gradients start AFTER the layer's input-gradient GEMM (A/B switch, off: see _Net._hold_wgrads)
 
 
@@ -141,6 +142,7 @@ class _Net:
             run = 16 if form == 'f' else 16 * (w.numel() // w.shape[0])
             out = hl.split_planes(w, run=run, out=ent[1] if ent else None)
             cache[(name, form)] = ent = (self.fp.version, out)
+        self.__dict__.setdefault('_wsplit_used', set()).add((name, form))     # read since the last refresh: worth refreshing again
         return ent[1]
 
     def refresh_wsplits(self):
@@ -150,17 +152,26 @@ class _Net:
         cache = self.__dict__.get('_wsplits')
         if not cache or self.precision != 'f32x3' or os.environ.get('MCG_WSPLIT_MULTI', '1') != '1':
             return
-        items = []
+        # only the pairs a launch has READ since the last refresh: hl.split_pays' timed trial of a geometry where the split form
+        # then lost also fills the cache, and such a filter would be re-split every iteration and never read (round 5's advice);
+        # a pair that was not refreshed keeps its old version and is rebuilt by _wsplit if a launch ever asks for it again
+        used, self._wsplit_used = self.__dict__.get('_wsplit_used', set()), set()
+        items, keys = [], []
         for (name, form), (ver, out) in cache.items():
-            if ver != self.fp.version:
+            if ver != self.fp.version and (name, form) in used:
                 w = self.fp.param(name)
                 items.append((w, 16 if form == 'f' else 16 * (w.numel() // w.shape[0]), out))
+                keys.append((name, form))
         if not items:
             return
+        saved_tag = hl.get_tag()                                   # (called from inside adam_update: the caller's timing tag stays)
         hl.set_tag(getattr(self, 'tag', 'G'))
-        for i in range(0, len(items), 32):
-            hl.split_planes_multi(items[i:i + 32])
-        for key in cache:
+        try:
+            for i in range(0, len(items), 32):
+                hl.split_planes_multi(items[i:i + 32])
+        finally:
+            hl.set_tag(saved_tag)
+        for key in keys:
             cache[key] = (self.fp.version, cache[key][1])
 
     def _cfprop(self, g, x, wname, w, b, y, ep=None, must_fuse=False, xs=None, force=False):
@@ -590,6 +601,14 @@ class DisNet(_Net):
                 # backward needs of the pre-activation -- its sign -- is kept as one bit per element
                 a = torch.empty((N, g.To, g.Ho, g.Wo, co), device=dev, dtype=adt)
                 mask = torch.empty((G * m, (co + 31) // 32), dtype=torch.int32, device=dev)
+                # 'f32x3' (round 6): when both GEMMs of layer 2 that read this tensor take the split form, the epilogue writes the
+                # three bf16 terms directly (MCG_IO_OUT_SPLIT) -- the fp32 tensor is never written, and the pass that read it back
+                # and split it (0.65 GB of traffic at 64 clips, the largest operand split of the iteration) is gone
+                a_split = None
+                g2 = self._geom(2, N)
+                if DC1_SPLIT_OUT and self._split_only(('fprop', g2), ('wgrad', g2)) and co % 16 == 0:
+                    a_split = saved['split'][2] = torch.empty(a.shape[:-1] + (4 * co,), device=dev, dtype=torch.bfloat16)
+                    saved['only'].add(2)                         # saved['a'][2] stays unwritten
                 na = [noise_args(grp, 2) for grp in groups]
                 kw = {}
                 if na[0]:
@@ -599,8 +618,9 @@ class DisNet(_Net):
                     else:
                         assert all(x['seed'] == na[0]['seed'] for x in na)
                         kw = dict(sigma=na[0]['sigma'], seed=na[0]['seed'], stream_id=[x['stream_id'] for x in na])
-                hl.conv_fprop(g, saved['a'][1], w, b, a, must_fuse=True,
-                              ep=hl.epilogue(act=hl.ACT_LRELU, groups=G, mask_out=mask, out_bf16=adt == torch.bfloat16, **kw))
+                hl.conv_fprop(g, saved['a'][1], w, b, a_split if a_split is not None else a, must_fuse=True,
+                              ep=hl.epilogue(act=hl.ACT_LRELU, groups=G, mask_out=mask, out_bf16=adt == torch.bfloat16,
+                                             out_split=a_split is not None, **kw))
                 saved['y'][1], saved['mask1'], saved['a'][2] = None, mask, a
                 continue
             # bf16 networks: the pre-BatchNorm values are bf16 too (the element-wise passes that read them are HBM-bound)

@@ -190,7 +190,9 @@ class TrainStep:
 
     # ---- one iteration -------------------------------------------------------------------------
     def run(self, x_real, t_real=None, inject=None, input_event=None):
-        """x_real: device tensor in the reference layout (N,C,T,H,W) (model/updater.py:89-90).
+        """x_real: device tensor in the reference layout (N,C,T,H,W) float32 (model/updater.py:89-90) -- or the loader's own
+        form, uint8 (N,T,H,W,C) as datasets.py decodes it: the first kernel of each discriminator then normalises (v - 128) / 128
+        while it writes the device layout (mcg_pack_clip_u8), and no float copy of the batch is ever made.
         t_real: int32 device tensor (N,) or None.
         input_event: an event recorded (on whatever stream produced x_real -- a loader's copy stream) when x_real was complete; the
         caller's current stream must be ordered behind it as well.  With it the two-chain schedule starts the VideoDiscriminator's
@@ -200,7 +202,13 @@ class TrainStep:
         device layout, pre-scaled) and 'gen' (latent draw dict); None = perf mode (Philox in-kernel,
         frame index from a seeded host generator shared by all ranks, quirk Q7)."""
         gen, di, dv = self.gen, self.dis_i, self.dis_v
-        n, c_img, T, H, W = x_real.shape
+        u8 = x_real.dtype == torch.uint8
+        if u8:
+            n, T, H, W, c_img = x_real.shape
+            if not x_real.is_contiguous():
+                raise hl.McgError("uint8 clips must be dense (N,T,H,W,C)")
+        else:
+            n, c_img, T, H, W = x_real.shape
         hw = H * W
         it = self.iteration
         base = self.stream_base(it, self.rank)
@@ -221,7 +229,7 @@ class TrainStep:
         if cgan:
             # label planes are part of D's input: build the device-layout clip once, then add noise
             tmp = torch.empty((n, T, H, W, lay.pad4(c_img)), device=self.device)
-            hl.pack_clip(n, c_img, lay.pad4(c_img), T, hw, x_real, tmp)
+            (hl.pack_clip_u8 if u8 else hl.pack_clip)(n, c_img, lay.pad4(c_img), T, hw, x_real, tmp)
             xr = self._concat_label_clip(tmp, t_real)
             c_valid = c_img + gen.dim_zl
 
@@ -233,10 +241,13 @@ class TrainStep:
                               item_stride=T * hw * cp, **na)
         else:
             def first_real_v(out, na):
-                hl.pack_clip(n, c_img, cp, T, hw, x_real, out, **na)
+                (hl.pack_clip_u8 if u8 else hl.pack_clip)(n, c_img, cp, T, hw, x_real, out, **na)
 
             def first_real_i(out, na):
-                hl.pack_clip(n, c_img, cp, 1, hw, x_real[:, :, t], out, stride_n=c_img * T * hw, stride_c=T * hw, **na)
+                if u8:                                               # frame t of every clip: the clip's item stride, one frame
+                    hl.pack_clip_u8(n, c_img, cp, 1, hw, x_real[:, t], out, stride_n=T * hw * c_img, **na)
+                else:
+                    hl.pack_clip(n, c_img, cp, 1, hw, x_real[:, :, t], out, stride_n=c_img * T * hw, stride_c=T * hw, **na)
 
         # ------------------------------------------------ forward: D_V on the real clips, as a chain of its own beside G's forward
         ex = self.exchange

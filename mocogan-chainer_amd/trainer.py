@@ -102,17 +102,32 @@ class SerialIterator:
         return self
 
 
+def _pid_namespace():
+    """an id of this process's PID namespace (the inode of /proc/self/ns/pid): pids are only meaningful inside one namespace, and
+    containers that share /dev/shm (`--ipc=host`) usually do not share it"""
+    try:
+        return '%x' % os.stat('/proc/self/ns/pid').st_ino
+    except OSError:
+        return '0'
+
+
+def _slot_name(owner_id, k):
+    return 'mcg_%s_%d_%x_%d' % (_pid_namespace(), os.getpid(), owner_id & 0xffffff, k)
+
+
 def _remove_stale_slots(root='/dev/shm'):
-    """batch slots ('mcg_<pid>_...') of training processes that no longer exist -- a run that was killed could not unlink its own, and
-    /dev/shm is memory"""
+    """batch slots ('mcg_<pid namespace>_<pid>_...') of training processes OF THIS PID NAMESPACE that no longer exist -- a run that was
+    killed could not unlink its own, and /dev/shm is memory.  Segments of another namespace are never touched: their pid says nothing
+    here (round 5's advice: two containers sharing /dev/shm would unlink each other's live slots)."""
     try:
         names = os.listdir(root)
     except OSError:
         return
+    ns = _pid_namespace()
     for name in names:
         parts = name.split('_')
-        if len(parts) == 4 and parts[0] == 'mcg' and parts[1].isdigit():
-            pid = int(parts[1])
+        if len(parts) == 5 and parts[0] == 'mcg' and parts[1] == ns and ns != '0' and parts[2].isdigit():
+            pid = int(parts[2])
             try:
                 os.kill(pid, 0)                                       # (signal 0: existence check only)
             except ProcessLookupError:
@@ -161,9 +176,23 @@ class PrefetchIterator(SerialIterator):
             self._clip_shape = tuple(np.asarray(dataset.get_example_raw(0)[0]).shape)
             np.random.set_state(st)
             nbytes = batch_size * int(np.prod(self._clip_shape))
-            for k in range(prefetch + 2):
-                shm = shared_memory.SharedMemory(create=True, size=nbytes, name='mcg_%d_%x_%d' % (os.getpid(), id(self) & 0xffffff, k))
-                self._slots.append((shm, np.ndarray((batch_size,) + self._clip_shape, dtype=np.uint8, buffer=shm.buf)))
+            try:
+                for k in range(prefetch + 2):
+                    shm = shared_memory.SharedMemory(create=True, size=nbytes, name=_slot_name(id(self), k))
+                    self._slots.append((shm, np.ndarray((batch_size,) + self._clip_shape, dtype=np.uint8, buffer=shm.buf)))
+                    # create=True only ftruncates: tmpfs pages are not reserved, and a worker's first write into a slot that
+                    # /dev/shm cannot back dies with SIGBUS (the 64 MB Docker default against ~300 MB at 256 clips).  Reserve now.
+                    os.posix_fallocate(shm._fd, 0, nbytes)
+            except OSError as exc:                                    # ENOSPC, or a name left behind by an un-closed iterator (EEXIST)
+                sys.stderr.write('PrefetchIterator: no shared-memory batch slots (%r): the workers return the frames through the '
+                                 'result pipes (MCG_LOADER_SHM=0 does the same without trying)\n' % (exc,))
+                while self._slots:
+                    shm = self._slots.pop()[0]
+                    for fn in (shm.unlink, shm.close):
+                        try:
+                            fn()
+                        except Exception:
+                            pass
             self._free_slots = list(range(len(self._slots)))
         super().__init__(dataset, batch_size, repeat, shuffle)
 
@@ -249,6 +278,9 @@ class PrefetchIterator(SerialIterator):
             if self._slots and len(idx) <= self.batch_size:
                 if not self._free_slots:
                     self._reclaim(block=True)
+                if not self._free_slots:
+                    raise RuntimeError('PrefetchIterator: every batch slot is in use and none is waiting for a device copy '
+                                       '(a slot was lost: %d slots, look-ahead %d)' % (len(self._slots), len(self._queue)))
                 slot = self._free_slots.pop()
                 futs = [self._pool.submit(_ds.worker_load_shm, idx[c:c + self._chunk], self._batch_no, c, self._slots[slot][0].name, c,
                                           self._clip_shape) for c in range(0, len(idx), self._chunk)]
@@ -268,7 +300,18 @@ class PrefetchIterator(SerialIterator):
         if not self._queue:
             raise StopIteration
         st, futs, slot = self._queue.pop(0)
-        parts = [f.result() for f in futs]
+        try:
+            parts = [f.result() for f in futs]
+        except BaseException:
+            for f in futs:                                            # (the others may still be writing into the slot)
+                if not f.cancel():
+                    try:
+                        f.result()
+                    except BaseException:
+                        pass
+            if slot is not None:
+                self._free_slots.append(slot)
+            raise
         self._set_state(st)                                           # what SerialIterator shows after this batch
         if slot is not None:                                          # the frames are in the batch slot; the workers returned the labels
             labels = [l for p in parts for l in p]
@@ -301,9 +344,11 @@ class PrefetchIterator(SerialIterator):
 
     __next__ = next
 
-    def next_device_batch(self, device, with_event=False):
+    def next_device_batch(self, device, with_event=False, as_uint8=False):
         """-> (x_real float32 (N,C,T,H,W) on `device`, labels list).  The H2D copy runs from pinned memory on a
-        side stream; the caller's stream waits for it.  with_event: -> (x_real, labels, event, labels_dev) -- the event recorded on
+        side stream; the caller's stream waits for it.  as_uint8 (raw datasets only; otherwise ignored): x_real is the copied
+        uint8 batch (N,T,H,W,C) itself -- step.TrainStep.run normalises it in its first kernels (mcg_pack_clip_u8), which saves the
+        five torch passes below (1.4 GB of traffic per 256-clip batch beside the GEMMs).  with_event: -> (x_real, labels, event, labels_dev) -- the event recorded on
         the copy stream when the batch was complete (`TrainStep.run(input_event=...)` lets a stream that needs nothing but the batch,
         the VideoDiscriminator's real chain, wait for exactly that instead of for everything queued on the caller's stream) and the
         labels as an int32 device tensor copied on that stream too (None for an unlabelled dataset)."""
@@ -331,7 +376,7 @@ class PrefetchIterator(SerialIterator):
             cur = torch.cuda.current_stream()
             with torch.cuda.stream(self._copy_stream):
                 dev = host.to(device, non_blocking=True)
-                if self._raw:
+                if self._raw and not as_uint8:
                     dev = ((dev.float() - 128.) / 128.).permute(0, 4, 1, 2, 3).contiguous()
                 lab_dev = None
                 if with_event and labels and labels[0] is not None:
@@ -369,7 +414,7 @@ class PrefetchIterator(SerialIterator):
         cur = torch.cuda.current_stream()
         with torch.cuda.stream(self._copy_stream):
             dev = host.to(device, non_blocking=True)
-            if self._raw:
+            if self._raw and not as_uint8:
                 dev = ((dev.float() - 128.) / 128.).permute(0, 4, 1, 2, 3).contiguous()     # (N,T,H,W,C) u8 -> (N,C,T,H,W)
             lab_dev = None
             if with_event and labels and labels[0] is not None:
@@ -405,11 +450,11 @@ class PrefetchIterator(SerialIterator):
             self._slots_pinned = False
         while slots:
             shm = slots.pop()[0]                                      # (the NumPy view of the slot goes first: a mapped buffer cannot be closed)
-            try:
-                shm.close()
-                shm.unlink()
-            except Exception:
-                pass
+            for fn in (shm.unlink, shm.close):                        # unlink FIRST and on its own: close() raises BufferError while any
+                try:                                                  # view of the slot is alive, and the name must leave /dev/shm anyway
+                    fn()
+                except Exception:
+                    pass
 
     def __del__(self):
         try:

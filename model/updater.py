@@ -2,6 +2,8 @@
 ``model/updater.py`` (Updater :9-19, loss_dis :21-44, loss_gen :46-63, concat_label_video :65-76,
 update_core :78-113).  ``update_core`` hands the batch to the device step (mocogan-chainer_amd/step.py),
 which reproduces the reference's kernel-visible ordering without an autograd graph."""
+import os
+
 import numpy as np
 import torch
 
@@ -124,7 +126,10 @@ class Updater:
         it = self.get_iterator('main')
         ready = t_real = None
         if hasattr(it, 'next_device_batch'):                                         # prefetching loader: uint8 from pinned memory on
-            x_real, labels, ready, t_real = it.next_device_batch(self._step.device, with_event=True)   # a copy stream, normalised on the GPU
+            # a copy stream; raw (uint8) datasets stay uint8 (N,T,H,W,C): TrainStep.run normalises in its first kernels (MCG_LOADER_U8=0:
+            # the float (N,C,T,H,W) batch of rounds 1-5, five torch passes on the copy stream)
+            x_real, labels, ready, t_real = it.next_device_batch(self._step.device, with_event=True,
+                                                                 as_uint8=os.environ.get('MCG_LOADER_U8', '1') == '1')
         else:
             batch = it.next()
             labels = [b[1] for b in batch]

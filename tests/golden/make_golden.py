@@ -20,7 +20,17 @@ from oracle import updater as oupd         # noqa: E402
 from oracle import philox                  # noqa: E402
 
 F64 = np.float64
-STEP_CASES = [("normal", 0, 303), ("normal", 6, 311), ("infogan", 6, 313), ("cgan", 6, 320)]
+# Seeds chosen by `python tests/golden/make_golden.py --search [model:dim_zl]` (round 6): per variant the first seed >= the round-1 seed
+# whose THREE iterations all keep every pre-activation at least MARGIN away from its kink (leaky_relu / relu at 0) -- the gradient
+# is discontinuous there, and an fp32 device result on the other side of a kink differs from the float64 oracle by a whole
+# activation slope, not by rounding.  With such seeds the GPU test holds every iteration to the tight gradient tolerances
+# (tests/test_gpu_golden.py); rounds 1-5 had a 0.15 fallback for the four iterations whose margin was below 2e-6.
+# Searched: normal/0 303..1267, normal/6 311..3342, cgan/6 320 (the round-1 seed qualifies); infogan/6 (seven logits, more
+# activations: one iteration in ten clears 3e-6) has no seed below 4313 at 3e-6 -- 481 is its first at 2.3e-6 (margins 4.6e-6,
+# 2.4e-6, 3.6e-6), still above the 2e-6 the device's rounding needs.
+MARGIN = {"normal": 3e-6, "cgan": 3e-6, "infogan": 2.3e-6}
+STEP_CASES = [("normal", 0, 1267), ("normal", 6, 3342), ("infogan", 6, 481), ("cgan", 6, 320)]
+SEARCH_FROM = {("normal", 0): 303, ("normal", 6): 311, ("infogan", 6): 313, ("cgan", 6): 320}
 
 
 def f64(p):
@@ -38,7 +48,8 @@ def step_inputs(model, dim_zl, seed, nf=4, n=2):
     return rng, gen, di, dv
 
 
-def step_case(model, dim_zl, seed, steps=3, nf=4, n=2):
+def step_case(model, dim_zl, seed, steps=3, nf=4, n=2, stop_below=None):
+    """stop_below (the seed search): give up -- return None -- at the first iteration whose margin is below it"""
     rng, gen, di, dv = step_inputs(model, dim_zl, seed, nf, n)
     og, oi, ov = (oupd.new_adam_state(q) for q in (gen, di, dv))
     rec = {}
@@ -49,6 +60,8 @@ def step_case(model, dim_zl, seed, steps=3, nf=4, n=2):
         ref = oupd.update_core(model, gen, di, dv, og, oi, ov, x_real, t_real, rnd, dim_zl=dim_zl, keep=True)
         rec['s%d/losses' % s] = np.array([ref['loss_dis_i'], ref['loss_dis_v'], ref['loss_gen']])
         rec['s%d/min_margin' % s] = np.array(ref['min_margin'])
+        if stop_below is not None and float(ref['min_margin']) < stop_below:
+            return None
         rec['s%d/t' % s] = np.array(rnd['t'])
         rec['s%d/x_fake_slice' % s] = ref['x_fake'][:, :3, ::5, ::16, ::16].copy()
         rec['s%d/gx_fake_slice' % s] = ref['gx_fake'][:, :, ::5, ::16, ::16].copy()
@@ -97,7 +110,30 @@ def op_cases():
     return rec
 
 
+def search(only=None, limit=4000):
+    """prints, per variant (or for the one named `model:dim_zl`), the first seed >= SEARCH_FROM whose three iterations all clear MARGIN[model]"""
+    found = []
+    for (model, dim_zl), first in sorted(SEARCH_FROM.items()):
+        if only and only != '%s:%d' % (model, dim_zl):
+            continue
+        for seed in range(first, first + limit):
+            rec = step_case(model, dim_zl, seed, stop_below=MARGIN[model])
+            if rec is not None:
+                print(model, dim_zl, seed, ['%.2e' % float(rec['s%d/min_margin' % s]) for s in range(3)], flush=True)
+                found.append((model, dim_zl, seed))
+                break
+        else:
+            print(model, dim_zl, 'no seed below', first + limit, flush=True)
+    print('STEP_CASES +=', found, flush=True)
+
+
 def main():
+    if '--search' in sys.argv:                                       # [--search model:dim_zl] one variant (run the four side by side)
+        i = sys.argv.index('--search')
+        return search(sys.argv[i + 1] if len(sys.argv) > i + 1 else None)
+    for f in os.listdir(HERE):                                       # (fixtures of seeds that are no longer in STEP_CASES)
+        if f.startswith('step_') and f.endswith('.npz'):
+            os.remove(os.path.join(HERE, f))
     np.savez_compressed(os.path.join(HERE, 'ops.npz'), **{k.replace('/', '.'): v for k, v in op_cases().items()})
     for model, dim_zl, seed in STEP_CASES:
         rec = step_case(model, dim_zl, seed)

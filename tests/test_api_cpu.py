@@ -156,9 +156,53 @@ def test_prefetch_iterator_shared_memory_slots_equal_the_result_pipes(tmp_path, 
     for got in (shm, staged, pipes):
         for a, b in zip(ref, got):
             assert a[0] == b[0] and a[2:] == b[2:]                  # labels, epoch bookkeeping: SerialIterator's
-        for a, b in zip(shm, got):                                  # frames: the workers' sub-sequence offsets are seeded per (seed, batch, chunk)
+        for a, b in zip(shm, got):                                  # frames: the workers' sub-sequence offsets are seeded per (seed, batch, position)
             assert all(np.array_equal(x, y) for x, y in zip(a[1], b[1]))
-    assert not [f for f in os.listdir('/dev/shm') if f.startswith('mcg_%d_' % os.getpid())]
+    # ... and so do not depend on how a batch is cut into worker tasks (round 5's advice: a resumed run with another worker count)
+    other = run(lambda: PrefetchIterator(mug, 3, n_workers=3, prefetch=2, chunk=1, shuffle=False))
+    for a, b in zip(shm, other):
+        assert a[0] == b[0] and all(np.array_equal(x, y) for x, y in zip(a[1], b[1]))
+    assert not [f for f in os.listdir('/dev/shm') if f.startswith('mcg_') and ('_%d_' % os.getpid()) in f]
+
+
+def test_stale_slot_reaping_stays_inside_this_pid_namespace(tmp_path, monkeypatch):
+    """Round 5's advice: batch slots are named after (PID namespace, pid); only segments of THIS namespace whose pid is gone are
+    reaped -- a foreign namespace's pid means nothing here (two containers sharing /dev/shm), and a slot that cannot be backed by
+    /dev/shm makes the iterator fall back to the result pipes instead of dying with SIGBUS in a worker."""
+    import os
+    import subprocess
+    import sys
+    from mocogan_chainer_amd import trainer as T
+    ns = T._pid_namespace()
+    dead = subprocess.Popen([sys.executable, '-c', 'pass'])
+    dead.wait()
+    mine_dead = tmp_path / ('mcg_%s_%d_abc_0' % (ns, dead.pid))
+    mine_live = tmp_path / ('mcg_%s_%d_abc_0' % (ns, os.getpid()))
+    foreign = tmp_path / ('mcg_%s_%d_abc_0' % ('deadbeef' if ns != 'deadbeef' else 'feedface', dead.pid))
+    old_style = tmp_path / ('mcg_%d_abc_0' % dead.pid)              # (round 5's names: no namespace in them -- left alone)
+    for f in (mine_dead, mine_live, foreign, old_style):
+        f.write_bytes(b'x')
+    T._remove_stale_slots(str(tmp_path))
+    assert not mine_dead.exists() and mine_live.exists() and foreign.exists() and old_style.exists()
+    assert T._slot_name(0x1234567, 3) == 'mcg_%s_%d_%x_3' % (ns, os.getpid(), 0x234567)
+
+    # no room in /dev/shm: the slots are given up in __init__, nothing is left behind, the batches still arrive
+    from datasets import MugDataset
+
+    def no_space(fd, off, n):
+        raise OSError(28, 'No space left on device')
+    monkeypatch.setattr(os, 'posix_fallocate', no_space)
+    _fake_frame_tree(tmp_path / "mug")
+    ds = MugDataset(tmp_path / "mug")
+    assert hasattr(ds, 'get_example_raw')
+    it = T.PrefetchIterator(ds, 2, n_workers=1, prefetch=1, shuffle=False)
+    try:
+        assert it._slots == [] and it._free_slots == []
+        b = it.next()
+        assert len(b) == 2 and b[0][0].shape == (3, 16, 64, 64)
+    finally:
+        it.close()
+    assert not [f for f in os.listdir('/dev/shm') if f.startswith('mcg_') and ('_%d_' % os.getpid()) in f]
 
 
 def test_grid_and_sequence_helpers():

@@ -40,6 +40,20 @@ def test_library_exports_every_declared_symbol(hl):
     assert 'define MCG_ABI_VERSION %d' % hl.ABI_VERSION in open(os.path.join(ROOT, 'include', 'mocogan_hip.h')).read()
 
 
+def test_library_exports_nothing_the_header_does_not_declare(hl):
+    """the dynamic symbol table holds exactly the declared mcg_* entry points (+ the diagnostic builds' mcg_debug_stamps, absent from
+    the shipped build): helpers shared between the library's translation units have hidden visibility (round 5's review)."""
+    import subprocess
+    import mocogan_chainer_amd as build
+    tool = '/opt/rocm/lib/llvm/bin/llvm-readelf'
+    if not os.path.exists(tool):
+        pytest.skip('llvm-readelf not found')
+    out = subprocess.run([tool, '--dyn-syms', '-W', build.lib_path()], capture_output=True, text=True, check=True).stdout
+    out = '\n'.join(l for l in out.splitlines() if ' UND ' not in l)                 # defined symbols only
+    exported = sorted(set(re.findall(r'\b(mcg_[A-Za-z0-9_]+)\b', out)))
+    assert exported == declared_symbols(), sorted(set(exported) ^ set(declared_symbols()))
+
+
 def test_header_cites_reference_call_sites():
     src = open(os.path.join(ROOT, 'include', 'mocogan_hip.h')).read()
     for cite in ('model/net.py', 'model/updater.py', 'train.py:93-101'):

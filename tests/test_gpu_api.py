@@ -183,6 +183,11 @@ def test_prefetching_loader_feeds_the_updater(tmp_path, monkeypatch):
                 x_dev, labels, ready, lab_dev = pre.next_device_batch(torch.device('cuda'), with_event=True)
                 ready.synchronize()
                 assert lab_dev.dtype == torch.int32 and lab_dev.cpu().tolist() == labels
+            elif _ == 2:                                             # round 6: the uint8 batch itself (TrainStep.run normalises it)
+                x_u8, labels = pre.next_device_batch(torch.device('cuda'), as_uint8=True)
+                torch.cuda.synchronize()
+                assert x_u8.shape == (4, 16, 64, 64, 3) and x_u8.dtype == torch.uint8 and x_u8.is_contiguous()
+                x_dev = ((x_u8.float() - 128.) / 128.).permute(0, 4, 1, 2, 3).contiguous()
             else:
                 x_dev, labels = pre.next_device_batch(torch.device('cuda'))
             torch.cuda.synchronize()
@@ -196,6 +201,36 @@ def test_prefetching_loader_feeds_the_updater(tmp_path, monkeypatch):
                      '--n_filters_gen', '8', '--save_name', 'pf', '--loader_workers', '2', '--snapshot_interval', '5'])
     assert tr.updater.iteration == 4 and tr.updater.epoch == 2
     tr.updater.get_iterator('main').close()
+
+
+@pytest.mark.parametrize("model", ['normal', 'cgan'])
+def test_train_step_takes_the_loaders_uint8_clips(model):
+    """TrainStep.run on the loader's uint8 (N,T,H,W,C) batch (mcg_pack_clip_u8 in front of both discriminators) against the same
+    iteration on the reference's float (N,C,T,H,W) batch (model/updater.py:87-92): same Philox streams, same frame index -- losses
+    and updated parameters agree to fp32 summation order (the weight gradients' float atomics)."""
+    import mocogan_chainer_amd.nets as nets
+    import mocogan_chainer_amd.step as step
+    rng = np.random.RandomState(5)
+    n, nf, dim_zl = 3, 4, 6
+    u8 = rng.randint(0, 256, (n, 16, 64, 64, 3)).astype(np.uint8)
+    t_real = torch.tensor(rng.randint(0, 6, n), dtype=torch.int32, device='cuda')
+    xs = {'u8': torch.tensor(u8, device='cuda'),
+          'f32': torch.tensor(((u8.astype(np.float32) - 128.) / 128.).transpose(0, 4, 1, 2, 3).copy(), device='cuda')}
+    res = {}
+    for form, x in xs.items():
+        gen, di, dv = step.make_models(model, num_labels=dim_zl, seed=3, n_filters=nf)
+        ts = step.TrainStep(model, gen, di, dv, seed=21, rank=0)
+        ts.run(x, t_real)
+        ts.run(x, t_real)
+        torch.cuda.synchronize()
+        res[form] = (ts.losses(), {'%s/%s' % (name, kk): np.asarray(vv.cpu() if torch.is_tensor(vv) else vv)
+                                   for name, net in (('gen', gen), ('di', di), ('dv', dv)) for kk, vv in net.export_reference_params().items()})
+    la, lb = res['u8'][0], res['f32'][0]
+    assert all(abs(la[k] - lb[k]) < 1e-5 for k in la), (la, lb)
+    for k, a in res['u8'][1].items():
+        b = res['f32'][1][k]
+        if a.dtype.kind == 'f' and a.size:
+            assert np.linalg.norm(a - b) <= 2e-4 * (np.linalg.norm(b) + 1e-12), k
 
 
 def test_train_on_a_moving_mnist_file(tmp_path, monkeypatch):

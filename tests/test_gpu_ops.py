@@ -342,6 +342,42 @@ def test_pack_unpack_and_tanh_bwd_to_frames(hl):
     assert rel_l2(gf, ref) < 1e-6
 
 
+@pytest.mark.parametrize("C,Cp", [(3, 4), (1, 4), (4, 4), (6, 8)])
+def test_pack_clip_u8_equals_the_reference_normalisation(hl, C, Cp):
+    """mcg_pack_clip_u8 on the loader's uint8 (N,T,H,W,C) clips against the reference's host arithmetic (datasets.py:95:
+    (x - 128) / 128, then the (C,T,H,W) transpose of updater.py:87-92) -- exact: both are exact in fp32 -- and, bit for bit, against
+    mcg_pack_clip on the float batch, with injected and with in-kernel Philox noise, for the clip and for one frame of every clip."""
+    rng = np.random.RandomState(17)
+    N, T, H = 3, 5, 8
+    u8 = rng.randint(0, 256, (N, T, H, H, C)).astype(np.uint8)
+    u8[0, 0, 0, 0, :] = 0
+    u8[0, 0, 0, 1, :] = 255
+    ref = ((u8.astype(np.float32) - 128.) / 128.).transpose(0, 4, 1, 2, 3)               # (N,C,T,H,W), what the reference feeds D
+    xu, xf = torch.tensor(u8, device="cuda"), dev(ref).contiguous()       # (torch.tensor keeps a transposed NumPy view's strides)
+    out = torch.full((N, T, H, H, Cp), 9.0, device="cuda")
+    hl.pack_clip_u8(N, C, Cp, T, H * H, xu, out)
+    got = out.cpu().numpy()
+    assert np.array_equal(got[..., :C].transpose(0, 4, 1, 2, 3), ref) and float(out[..., C:].abs().sum()) == 0.0
+    noise = torch.randn((N, T, H, H, Cp), device="cuda")
+    for kw in (dict(addend=noise), dict(sigma=0.2, seed=11, stream_id=5)):
+        a, b = torch.empty_like(out), torch.empty_like(out)
+        hl.pack_clip_u8(N, C, Cp, T, H * H, xu, a, **kw)
+        hl.pack_clip(N, C, Cp, T, H * H, xf, b, **kw)
+        assert torch.equal(a, b), kw.keys()
+        if 'sigma' in kw:
+            assert float(a[..., C:].abs().sum()) == 0.0 and float((a - out).abs().max()) > 0.1
+        t = 3                                                     # frame t of every clip (the ImageDiscriminator's input, updater.py:96-97)
+        a1, b1 = torch.empty((N, 1, H, H, Cp), device="cuda"), torch.empty((N, 1, H, H, Cp), device="cuda")
+        kw1 = dict(kw, addend=kw['addend'][:, :1].contiguous()) if 'addend' in kw else kw
+        hl.pack_clip_u8(N, C, Cp, 1, H * H, xu[:, t], a1, stride_n=T * H * H * C, **kw1)
+        hl.pack_clip(N, C, Cp, 1, H * H, xf[:, :, t], b1, stride_n=C * T * H * H, stride_c=T * H * H, **kw1)
+        assert torch.equal(a1, b1)
+        if 'addend' in kw:
+            assert float((a1[:, 0] - kw1['addend'][:, 0] - out[:, t]).abs().max()) < 1e-6      # (frame t of the clip, up to the rounding of + / - noise)
+    with pytest.raises(hl.McgError):
+        hl.pack_clip_u8(N, C, Cp, T, H * H, xf, out)                # a float tensor is not the loader's form
+
+
 @pytest.mark.parametrize("N,dim_zl,dz", [(5, 0, 10), (37, 6, 10), (7, 0, 24), (9, 6, 40), (3, 64, 64)])
 def test_gru_sequence(hl, N, dim_zl, dz):
     """mcg_gru_seq_fwd / _bwd against the oracle's StatelessGRU steps: the register-resident kernels (dim_zm <= 16, the reference's
@@ -492,6 +528,88 @@ def test_fprop_epilogue_statistics_and_first_layer(hl, case, tile):
             zd = torch.empty((mg, Co), device="cuda")
             hl.randn_rowquad(zd, Co, 0.2, 77, [5, 9][gi])
             assert np.abs(zd.cpu().double().numpy() - z).max() < 4e-6
+
+
+@pytest.mark.parametrize("case", [(2, 6, 64, 4), (4, 5, 32, 4), (2, 4, 64, 4), (3, 9, 32, 4)])        # N, Ti, H, kt: Wo = 32 / 16; To = 3, 2, 1, 6
+def test_overlapped_first_layer_forward_equals_the_weight_stationary_kernel(hl, case):
+    """Round 6: fprop_c4_ab_kernel (tile code 0 on the 3-D first layer in a -DMCG_C4_AB=1 build: two wave groups half a frame step
+    apart, filters in registers, a ring of kt + 1 slabs -- measured slower and switched off, see the kernel's comment) against
+    fprop_c4_kernel (tile code 6) -- the same additions in the same order: BIT-identical; in the shipped build both codes run
+    fprop_c4_kernel and the test pins that kernel -- and against the float64 oracle, for the plain store, the first layer's leaky_relu + injected-noise + sign-bit epilogue and
+    its in-kernel Philox form (model/net.py:148-149,189-190), one and two noise groups."""
+    N, Ti, H, kt = case
+    Ci, Co = 3, 64
+    rng = np.random.RandomState(900 + Ti * H)
+    x = rng.uniform(-1, 1, (N, Ci, Ti, H, H))
+    W = rng.randn(Co, Ci, kt, 4, 4) * 0.1
+    b = rng.randn(Co) * 0.3
+    y_ref = F.conv3d_fwd(x, W, b, (1, 2, 2), (0, 1, 1))
+    lay = L()
+    xd, wd, bd = lay.act_to_dev(dev(x)), lay.conv_w_to_dev(dev(W)), dev(b)
+    out = {}
+    for tile in (0, 6):
+        g = hl.make_geom(N, Ti, H, H, 4, Co, kt, ci_valid=3)
+        g.tile = tile
+        M = N * g.To * g.Ho * g.Wo
+        yd = torch.full((N, g.To, g.Ho, g.Wo, Co), 5.0, device="cuda")
+        hl.conv_fprop(g, xd, wd, bd, yd)
+        res = [yd]
+        for groups in ((1, 2) if N % 2 == 0 else (1,)):
+            ng = N // groups
+            noise = lay.act_to_dev(dev(0.2 * np.random.RandomState(5).randn(*y_ref.shape)))
+            for kw in (dict(addend=[noise[i * ng:(i + 1) * ng] for i in range(groups)]), dict(sigma=0.2, seed=31, stream_id=[4, 8][:groups])):
+                mask = torch.zeros((M, 2), dtype=torch.int32, device="cuda")
+                ad = torch.full_like(yd, 7.0)
+                assert hl.conv_fprop(g, xd, wd, bd, ad, ep=hl.epilogue(act=hl.ACT_LRELU, groups=groups, mask_out=mask, **kw), must_fuse=True)
+                res += [ad, mask]
+        out[tile] = res
+    assert rel_l2(lay.act_from_dev(out[0][0], Co), y_ref) < FWD_TOL
+    noise_np = lay.act_from_dev(noise, Co).cpu().double().numpy()
+    assert rel_l2(lay.act_from_dev(out[0][1], Co), F.leaky_relu_fwd(y_ref) + noise_np) < FWD_TOL
+    bits = _mask_bits(out[0][2], Co)
+    pre = lay.act_to_dev(dev(y_ref)).reshape(-1, Co).cpu().numpy()
+    sure = np.abs(pre) > 1e-5
+    assert np.array_equal(bits[sure], (pre >= 0)[sure])
+    for i, (a, c) in enumerate(zip(out[0], out[6])):
+        assert torch.equal(a, c), "launch %d differs from fprop_c4_kernel" % i
+
+
+@pytest.mark.parametrize("case", [(2, 5, 32, 3, 64, 4, 0), (2, 6, 64, 3, 64, 4, 6), (4, 1, 32, 3, 64, 1, 0), (2, 5, 16, 8, 32, 4, 0), (2, 5, 16, 8, 32, 4, 2)])
+def test_first_layer_epilogue_writes_the_split_form(hl, case):
+    """Round 6 (MCG_IO_OUT_SPLIT): the first layer's leaky_relu + noise epilogue of an 'f32x3' network writes the three bf16 terms
+    layer 2's split GEMMs read (model/net.py:148-149,189-190 feeding :150,191) -- bit for bit mcg_split_planes of the fp32 tensor
+    the same launch writes otherwise, sign bits unchanged, for the weight-stationary first-layer kernels and the generic tiles,
+    injected and in-kernel noise, one and two groups; the fp32 terms add up to the oracle's activation."""
+    N, Ti, H, Ci, Co, kt, tile = case
+    rng = np.random.RandomState(40 + H + Co)
+    x = rng.uniform(-1, 1, (N, Ci, Ti, H, H))
+    W = rng.randn(Co, Ci, kt, 4, 4) * 0.1
+    b = rng.randn(Co) * 0.3
+    y_ref = F.conv3d_fwd(x, W, b, (1, 2, 2), (0, 1, 1))
+    lay = L()
+    xd, wd, bd = lay.act_to_dev(dev(x)), lay.conv_w_to_dev(dev(W)), dev(b)
+    g = hl.make_geom(N, Ti, H, H, xd.shape[-1], Co, kt, ci_valid=Ci if xd.shape[-1] != Ci else 0)
+    g.tile = tile
+    M = N * g.To * g.Ho * g.Wo
+    noise = 0.2 * rng.randn(*y_ref.shape)
+    nd = lay.act_to_dev(dev(noise))
+    for groups in (1, 2):
+        ng = N // groups
+        for kw in (dict(addend=[nd[i * ng:(i + 1) * ng] for i in range(groups)]), dict(sigma=0.2, seed=3, stream_id=[6, 2][:groups])):
+            m32, m16 = (torch.zeros((M, (Co + 31) // 32), dtype=torch.int32, device="cuda") for _ in range(2))
+            a32 = torch.empty((N, g.To, g.Ho, g.Wo, Co), device="cuda")
+            asp = torch.full((N, g.To, g.Ho, g.Wo, 4 * Co), 3.0, device="cuda", dtype=torch.bfloat16)
+            assert hl.conv_fprop(g, xd, wd, bd, a32, ep=hl.epilogue(act=hl.ACT_LRELU, groups=groups, mask_out=m32, **kw), must_fuse=True)
+            assert hl.conv_fprop(g, xd, wd, bd, asp, ep=hl.epilogue(act=hl.ACT_LRELU, groups=groups, mask_out=m16, out_split=True, **kw), must_fuse=True)
+            want = hl.split_planes(a32).view(M, Co // 16, 4, 16)
+            got = asp.view(M, Co // 16, 4, 16)
+            assert torch.equal(got[:, :, :3], want[:, :, :3]) and torch.equal(m32, m16), (groups, list(kw))
+            assert float((got[:, :, 3].float() - 3.0).abs().max()) == 0.0                    # the padding plane is not written
+            if 'addend' in kw:
+                terms = got[:, :, :3].double().sum(2).reshape(N, g.To, g.Ho, g.Wo, Co)
+                assert rel_l2(lay.act_from_dev(terms.float(), Co), F.leaky_relu_fwd(y_ref) + noise) < FWD_TOL
+    with pytest.raises(hl.McgError):                                                          # only with the activation epilogue
+        hl.conv_fprop(g, xd, wd, bd, asp, ep=hl.epilogue(out_split=True), must_fuse=True)
 
 
 @pytest.mark.parametrize("case", EPI_CASES[:3])

@@ -261,9 +261,11 @@ def _run_steps(pkg, model, dim_zl, nf, n, steps, seed, min_tight_steps=1, overla
     assert tight_steps >= min_tight_steps, "seed no longer yields a well-conditioned iteration"
 
 
-@pytest.mark.parametrize("model,dim_zl,seed", [("normal", 0, 303), ("normal", 6, 311), ("infogan", 6, 313), ("cgan", 6, 320)])
+@pytest.mark.parametrize("model,dim_zl,seed", [("normal", 0, 1267), ("normal", 6, 3342), ("infogan", 6, 481), ("cgan", 6, 320)])
 def test_update_core_three_steps(pkg, model, dim_zl, seed):
-    _run_steps(pkg, model, dim_zl, nf=4, n=2, steps=3, seed=seed)
+    """the seeds of the committed golden iterations (tests/golden/make_golden.py searched them in round 6): all three iterations of
+    every variant keep their pre-activations clear of the kinks, so every gradient and update is held to the tight tolerances"""
+    _run_steps(pkg, model, dim_zl, nf=4, n=2, steps=3, seed=seed, min_tight_steps=3)
 
 
 def test_update_core_with_side_streams(pkg):
@@ -439,6 +441,73 @@ def test_update_core_full_width_with_the_devices_activation_decisions(pkg, preci
     check_params(DI.export_reference_params(), di, 'dis', 1e-4, 'D_I', ref['grads_dis_i'])
     check_params(DV.export_reference_params(), dv, 'dis', 1e-4, 'D_V', ref['grads_dis_v'])
     check_params(G.export_reference_params(), gen, 'gen', 1e-4, 'G', ref['grads_gen'])
+
+
+def _free_params_rel_l2(net, ref):
+    """rel-L2 over all trained tensors of a network (running statistics and the exact-zero pre-BatchNorm biases left out)"""
+    got = net.export_reference_params()
+    num = den = 0.0
+    for k, v in ref.items():
+        if v.dtype.kind != 'f' or 'avg_' in k:
+            continue
+        if k.startswith('dc') and k.endswith('/b') and ('bn%s/gamma' % k[2]) in ref:
+            continue
+        a = np.asarray(got[k].cpu() if torch.is_tensor(got[k]) else got[k], F64)
+        num += float(((a - v) ** 2).sum())
+        den += float((v ** 2).sum())
+    return (num / den) ** 0.5
+
+
+@pytest.mark.parametrize("precision,nf,n", [('f32x3', 16, 3), ('f32x3', 64, 2), ('f32', 16, 3)])
+def test_free_running_iterations_with_the_devices_activation_decisions(pkg, precision, nf, n, monkeypatch):
+    """Three FREE-RUNNING iterations of the headline's arithmetic ('f32x3': every launch that has a split form takes it; side streams)
+    held to the fp32 tolerances in EVERY iteration: losses and the generated clip to 1e-5, all parameters to 1e-4 after the third
+    (SURVEY 8c).  The device keeps its own parameters, Adam moments and BatchNorm statistics; the oracle keeps its own too and, per
+    iteration, takes the device's ReLU / LeakyReLU decisions inside the band |pre-activation| < 1e-4 (oracle.net._decide) -- at
+    n_filters >= 16 some pre-activation always lies within fp32 rounding of its kink, and without that a free-running comparison is
+    tight in its first iteration only (tests/test_gpu_fullwidth.py holds its f32x3 schedule to 2e-3 for that reason).  Outside the
+    band the two must agree (asserted).  Round 5's review, item 5b; model/updater.py:78-113."""
+    hl, lay, nets, step = pkg
+    model, dim_zl = 'infogan', 6
+    monkeypatch.setenv('MCG_SPLIT', 'always')
+    rng = np.random.RandomState(4)
+    gen = _f64(onet.init_generator(rng, dim_zl=dim_zl, n_filters=nf))
+    di = _f64(onet.init_discriminator(rng, 2, 3, 7, nf))
+    dv = _f64(onet.init_discriminator(rng, 3, 3, 7, nf))
+    G, DI, DV = nets.GenNet(dim_zl=dim_zl, n_filters=nf), nets.DisNet(2, 3, 7, nf, use_noise=True), nets.DisNet(3, 3, 7, nf, use_noise=True)
+    og, oi, ov = (oupd.new_adam_state(q) for q in (gen, di, dv))
+    for net, p, st in ((G, gen, og), (DI, di, oi), (DV, dv, ov)):       # identical START only
+        net.load_reference_params(p)
+        net.load_adam_state(st)
+    split_before, multi_before = hl.split_launches, hl.split_multi_launches
+    ts = step.TrainStep(model, G, DI, DV, overlap=True, precision=precision)
+    forced = []
+    for it in range(3):
+        x_real = rng.uniform(-1, 1, (n, 3, 16, 64, 64))
+        t_real = rng.randint(0, 6, n)
+        rnd = oupd.draw_step_randomness(rng, model, n, 3, nf, dim_zl=dim_zl, dtype=F64)
+        inject = {'t': rnd['t'], 'gen': draw_to_dev(rnd['gen'])}
+        for k in ('noise_i_real', 'noise_v_real', 'noise_i_fake', 'noise_v_fake'):
+            inject[k] = noise_to_dev(lay, rnd[k])
+        out = ts.run(dev(x_real), dev(t_real, torch.int32), inject)
+        losses = ts.losses()
+        kinks = device_decisions(out, G, DI, DV)
+        kinks['eps'] = KINK_BAND
+        ref = oupd.update_core(model, gen, di, dv, og, oi, ov, x_real, t_real, rnd, dim_zl=dim_zl, keep=True, kinks=kinks)
+        assert ref['kink_disagree'] == 0, it
+        forced.append(ref['kink_forced'])
+        assert abs(losses['image_dis/loss'] - ref['loss_dis_i']) < 1e-5, it
+        assert abs(losses['video_dis/loss'] - ref['loss_dis_v']) < 1e-5, it
+        assert abs(losses['image_gen/loss'] - ref['loss_gen']) < 1e-5, it
+        assert rel_l2(lay.act_from_dev(out['x_fake'], 3), ref['x_fake'][:, :3]) < 1e-5, it
+        assert rel_l2(lay.act_from_dev(out['gx_fake'], 3), ref['gx_fake']) < 1e-4, it
+    errs = {name: _free_params_rel_l2(net, p) for name, net, p in (('G', G, gen), ('D_I', DI, di), ('D_V', DV, dv))}
+    print('free-running %s nf=%d: decisions taken from the device per iteration %s, parameters rel-L2 after 3 iterations %s' % (precision, nf, forced, errs))
+    assert all(e < 1e-4 for e in errs.values()), errs
+    assert G.t == DI.t == DV.t == 3
+    if precision == 'f32x3':
+        assert hl.split_launches - split_before >= 3 * 8, "the split form did not run"
+        assert hl.split_multi_launches - multi_before >= 2 * 2, "the filters' split forms were not refreshed in one launch per Adam update"
 
 
 @pytest.mark.parametrize("chains", [False, True])
