@@ -85,7 +85,7 @@ def pmc_traffic(batch, dtype='f32'):
     (FETCH_SIZE / WRITE_SIZE cannot be read from inside the process; tools/pmc_traffic.py documents the
     collection).  Scaled linearly from the profiled batch.  Returns (bytes_per_step | None, source)."""
     names = ('r05_dv_conv_traffic_bf16.json', 'r04_dv_conv_traffic_bf16.json', 'r03_dv_conv_traffic_bf16.json') if dtype == 'bf16' else \
-        ('r05_dv_conv_traffic_f32x3.json', 'r04_dv_conv_traffic_f32x3.json', 'r03_dv_conv_traffic_f32x3.json') if dtype == 'f32x3' else \
+        ('r06_dv_conv_traffic_f32x3.json', 'r05_dv_conv_traffic_f32x3.json', 'r04_dv_conv_traffic_f32x3.json', 'r03_dv_conv_traffic_f32x3.json') if dtype == 'f32x3' else \
         ('r05_dv_conv_traffic.json', 'r04_dv_conv_traffic.json', 'r03_dv_conv_traffic.json', 'r02_dv_conv_traffic.json', 'r01_dv_conv_traffic.json')
     for name in names:                                                              # newest collection first
         try:

@@ -458,7 +458,7 @@ def _free_params_rel_l2(net, ref):
     return (num / den) ** 0.5
 
 
-@pytest.mark.parametrize("precision,nf,n", [('f32x3', 16, 3), ('f32x3', 64, 2), ('f32', 16, 3)])
+@pytest.mark.parametrize("precision,nf,n", [('f32x3', 16, 3), ('f32', 16, 3)])
 def test_free_running_iterations_with_the_devices_activation_decisions(pkg, precision, nf, n, monkeypatch):
     """Three FREE-RUNNING iterations of the headline's arithmetic ('f32x3': every launch that has a split form takes it; side streams)
     held to the fp32 tolerances in EVERY iteration: losses and the generated clip to 1e-5, all parameters to 1e-4 after the third
@@ -466,7 +466,11 @@ def test_free_running_iterations_with_the_devices_activation_decisions(pkg, prec
     iteration, takes the device's ReLU / LeakyReLU decisions inside the band |pre-activation| < 1e-4 (oracle.net._decide) -- at
     n_filters >= 16 some pre-activation always lies within fp32 rounding of its kink, and without that a free-running comparison is
     tight in its first iteration only (tests/test_gpu_fullwidth.py holds its f32x3 schedule to 2e-3 for that reason).  Outside the
-    band the two must agree (asserted).  Round 5's review, item 5b; model/updater.py:78-113."""
+    band the two must agree (asserted).  Round 5's review, item 5b; model/updater.py:78-113.
+    (Not at n_filters = 64: tried in round 6 with 2 clips -- the first iteration is tight, in the second 66 of ~2e7 decisions differ
+    OUTSIDE the 1e-4 band: Adam's first updates are +-alpha whatever the gradient's size, so parameters whose gradient is rounding
+    noise on both sides move 4e-4 apart, and with two samples per BatchNorm channel that reaches the pre-activations.  The
+    full-width iteration is held tight by test_update_core_full_width_with_the_devices_activation_decisions, teacher-forced.)"""
     hl, lay, nets, step = pkg
     model, dim_zl = 'infogan', 6
     monkeypatch.setenv('MCG_SPLIT', 'always')
