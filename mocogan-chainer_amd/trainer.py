@@ -206,6 +206,7 @@ class PrefetchIterator(SerialIterator):
 
     def _drop_queue(self):
         """forget the look-ahead: cancel what has not started, wait for what is running (it writes into a slot), free the slots"""
+        self._dev_next = None                                         # (a batch already on the device: its slot returns through _busy)
         for _, futs, slot in getattr(self, '_queue', []):
             for f in futs:
                 if not f.cancel():
@@ -232,7 +233,7 @@ class PrefetchIterator(SerialIterator):
     def consumed_batches(self):
         """number of batches handed out so far (the look-ahead's are not counted): what a snapshot stores, so that a
         resumed run seeds the workers' per-batch draws (sub-sequence offsets) where this one stopped"""
-        return self._batch_no - len(self._queue)
+        return self._batch_no - len(self._queue) - (1 if isinstance(getattr(self, '_dev_next', None), dict) else 0)
 
     # -- bookkeeping: SerialIterator.next() minus the loading ------------------------------------------
     def _state(self):
@@ -344,17 +345,57 @@ class PrefetchIterator(SerialIterator):
 
     __next__ = next
 
-    def next_device_batch(self, device, with_event=False, as_uint8=False):
+    def next_device_batch(self, device, with_event=False, as_uint8=False, ahead=False):
         """-> (x_real float32 (N,C,T,H,W) on `device`, labels list).  The H2D copy runs from pinned memory on a
         side stream; the caller's stream waits for it.  as_uint8 (raw datasets only; otherwise ignored): x_real is the copied
         uint8 batch (N,T,H,W,C) itself -- step.TrainStep.run normalises it in its first kernels (mcg_pack_clip_u8), which saves the
         five torch passes below (1.4 GB of traffic per 256-clip batch beside the GEMMs).  with_event: -> (x_real, labels, event, labels_dev) -- the event recorded on
         the copy stream when the batch was complete (`TrainStep.run(input_event=...)` lets a stream that needs nothing but the batch,
         the VideoDiscriminator's real chain, wait for exactly that instead of for everything queued on the caller's stream) and the
-        labels as an int32 device tensor copied on that stream too (None for an unlabelled dataset)."""
+        labels as an int32 device tensor copied on that stream too (None for an unlabelled dataset).
+        ahead (round 6; every call of an iterator must then use the same arguments): the copy of the batch AFTER the one returned is
+        issued in this call too, one iteration early.  HIP maps streams onto four hardware queues in creation order and TrainStep's
+        six side streams exist already, so the copy stream shares a queue with a compute stream and a copy waits behind that
+        stream's queued kernels: issued when it is needed, it completed up to an iteration late (the host waited 5 ms per
+        iteration at batch 256 for a batch slot whose copy had not run; the next real chain for its input).  Epoch bookkeeping
+        (`epoch`, `is_new_epoch`, `epoch_detail`) stays that of the batch RETURNED."""
+        key = (str(device), bool(with_event), bool(as_uint8))
+        rec, self._dev_next = getattr(self, '_dev_next', None), None
+        if rec is StopIteration:
+            raise StopIteration
+        if rec is not None and rec['key'] != key:
+            raise ValueError('next_device_batch(ahead=True): the look-ahead batch was issued with other arguments %r' % (rec['key'],))
+        if rec is None:
+            rec = self._issue_device_batch(device, with_event, as_uint8, key)
+        out = self._consume_device_batch(rec, with_event)
+        if ahead:
+            try:
+                self._dev_next = self._issue_device_batch(device, with_event, as_uint8, key)
+            except StopIteration:
+                self._dev_next = StopIteration
+        return out
+
+    def _consume_device_batch(self, rec, with_event):
+        """hand an issued batch to the caller's stream: that stream waits for the copy, the iterator shows the batch's bookkeeping"""
+        import torch
+        cur = torch.cuda.current_stream()
+        cur.wait_event(rec['event'])
+        rec['dev'].record_stream(cur)
+        if rec['lab_dev'] is not None:
+            rec['lab_dev'].record_stream(cur)
+        self._set_state(rec['state'])
+        return (rec['dev'], rec['labels'], rec['event'], rec['lab_dev']) if with_event else (rec['dev'], rec['labels'])
+
+    def _issue_device_batch(self, device, with_event, as_uint8, key):
+        """pop the next batch and queue its H2D copy on the copy stream; the iterator's visible bookkeeping does not move"""
         import torch
         if self._copy_stream is None:
-            self._copy_stream = torch.cuda.Stream(device=device)
+            # (MCG_LOADER_STREAM_SKIP throw-away streams created first choose WHICH hardware queue the copy stream shares;
+            #  MCG_LOADER_STREAM_PRIO=-1 asks for a high-priority stream: measured in round 6 -- no placement avoids the sharing, and the
+            #  high-priority stream costs the iteration 8 %; see `ahead` above for what helps)
+            skip = int(os.environ.get('MCG_LOADER_STREAM_SKIP', '0'))
+            self._skipped_streams = [torch.cuda.Stream(device=device) for _ in range(skip)]
+            self._copy_stream = torch.cuda.Stream(device=device, priority=int(os.environ.get('MCG_LOADER_STREAM_PRIO', '0')))
             self._pin, self._pin_free, self._pin_i, self._pin_lab = [None] * 3, [None] * 3, 0, [None] * 3
             # The batch slots themselves are page-locked when that is possible (hipHostRegister of the shared-memory segments): the
             # workers then decode straight into pinned memory and the H2D copy reads the slot -- no host copy at all (50 MB per batch
@@ -368,12 +409,19 @@ class PrefetchIterator(SerialIterator):
                     self._slots_pinned = torch.from_numpy(self._slots[0][1]).is_pinned()
                 except Exception as exc:                              # (fall back to the staging ring)
                     sys.stderr.write('PrefetchIterator: batch slots not page-locked (%r): staging through pinned buffers\n' % (exc,))
+        user = self._state()
+        try:
+            return self._issue_popped(device, with_event, as_uint8, key)
+        finally:
+            self._set_state(user)                                     # (_pop moved the bookkeeping to the popped batch: rec['state'] holds it)
+
+    def _issue_popped(self, device, with_event, as_uint8, key):
+        import torch
         if getattr(self, '_slots_pinned', False):
             self._reclaim()
             view, labels, slot = self._pop(keep_slot=True)
             host = torch.from_numpy(view)
             i = self._pin_i = (self._pin_i + 1) % 3
-            cur = torch.cuda.current_stream()
             with torch.cuda.stream(self._copy_stream):
                 dev = host.to(device, non_blocking=True)
                 if self._raw and not as_uint8:
@@ -390,11 +438,7 @@ class PrefetchIterator(SerialIterator):
                 done.record(self._copy_stream)
                 self._pin_free[i] = done
                 self._busy.append((slot, done))
-            cur.wait_event(done)
-            dev.record_stream(cur)
-            if lab_dev is not None:
-                lab_dev.record_stream(cur)
-            return (dev, labels, done, lab_dev) if with_event else (dev, labels)
+            return dict(key=key, dev=dev, labels=labels, event=done, lab_dev=lab_dev, state=self._state())
         # Otherwise: a ring of three PINNED staging buffers, allocated once; the batch is assembled in one of them and copied from there.
         # (Round 5, found by timing the product path -- tools/bench_train.py: `torch.from_numpy(videos).pin_memory()` allocated and
         # freed pinned memory every iteration, and freeing pinned memory waits for the device -- 35-40 ms per batch whatever its
@@ -411,7 +455,6 @@ class PrefetchIterator(SerialIterator):
             return t.numpy()
         videos, labels = self._pop(out=staging)
         host = self._pin[i]
-        cur = torch.cuda.current_stream()
         with torch.cuda.stream(self._copy_stream):
             dev = host.to(device, non_blocking=True)
             if self._raw and not as_uint8:
@@ -424,16 +467,10 @@ class PrefetchIterator(SerialIterator):
                     self._pin_lab[i] = torch.empty(max(len(labels), self.batch_size), dtype=torch.int32, pin_memory=True)
                 self._pin_lab[i][:len(labels)] = torch.from_numpy(np.asarray(labels, dtype=np.int32))
                 lab_dev = self._pin_lab[i][:len(labels)].to(device, non_blocking=True)
-            self._pin_free[i] = torch.cuda.Event()                    # both staging buffers of slot i have been read
-            self._pin_free[i].record(self._copy_stream)
-            ready = torch.cuda.Event() if with_event else None
-            if ready is not None:
-                ready.record(self._copy_stream)
-        cur.wait_stream(self._copy_stream)
-        dev.record_stream(cur)
-        if lab_dev is not None:
-            lab_dev.record_stream(cur)
-        return (dev, labels, ready, lab_dev) if with_event else (dev, labels)
+            ready = torch.cuda.Event()                                # the batch (and both staging buffers of ring position i) has been read
+            ready.record(self._copy_stream)
+            self._pin_free[i] = ready
+        return dict(key=key, dev=dev, labels=labels, event=ready, lab_dev=lab_dev, state=self._state())
 
     def close(self):
         self._pool.shutdown(wait=bool(getattr(self, '_slots', None)), cancel_futures=True)      # (workers may still be writing into a slot)

@@ -128,8 +128,10 @@ class Updater:
         if hasattr(it, 'next_device_batch'):                                         # prefetching loader: uint8 from pinned memory on
             # a copy stream; raw (uint8) datasets stay uint8 (N,T,H,W,C): TrainStep.run normalises in its first kernels (MCG_LOADER_U8=0:
             # the float (N,C,T,H,W) batch of rounds 1-5, five torch passes on the copy stream)
+            # ahead: the copy of the NEXT batch is queued now as well (MCG_LOADER_AHEAD=0: when it is needed, as in rounds 1-5)
             x_real, labels, ready, t_real = it.next_device_batch(self._step.device, with_event=True,
-                                                                 as_uint8=os.environ.get('MCG_LOADER_U8', '1') == '1')
+                                                                 as_uint8=os.environ.get('MCG_LOADER_U8', '1') == '1',
+                                                                 ahead=os.environ.get('MCG_LOADER_AHEAD', '1') == '1')
         else:
             batch = it.next()
             labels = [b[1] for b in batch]

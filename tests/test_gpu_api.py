@@ -196,6 +196,23 @@ def test_prefetching_loader_feeds_the_updater(tmp_path, monkeypatch):
             assert (pre.epoch, pre.is_new_epoch) == (ser.epoch, ser.is_new_epoch)
     finally:
         pre.close()
+    # round 6: with ahead=True the copy of the NEXT batch is queued in the same call; batches, labels and the epoch bookkeeping are
+    # still those of the batch returned (SerialIterator's), across a wrap-around, and a snapshot position counts returned batches only
+    ser = T.SerialIterator(ds, 4, shuffle=False)
+    pre = T.PrefetchIterator(ds, 4, shuffle=False, n_workers=2, prefetch=2, chunk=2)
+    try:
+        for k in range(4):
+            b = ser.next()
+            x_u8, labels, ready, lab_dev = pre.next_device_batch(torch.device('cuda'), with_event=True, as_uint8=True, ahead=True)
+            ready.synchronize()
+            x_dev = ((x_u8.float() - 128.) / 128.).permute(0, 4, 1, 2, 3)
+            assert np.array_equal(x_dev.cpu().numpy(), np.stack([e[0] for e in b])) and labels == [e[1] for e in b], k
+            assert (pre.epoch, pre.is_new_epoch, pre.epoch_detail) == (ser.epoch, ser.is_new_epoch, ser.epoch_detail), k
+            assert pre.consumed_batches() == k + 1 and isinstance(pre._dev_next, dict)
+        with pytest.raises(ValueError):
+            pre.next_device_batch(torch.device('cuda'), with_event=False, ahead=True)
+    finally:
+        pre.close()
     monkeypatch.chdir(tmp_path)
     tr = train.main(['--dataset_type', 'mug', '--dataset', str(tmp_path / 'mug'), '--batchsize', '3', '--max_epoch', '2',
                      '--n_filters_gen', '8', '--save_name', 'pf', '--loader_workers', '2', '--snapshot_interval', '5'])
