@@ -875,6 +875,36 @@ __device__ __forceinline__ void fused_epilogue(const P& p, f32x16 (&acc)[TM][TN]
     }
 }
 
+// dgrad: linear block index -> (M tile bx, N tile by, bz = K chunk * 4 + parity class); false for the padding of the tile count to a
+// multiple of 8.  (M tile, N tile) pairs are dealt round-robin over the XCDs in dispatch order, the four parity classes of a pair
+// are consecutive workgroups of one XCD (see gemm_kernel).  Split-K launches of 3-D layers (round 6, MCG_DGRAD_HEAVY_FIRST): rows
+// are time-major and a K chunk of a tile near the clip's ends holds few or no live temporal taps, so blocks differ 0 : 1 : 2 in
+// length; in plain order (chunk slowest, frames ascending) the long blocks of the middle frames' second chunk start last and the
+// launch ends with them alone (3 tap-units on 512 block slots where 2 are needed: D_V dc4 at 64 clips).  With the switch on the tile
+// groups go from the MIDDLE frames outwards with the chunks of a group adjacent: long blocks first, the short and empty ones fill
+// the end.  MEASURED (alternating A/B on one MI355X, f32x3 operands, profiles/r06_dgrad_heavy_first_ab.txt) and NOT kept: dc4 at 64
+// clips 1010: 0.450 -> 0.488 ms, 2010: 0.457 -> 0.550, 1007: 0.538 -> 0.471; at 32 clips 1010: 0.291 -> 0.276, 2010: 0.262 -> 0.340;
+// dc3 at 64 clips 1010: 0.76 -> 0.81.  The scheduling model is not what bounds these launches: in plain order every resident block
+// works on the SAME K chunk -- the same filter slab streams through the L2s once for all of them -- and interleaving the chunks
+// doubles the filter bytes in flight (dc4's blocks re-stream 67 MB of split filters per 128-row tile).  Off.
+#ifndef MCG_DGRAD_HEAVY_FIRST
+#define MCG_DGRAD_HEAVY_FIRST 0
+#endif
+template <class P> __device__ __forceinline__ bool dgrad_block(const P& p, int Lb, int& bx, int& by, int& bz) {
+    const int xq = Lb & 7, qq = Lb >> 3, cls = qq & 3, rr = qq >> 2;
+    int split, g8;
+    const int nsplit = p.kchunk < p.K ? (p.K + p.kchunk - 1) / p.kchunk : 1;
+    if (MCG_DGRAD_HEAVY_FIRST != 0 && nsplit > 1 && p.g.kt == 4) {
+        const int j = rr / nsplit, c = (p.tiles8 - 1) >> 1;
+        split = rr - j * nsplit;
+        g8 = (j & 1) ? c + 1 + (j >> 1) : c - (j >> 1);
+    } else { split = rr / p.tiles8; g8 = rr - split * p.tiles8; }
+    const int tl = g8 * 8 + xq;
+    if (tl >= p.gxm * p.gyn) return false;
+    by = tl % p.gyn; bx = tl / p.gyn; bz = split * 4 + cls;
+    return true;
+}
+
 // p.idle(first live K-step, end of the block's K range) where the policy has one (DgradP), else false
 template <class P> __device__ __forceinline__ auto block_idle(const P& p, int k, int kend, int) -> decltype(p.idle(k, kend)) { return p.idle(k, kend); }
 template <class P> __device__ __forceinline__ bool block_idle(const P&, int, int, long) { return false; }
@@ -921,11 +951,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(P p) {
             // XCDs unequal work (measured: dc2 0.81 -> 0.97 ms) -- and the FOUR PARITY CLASSES of a pair, which read
             // the same y rows at the same K phase, are consecutive workgroups of one XCD (1-D grid, launch_dgrad).
 #ifndef MCG_NO_CLASS_ADJ
-            const int Lb = blockIdx.x, xq = Lb & 7, qq = Lb >> 3;
-            const int cls = qq & 3, rr = qq >> 2;
-            const int split = rr / p.tiles8, tl = (rr - split * p.tiles8) * 8 + xq;
-            if (tl >= p.gxm * p.gyn) return;                       // padding of the tile count to a multiple of 8
-            by = tl % p.gyn; bx = tl / p.gyn; bz = split * 4 + cls;
+            if (!dgrad_block(p, blockIdx.x, bx, by, bz)) return;      // padding of the tile count to a multiple of 8
 #else
             bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
 #endif
@@ -1169,11 +1195,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(P p) {
             by = t % gy; bx = (t / gy) % gx; bz = t / (gy * gx);
         } else if constexpr (P::ORDER == 1) {
 #ifndef MCG_NO_CLASS_ADJ
-            const int Lb = blockIdx.x, xq = Lb & 7, qq = Lb >> 3;
-            const int cls = qq & 3, rr = qq >> 2;
-            const int split = rr / p.tiles8, tl = (rr - split * p.tiles8) * 8 + xq;
-            if (tl >= p.gxm * p.gyn) return;
-            by = tl % p.gyn; bx = tl / p.gyn; bz = split * 4 + cls;
+            if (!dgrad_block(p, blockIdx.x, bx, by, bz)) return;
 #else
             bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
 #endif
@@ -1510,11 +1532,7 @@ __global__ __launch_bounds__(NT2) void gemm_bf16_v2_kernel(P p) {
         if constexpr (P::ORDER == 0) {
             by = t % gy; bx = (t / gy) % gx; bz = t / (gy * gx);
         } else if constexpr (P::ORDER == 1) {
-            const int Lb = blockIdx.x, xq = Lb & 7, qq = Lb >> 3;
-            const int cls = qq & 3, rr = qq >> 2;
-            const int split = rr / p.tiles8, tl = (rr - split * p.tiles8) * 8 + xq;
-            if (tl >= p.gxm * p.gyn) return;
-            by = tl % p.gyn; bx = tl / p.gyn; bz = split * 4 + cls;
+            if (!dgrad_block(p, blockIdx.x, bx, by, bz)) return;
         } else { bx = t % gx; by = (t / gx) % gy; bz = t / (gx * gy); }
     }
     const int m0 = bx * BM, n0 = by * BN;
