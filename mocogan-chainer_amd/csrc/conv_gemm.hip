@@ -3563,8 +3563,10 @@ int launch_wgrad_v2(const Geom& g, const float* x, const float* y, float* dw, hi
     const int tiles = ((g.Co + BM - 1) / BM) * ((p.Kf + BN - 1) / BN);
     const int ksteps = (p.Mpix + BK - 1) / BK;
     // one block per CU at a time (LDS): aim at 2 rounds of blocks; every block ends in BM x BN float atomics, so fewer, longer
-    // blocks than the register-staged kernel's
-    int splits = (512 + tiles - 1) / tiles;
+    // blocks than the register-staged kernel's.  Tile codes + 1000 / + 2000 (round 6) double / halve the target: a 2-D layer with
+    // few taps has few tiles (G's dc3: 4), so 128 pixel splits each add 128 x 256 atomics onto the SAME 0.5 MB of dw
+    const int target = g.ksplit == 2 ? 1024 : (g.ksplit == 4 ? 256 : 512);
+    int splits = (target + tiles - 1) / tiles;
     constexpr int MINSTEPS = SPLIT ? 32 : 8;             // keep >= 512 pixels per block
     if (splits > ksteps / MINSTEPS) splits = ksteps / MINSTEPS;
     if (splits < 1) splits = 1;
@@ -3892,7 +3894,7 @@ extern "C" int mcg_conv_wgrad(const mcg_conv_geom* c, const float* x, const floa
         const long long x_el = (g.perm_n ? (long long)(g.perm_n - 1) * g.xs0 + (long long)(g.N / g.perm_n - 1) * g.xs1 : (long long)(g.N - 1) * g.xs0) +
                                (long long)g.Ti * g.Hi * g.Wi * g.Ci;
         const long long y_el = (long long)g.N * g.To * g.Ho * g.Wo * g.Co;
-        if ((g.tile != 0 && g.tile != 7 && g.tile != 8 && g.tile != 10) || g.Co < 128 || (g.Co & 63) || g.Ci < 64 || (g.Ci & (g.Ci - 1)) || g.ksplit != 1 ||
+        if ((g.tile != 0 && g.tile != 7 && g.tile != 8 && g.tile != 10) || g.Co < 128 || (g.Co & 63) || g.Ci < 64 || (g.Ci & (g.Ci - 1)) ||
             x_el * 8 >= (1ll << 31) || y_el * 8 >= (1ll << 31) || (y_el / g.Co) % 16) return MCG_ERR_UNSUPPORTED;
         Geom h = g;
         h.prec = MCG_PREC_BF16_STORE; h.x_bytes = (u32)(x_el * 8); h.y_bytes = (u32)(y_el * 8);

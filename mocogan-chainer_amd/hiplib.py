@@ -264,6 +264,7 @@ def _launch(kind, fn, *args):
 TILE_CANDIDATES = (0, 101, 102, 103, 201, 202, 203)     # (the long tiles 4 = 256x64 and 5 = 64x256 exist, but when they
                                                         # win the isolated timing they lose inside the iteration: measured)
 FPROP_SPLIT_CANDIDATES = (1103, 1203, 1202, 2103, 2203, 2202)     # 2- / 4-way split-K: only when few tiles (see _tuned)
+WGRAD_SPLIT_CANDIDATES = (2007, 2008, 2010, 1010)      # LDS-DMA weight gradient with half / twice the pixel splits (few-tile layers)
 V2_CANDIDATES = (7, 8, 10)                              # gemm_bf16_v2_kernel (bf16-stored / split / fp32 operands): 256x128 / 256x256 (wgrad 128x256 / 256x256) one block per CU; 10 = 128x128, two blocks per CU
 _autotune = False
 _tile_cache = {}
@@ -438,6 +439,8 @@ def _tuned(kind, g, extra, out_side, run_on):
                 # against 128-134 TFLOP/s on the big layers, and one 256-row block per CU quantises badly at batch 32
                 if not (kind == "dgrad" and g.Ci == 64):        # (64 output columns per parity class: the 256x64 tile never wins)
                     cands = cands + V2_CANDIDATES
+                    if kind == "wgrad" and g.Co * g.kt * 16 * g.Ci <= (1 << 21):
+                        cands = cands + WGRAD_SPLIT_CANDIDATES
                 else:
                     cands = cands + (10,)                       # ... but 256x64 with two buffers lets two blocks share a CU
                     if g.Ho == 16 and g.Wo == 16:
@@ -447,6 +450,10 @@ def _tuned(kind, g, extra, out_side, run_on):
             if g.precision == PREC_SPLIT:
                 # (the LDS-DMA kernels are the only ones that multiply split operands; one 256-row block per CU: late layers need K splits)
                 cands = V2_CANDIDATES + ((1007, 2007, 1010, 2010) if kind in ("fprop", "dgrad") and out_elems <= (1 << 25) else ())
+                if kind == "wgrad" and g.Co * g.kt * 16 * g.Ci <= (1 << 21):
+                    # few (Co, tap x Ci) tiles -- the 2-D layers: many pixel splits then add onto the same small dw with float
+                    # atomics; + 2000 halves / + 1000 doubles the number of splits (round 6)
+                    cands = cands + WGRAD_SPLIT_CANDIDATES
                 if kind == "dgrad" and g.Ci == 64 and g.Ho == 16 and g.Wo == 16:
                     cands = cands + (9,)                        # the patch-stationary kernel (four parity classes per block)
             for cand in cands:
