@@ -3256,6 +3256,221 @@ __global__ __launch_bounds__(512) void wgrad_c4_kernel(C4WgradP p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The first layer's weight gradient of bf16 networks on the bf16 MFMA (round 6): y is bf16 in memory (MCG_PREC_BF16_Y16), the clip x
+// fp32.  The generic 64x64 tile gathers its B operand 16 bytes per (pixel, tap) from global memory and ran D_V's dc1 at 0.60 ms for
+// 512 clips against an HBM floor of 0.28; wgrad_c4_kernel above needs fp32 MFMAs.  Here, per step of 256 output pixels (R = 256 / Wo
+// rows of one frame):
+//   * the y tile [256 pixels][64 co] goes global -> LDS as it is (32 KB, row stride 160 B: the four pixel rows a 16-lane group of
+//     the transposing read touches then fall into four different bank octets);
+//   * the input patch is a ring of kt + 1 frame slabs in bf16, pixel-major with one pixel of left padding -- the layout of
+//     fprop_c4_bf16_kernel: the clip is rounded to bf16 on its way into LDS;
+//   * BOTH MFMA operands are K-major in LDS (K = pixels) and both are read with ds_read_b64_tr_b16, whose lanes each supply the
+//     address of four consecutive columns of one k row: for A = y^T that is four output channels of a pixel, for B it is the FOUR
+//     CHANNELS OF ONE INPUT PIXEL -- lane (q, p) of a 16-lane group addresses output pixel q at tap kw = p, i.e. patch pixel
+//     2 wo + kw of row 2 ho + kh, 16 bytes per output pixel apart.  The pixel-major patch IS the B operand: no column-planar copy.
+//   * v_mfma_f32_32x32x16_bf16: M = 64 output channels (2 blocks), N = kt * 16 taps x 4 channels (8 blocks of 8 taps for kt = 4),
+//     K = 16 pixels.  A wave owns both M blocks and NBW N blocks (4 for kt = 4: 128 accumulator registers) and a quarter / an
+//     eighth of a step's pixels; the partial sums of the pixel groups meet in LDS at the end (ds_add_f32) and leave with float
+//     atomics, as wgrad_c4_kernel's.  Fragment reads: 12 x 8 B per lane per 8 MFMAs = 96 B/clk of the LDS's 128 at the full matrix
+//     rate; loads of step s + 1 (y tile, one new slab) are in flight under the MFMAs of step s, one barrier per step.
+// ------------------------------------------------------------------------------------------
+// NT / BM: threads and output pixels per step.  512 / 256 is one block per CU (131 KB of LDS); 256 / 128 (68 KB) puts TWO blocks on a CU:
+// each block's loads of the next step (its waves wait for them at the LDS store behind the MFMAs) then overlap the other block's MFMAs
+// (measured on D_V's dc1 at 512 clips: no faster by itself -- 0.454 -> 0.456 ms; what moved the kernel is in NOTES_r06 section 7).
+#ifndef MCG_WC4_YS               // LDS row strides of wgrad_c4_bf16_kernel (tuning switches): y tile rows, extra bytes per patch row
+#define MCG_WC4_YS 160
+#endif
+#ifndef MCG_WC4_ROWPAD
+#define MCG_WC4_ROWPAD 0
+#endif
+template <int KT, int WO, int NT, int BM>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void wgrad_c4_bf16_kernel(C4WgradP p) {     // (two waves per SIMD: <= 256 registers)
+    constexpr int K = KT * 64;
+    constexpr int R = BM / WO, PR = 2 * R + 2, WI = 2 * WO;
+    constexpr int ENT = WI + 4, ROW = ENT * 8 + MCG_WC4_ROWPAD, SLAB = PR * ROW;     // bytes (a pixel = 4 bf16), as fprop_c4_bf16_kernel + row padding
+    constexpr int NLD = (PR * ENT + NT - 1) / NT, RING = KT + 1, NY = BM * 8 / NT;     // slab entries / 16-byte y chunks per thread
+    constexpr int YS = MCG_WC4_YS, YT = BM * YS;                                            // y tile: row stride, bytes per buffer
+    constexpr int NB = KT * 2, NBW = KT == 4 ? 4 : 2, WC = NB / NBW, PG = (NT / 64) / WC, KGW = (BM / 16) / PG;     // N blocks; per wave; wave columns; pixel groups; K groups per wave and step
+    constexpr int NC = NB * 32;                                                      // columns (tap, ci) incl. the padded channel
+    static_assert(64 * NC * 4 <= RING * SLAB + 2 * YT, "the reduction buffer reuses the tiles");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* pl = smem;                                  // RING * SLAB
+    unsigned char* yl = smem + RING * SLAB;                    // 2 * YT
+    float* red = reinterpret_cast<float*>(smem);               // [64][NC] after the last step
+    const Geom& g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int hblocks = g.Ho / R;
+    const int hb = blockIdx.x % hblocks, rest = blockIdx.x / hblocks;
+    const int n0 = rest % p.nsplit, ts = rest / p.nsplit, ho0 = hb * R;
+    const int tper = (g.To + p.tsplit - 1) / p.tsplit, t0 = ts * tper, t1 = t0 + tper < g.To ? t0 + tper : g.To;
+    const __amdgpu_buffer_rsrc_t xr = make_srd(p.x, g.x_bytes);
+    const u32 fbytes = (u32)g.Hi * WI * 16u;
+
+    // ---- patch slabs (as fprop_c4_bf16_kernel): position `en` of patch row pr holds input pixel (2 ho0 - 1 + pr, en - 1)
+    u32 goff[NLD]; int loff[NLD];
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int idx = tid + NT * j, pr = idx / ENT, en = idx - pr * ENT;
+        const int hi = 2 * ho0 - 1 + pr, wi = en - 1;
+        const bool ok = pr < PR && (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)WI;
+        goff[j] = ok ? (u32)(hi * WI + wi) * 16u : OOB;        // + (n * Ti + t) * fbytes per frame
+        loff[j] = pr < PR ? pr * ROW + en * 8 : -1;
+    }
+    // Two register sets: the loads of step k + 2 are issued in step k and stored to LDS at the end of step k + 1 -- at the kernel's rate
+    // (a step per ~4 us and CU) one step of look-ahead left 54 KB per CU in flight, which is what its 3.6 TB/s were (latency-bound).
+    f32x4 xs0[NLD], xs1[NLD];
+    auto slab_load = [&](f32x4 (&xst)[NLD], int n, int t, bool live) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) xst[j] = bload(xr, (goff[j] == OOB || !live) ? OOB : goff[j] + (u32)(n * g.Ti + t) * fbytes);
+    };
+    auto slab_store = [&](const f32x4 (&xst)[NLD], int slot) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j)
+            if (loff[j] >= 0) *reinterpret_cast<bf16x4*>(pl + slot * SLAB + loff[j]) = __builtin_convertvector(xst[j], bf16x4);
+    };
+    // ---- y tile of a step: BM consecutive pixels x 128 bytes, contiguous in memory
+    const u32x4* ysrc = reinterpret_cast<const u32x4*>(p.y);
+    u32x4 ys0[NY], ys1[NY];
+    auto y_load = [&](u32x4 (&yst)[NY], int n, int to) {
+        const long long m0 = ((long long)(n * g.To + to) * g.Ho + ho0) * WO;
+#pragma unroll
+        for (int j = 0; j < NY; ++j) yst[j] = ysrc[m0 * 8 + tid + NT * j];
+    };
+    auto y_store = [&](const u32x4 (&yst)[NY], int buf) {
+#pragma unroll
+        for (int j = 0; j < NY; ++j) {
+            const int c = tid + NT * j;
+            *reinterpret_cast<u32x4*>(yl + buf * YT + (c >> 3) * YS + (c & 7) * 16) = yst[j];
+        }
+    };
+
+    // ---- lane constants of the transposing reads (the mapping gemm_bf16_kernel uses: k row 8 lh + q, columns 16 g1 + 4 p)
+    const int q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = (lane >> 4) & 1;
+    const int pgi = wave / WC, wc = wave - pgi * WC;           // this wave's pixel group and wave column
+    const int a_lane = (8 * lh + q4) * YS + (16 * g1 + 4 * p4) * 2;                          // + mb * 64 + kg * 16 * YS (+ 4 * YS)
+    // B: output pixel 16 kg + 8 lh + q (+ 4) at tap (kh = 2 (nb & 1) + g1, kw = p): patch row 2 hol + kh, pixel position 2 wo + kw
+    const int b_lane = g1 * ROW + (2 * (8 * lh + q4) + p4) * 8;
+
+    f32x16 acc[2][NBW];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int k = 0; k < NBW; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][k][r] = 0.f;
+
+    // one step: MFMAs of frame `to` on y buffer to & 1 and ring slots to .. to + kt - 1
+    auto multiply = [&](int to) {
+        const unsigned char* yb = yl + (to & 1) * YT;
+        const int s0 = to % RING;
+#pragma unroll
+        for (int kk = 0; kk < KGW; ++kk) {
+            const int kg = pgi * KGW + kk;                     // 16 pixels: output row hol, columns wo0 .. wo0 + 15
+            const int hol = WO == 32 ? kg >> 1 : kg, wo0 = WO == 32 ? 16 * (kg & 1) : 0;
+            bf16x8 fa[2], fb[NBW];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const u16* ap = reinterpret_cast<const u16*>(yb + a_lane + mb * 64 + kg * 16 * YS);
+                const s16x4 lo = lds_tr16(ap), hi = lds_tr16(ap + 2 * YS);                  // (k rows + 4: 4 * YS bytes)
+                fa[mb] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int k = 0; k < NBW; ++k) {
+                const int nb = wc * NBW + k, a = KT == 4 ? nb >> 1 : 0;
+                int sl = s0 + a;
+                sl = sl >= RING ? sl - RING : sl;
+                const u16* bp = reinterpret_cast<const u16*>(pl + sl * SLAB + b_lane + (2 * hol + 2 * (nb & 1)) * ROW + 2 * wo0 * 8);
+                const s16x4 lo = lds_tr16(bp), hi = lds_tr16(bp + 32);                      // (output pixels + 4: 64 bytes)
+                fb[k] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int k = 0; k < NBW; ++k)
+                    acc[mb][k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mb], fb[k], acc[mb][k], 0, 0, 0);
+        }
+    };
+    // step `to` of an item with register sets (ld: receives the loads of step to + 2; st: holds step to + 1, loaded a step ago)
+    auto step = [&](int n, int to, u32x4 (&yld)[NY], f32x4 (&xld)[NLD], const u32x4 (&yst)[NY], const f32x4 (&xst)[NLD]) {
+        if (to + 2 < t1) { y_load(yld, n, to + 2); slab_load(xld, n, to + 2 + KT - 1, to + 2 + KT - 1 < g.Ti); }
+        multiply(to);
+        if (to + 1 < t1) { y_store(yst, (to + 1) & 1); slab_store(xst, (to + KT) % RING); }   // (a frame past the clip's end stores zeros nobody reads)
+        __syncthreads();
+    };
+    for (int n = n0; n < g.N; n += p.nsplit) {
+        if (t0 >= t1) break;
+        __syncthreads();                                       // the previous item's last step may still read the tiles
+        // the item's first kt frames and y tile, two slabs per round trip (every load of a round is issued before the first store waits)
+        y_load(ys0, n, t0);
+#pragma unroll
+        for (int a = 0; a < KT; a += 2) {
+            slab_load(xs0, n, t0 + a, true);
+            if (a + 1 < KT) slab_load(xs1, n, t0 + a + 1, true);
+            if (a == 0) y_store(ys0, t0 & 1);
+            slab_store(xs0, (t0 + a) % RING);
+            if (a + 1 < KT) slab_store(xs1, (t0 + a + 1) % RING);
+        }
+        if (t0 + 1 < t1) { y_load(ys1, n, t0 + 1); slab_load(xs1, n, t0 + KT, t0 + KT < g.Ti); }      // step t0 + 1 lives in set 1
+        __syncthreads();
+        for (int to = t0; to < t1; to += 2) {                  // steps t0 + 2 i load into set 0 and store set 1; the odd ones the other way
+            step(n, to, ys0, xs0, ys1, xs1);
+            if (to + 1 < t1) step(n, to + 1, ys1, xs1, ys0, xs0);
+        }
+    }
+
+    // ---- partial results of the pixel groups -> LDS -> dw
+    __syncthreads();
+    for (int i = tid; i < 64 * NC; i += NT) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int k = 0; k < NBW; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, col = (wc * NBW + k) * 32 + li;
+                __hip_atomic_fetch_add(&red[co * NC + col], acc[mb][k][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+    __syncthreads();
+    for (int i = tid; i < 64 * NC; i += NT) {
+        const int co = i / NC, col = i - co * NC;
+        if ((col & 3) < 3) atomicAdd(p.dw + (long long)co * K + col, red[i]);      // column = tap * 4 + ci; the padded channel has no gradient
+    }
+}
+
+bool c4_wgrad_bf16_ok(const Geom& g) {
+    const long long frame = (long long)g.Ti * g.Hi * g.Wi * g.Ci;
+    return g.Ci == 4 && g.cv <= 3 && g.Co == 64 && (g.Wo == 32 || g.Wo == 16) && g.Ho % (256 / g.Wo) == 0 && !g.perm_n &&
+           g.xs0 == frame && g.prec == MCG_PREC_BF16 && g.y16;          // (Ho a multiple of the 256-pixel step's rows, hence of the 128-pixel step's)
+}
+
+template <int KT, int WO>
+int launch_wgrad_c4_bf16(const Geom& g, const float* x, const float* y, float* dw, hipStream_t s) {
+    // 3-D layers with enough rows: 128-pixel steps, 256 threads, two blocks per CU; otherwise 256-pixel steps, one block per CU
+    constexpr bool SMALL = KT == 4;
+    constexpr int BM = SMALL ? 128 : 256, NT = SMALL ? 256 : 512;
+    C4WgradP p;
+    p.g = g; p.x = x; p.y = y; p.dw = dw;
+    constexpr int R = BM / WO;
+    const size_t lds = (size_t)(KT + 1) * (2 * R + 2) * ((2 * WO + 4) * 8 + MCG_WC4_ROWPAD) + 2 * BM * MCG_WC4_YS;
+    static std::once_flag once;
+    hipError_t attr = hipSuccess;
+    std::call_once(once, [&] { attr = hipFuncSetAttribute((const void*)wgrad_c4_bf16_kernel<KT, WO, NT, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+    if (attr != hipSuccess) return MCG_ERR_LAUNCH;
+    // (row block, batch item) pairs over ~2 rounds of blocks; with fewer the frames of an item are split (as launch_wgrad_c4)
+#ifndef MCG_WC4_TARGET           // blocks of the 3-D form: 512 = ONE round at two per CU (every block ends in 64 x kt * 48 float atomics onto the same
+#define MCG_WC4_TARGET 512       // dw: measured at 512 clips 0.458-0.472 ms with 1024 blocks, 0.397-0.406 with 512, 0.412-0.420 with 256)
+#endif
+    const int hblocks = g.Ho / R, target = SMALL ? MCG_WC4_TARGET : 512;
+    p.nsplit = g.N; p.tsplit = 1;
+    if (hblocks * p.nsplit > target) p.nsplit = target / hblocks > 0 ? target / hblocks : 1;
+    while (hblocks * p.nsplit * p.tsplit < target / 2 && 2 * p.tsplit * 2 <= g.To) p.tsplit *= 2;
+    hipLaunchKernelGGL((wgrad_c4_bf16_kernel<KT, WO, NT, BM>), dim3(hblocks * p.nsplit * p.tsplit), dim3(NT), lds, s, p);
+    return MCG_OK;
+}
+
 bool c4_wgrad_ok(const Geom& g) {
     const long long frame = (long long)g.Ti * g.Hi * g.Wi * g.Ci;
     return g.Ci == 4 && g.cv <= 3 && g.Co == 64 && (g.Wo == 32 || g.Wo == 16) && g.Ho % (256 / g.Wo) == 0 && !g.perm_n &&
@@ -3910,6 +4125,11 @@ extern "C" int mcg_conv_wgrad(const mcg_conv_geom* c, const float* x, const floa
     // the 3-channel clip padded to 4: patch-in-LDS kernel.  Only on request (tile code 6): measured on the MI355X it equals the
     // generic kernel on D_V's first layer at 64 clips (0.250 ms) and loses below that -- its steps run at the MFMA rate, but all
     // blocks finish together and their 64 x kt * 48 device-scope atomics each (~80 us) are not hidden behind other blocks' work
+    if (t == 6 && c4_wgrad_bf16_ok(g)) {                         // bf16 networks (y bf16 beside the fp32 clip): patch + y tile in LDS, bf16 MFMA
+        if (g.kt == 4) st = g.Wo == 32 ? launch_wgrad_c4_bf16<4, 32>(g, x, y, dw, s) : launch_wgrad_c4_bf16<4, 16>(g, x, y, dw, s);
+        else st = g.Wo == 32 ? launch_wgrad_c4_bf16<1, 32>(g, x, y, dw, s) : launch_wgrad_c4_bf16<1, 16>(g, x, y, dw, s);
+        return finish(st);
+    }
     if (g.y16 && (t == 6 || t == 7 || t == 8 || t == 9 || t == 10)) return MCG_ERR_UNSUPPORTED;      // (the register-staged tiles only)
     if (t == 6 && c4_wgrad_ok(g)) {
         if (g.kt == 4) st = g.Wo == 32 ? launch_wgrad_c4<4, 32>(g, x, y, dw, s) : launch_wgrad_c4<4, 16>(g, x, y, dw, s);

@@ -1433,6 +1433,40 @@ def test_bf16_y_beside_fp32_clip(hl, case):
         assert torch.equal(y16, y32.to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("case", [(2, 6, 64, 4), (3, 1, 64, 1), (4, 5, 32, 4), (2, 1, 32, 1), (5, 16, 64, 4), (140, 5, 64, 4), (600, 1, 32, 1)])
+def test_first_layer_weight_gradient_of_bf16_networks(hl, case):
+    """Round 6: wgrad_c4_bf16_kernel (tile code 6 on a 'bf16y' launch: y bf16 in memory beside the fp32 clip -- the weight gradient of
+    D's dc1 and of G's dc5 in bf16 networks, model/net.py:148,189 / :114 backwards): patch ring + y tile in LDS, both MFMA operands
+    through the transposing read.  On bf16-representable inputs every product is exact, so the kernel must equal the generic tile
+    (code 0) to fp32 summation order and the float64 oracle to the backward tolerance; Wo = 32 / 16, 3-D and 2-D, frames split over
+    blocks (5 clips x 16 frames), several batch items per block (140 clips: 560 (row block, item) pairs on 512 blocks; 600 frames)."""
+    N, Ti, H, kt = case
+    Ci, Co = 3, 64
+    rng = np.random.RandomState(7100 + N + Ti + H)
+    lay = L()
+    x = _bf16_round(rng.uniform(-1, 1, (N, Ci, Ti, H, H)))
+    gy = _bf16_round(rng.randn(N, Co, Ti - kt + 1, H // 2, H // 2))
+    xd, gyd = lay.act_to_dev(dev(x)), lay.act_to_dev(dev(gy))
+    gy16 = gyd.to(torch.bfloat16)
+    g = hl.make_geom(N, Ti, H, H, 4, Co, kt, precision='bf16y', ci_valid=3)
+    dw = {}
+    for tile in (0, 6):
+        g.tile = tile
+        dw[tile] = torch.zeros((Co, kt, 4, 4, 4), device="cuda")
+        hl.conv_wgrad(g, xd, gy16, dw[tile])
+        hl.conv_wgrad(g, xd, gy16, dw[tile])                           # dw += ...: the second launch adds onto the first
+    assert float(dw[6][..., 3].abs().max()) == 0.0                     # the padded channel has no gradient
+    assert rel_l2(dw[6], dw[0].cpu().double().numpy()) < 2e-6, case
+    if N <= 5:
+        W0 = np.zeros((Co, Ci, kt, 4, 4))
+        _, gW_ref, _ = F.conv3d_bwd(x, W0, gy, (1, 2, 2), (0, 1, 1))
+        assert rel_l2(lay.conv_w_from_dev(dw[6], Ci, 3), 2 * gW_ref) < BWD_TOL, case
+    g32 = hl.make_geom(N, Ti, H, H, 4, Co, kt, precision='bf16', ci_valid=3)
+    g32.tile = 6
+    with pytest.raises(hl.McgError):                                   # (an fp32 y under tile code 6 in a bf16 network: no such kernel)
+        hl.conv_wgrad(g32, xd, gyd, torch.zeros_like(dw[0]))
+
+
 @pytest.mark.parametrize("case", [(160, 1, 64, 3, 64, 1), (130, 5, 64, 3, 64, 4)])
 def test_first_layer_input_gradient_walks_more_tiles_than_blocks(hl, case):
     """The first-layer input-gradient kernel is persistent (round 4): at most 1024 blocks walk the (batch item, 4 output rows) tiles.
