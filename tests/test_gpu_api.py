@@ -225,7 +225,6 @@ def test_train_step_takes_the_loaders_uint8_clips(model):
     """TrainStep.run on the loader's uint8 (N,T,H,W,C) batch (mcg_pack_clip_u8 in front of both discriminators) against the same
     iteration on the reference's float (N,C,T,H,W) batch (model/updater.py:87-92): same Philox streams, same frame index -- losses
     and updated parameters agree to fp32 summation order (the weight gradients' float atomics)."""
-    import mocogan_chainer_amd.nets as nets
     import mocogan_chainer_amd.step as step
     rng = np.random.RandomState(5)
     n, nf, dim_zl = 3, 4, 6

@@ -1,7 +1,6 @@
 #!/usr/bin/env python
 """H2D copy rate of a 256-clip uint8 batch (50 MB) from (a) torch pinned memory, (b) a shared-memory segment page-locked with
 hipHostRegister (what PrefetchIterator's batch slots are), (c) the same segment not registered (pageable)."""
-import sys
 import time
 from multiprocessing import shared_memory
 
