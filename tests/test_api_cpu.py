@@ -249,7 +249,9 @@ def test_shipped_tile_table_is_well_formed():
     seen = set()
     for key, code in table:
         kind, N, Ti, Hi, Wi, Ci, Co, kt, perm, prec = key[:10]
-        assert Hi == Wi and Hi in (8, 16, 32, 64) and kt in (1, 4) and prec in (0, 1, 2, 3) and Ci % 4 == 0 and N > 0
+        assert Hi == Wi and Hi in (8, 16, 32, 64) and kt in (1, 4) and prec in (0, 1, 2, 3, 4) and Ci % 4 == 0 and N > 0
+        # (4 = MCG_PREC_BF16_Y16, round 6: the first layer's weight / input gradient of bf16 networks, y bf16 beside the fp32 clip)
+        assert prec != 4 or (kind in ('wgrad', 'dgrad') and Ci == 4 and Co == 64), (key, code)
         if kind.startswith('split-'):
             # 'f32x3' networks: does the split form (fp32 values as three bf16 terms, bf16 MFMA) of this fp32 launch pay?  (hiplib.split_pays)
             assert kind[6:] in ('fprop', 'dgrad', 'wgrad') and len(key) == 10 and prec == 0 and code in (0, 1), (key, code)
