@@ -455,6 +455,29 @@ def test_bench_self_launches_its_ranks(tmp_path):
         assert r.returncode == 2 and 'GPU(s) visible' in r.stderr
 
 
+def test_drivers_eight_rank_launch_line_reaches_one_result_line():
+    """The driver's own command for N = 8 -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1
+    --master-port P bench.py --gpus 8 --steps K --warmup W` -- with MCG_BENCH_DRYRUN=1 (no GPU here: the ranks rendezvous over gloo and
+    run the timed region's MAX all-reduce): eight ranks parse RANK / WORLD_SIZE / MASTER_*, agree on the world size, and rank 0 alone
+    prints the line.  (The GPU side of the eight-rank branch is walked by four ranks on one card: tests/test_gpu_dp.py.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MCG_BENCH_DRYRUN='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    port = 34500 + os.getpid() % 2000
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '4', '--warmup', '2'],
+                       capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 8 and line['steps'] == 4 and line['warmup'] == 2 and line['dry_run'] is True and line['max_over_ranks_check'] == 8.0
+
+
 def test_bench_stdout_line_stays_small():
     """The driver parses ONE stdout line; round 3's grew to 51 KB (tile table, per-layer tables of four workloads) and was not
     parsed.  compact_line() keeps the contract fields + config + roofline + cpu_baseline + one short record per secondary
