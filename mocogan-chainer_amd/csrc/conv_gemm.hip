@@ -2714,8 +2714,11 @@ __global__ __launch_bounds__(512) void dgrad_c4_mfma_kernel(C4DgradP p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* yl = sm;                                  // [PIX][YLD]
     float* wl = yl + PIX * YLD;                      // [KT * 48][WLD]: wl[(a * 16 + kh * 4 + kw) * 3 + ci][co]
-    float* zl = wl + KT * 48 * WLD;                  // [PIX][ZLD]
-    f32x4* al = reinterpret_cast<f32x4*>(zl + PIX * ZLD);                   // [KT][XR][WI] accumulators (x, y, z = ci 0..2)
+    // ZB (round 6): two Z buffers where LDS allows (bf16 operands, 3-D: 145 KB) -- tap a + 1's Z goes into the other buffer while tap a's is
+    // gathered, ONE barrier per temporal tap instead of two (7 instead of 10 per frame step)
+    constexpr int ZB = (BF && KT > 1) ? 2 : 1;
+    float* zl = wl + KT * 48 * WLD;                  // [ZB][PIX][ZLD]
+    f32x4* al = reinterpret_cast<f32x4*>(zl + ZB * PIX * ZLD);              // [KT][XR][WI] accumulators (x, y, z = ci 0..2)
     const Geom& g = p.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hblocks = g.Ho / R;
@@ -2842,12 +2845,13 @@ __global__ __launch_bounds__(512) void dgrad_c4_mfma_kernel(C4DgradP p) {
                     }
                 }
             }
-            if (a > 0) __syncthreads();                           // the previous tap's gather has read zl
+            if (ZB == 1 && a > 0) __syncthreads();                // the previous tap's gather has read zl (ZB == 2: it read the OTHER buffer;
+            float* zb = zl + (ZB == 2 ? (a & 1) * PIX * ZLD : 0);  //  this one was last read two taps ago, a barrier behind)
             // D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + reg
 #pragma unroll
             for (int cb = 0; cb < 3; ++cb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) zl[(wave * 16 + kq * 4 + r) * ZLD + cb * 16 + li] = zc[cb][r];
+                for (int r = 0; r < 4; ++r) zb[(wave * 16 + kq * 4 + r) * ZLD + cb * 16 + li] = zc[cb][r];
             __syncthreads();
             const int slot = (to + a) % KT;
 #pragma unroll
@@ -2857,7 +2861,7 @@ __global__ __launch_bounds__(512) void dgrad_c4_mfma_kernel(C4DgradP p) {
                 f32x4 v = al[slot * NPX + px];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (gz[q][k] >= 0) { const float* z = zl + gz[q][k]; v[0] += z[0]; v[1] += z[1]; v[2] += z[2]; }
+                    if (gz[q][k] >= 0) { const float* z = zb + gz[q][k]; v[0] += z[0]; v[1] += z[1]; v[2] += z[2]; }
                 al[slot * NPX + px] = v;
             }
         }
@@ -3058,7 +3062,7 @@ int launch_dgrad_c4_mfma(const Geom& g, const float* y, const float* w, float* x
     C4DgradP p;
     p.g = g; p.y = y; p.w = w; p.x = x;
     constexpr int R = 128 / WO, NPX = (2 * R + 2) * 2 * WO, LD = BF ? 40 : 68;
-    const size_t lds = (size_t)(128 * LD + KT * 48 * LD + 128 * 52) * 4 + (size_t)KT * NPX * 16;
+    const size_t lds = (size_t)(128 * LD + KT * 48 * LD + ((BF && KT > 1) ? 2 : 1) * 128 * 52) * 4 + (size_t)KT * NPX * 16;
     static std::once_flag once;
     hipError_t attr = hipSuccess;
     std::call_once(once, [&] { attr = hipFuncSetAttribute((const void*)dgrad_c4_mfma_kernel<KT, WO, BF, Y16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
